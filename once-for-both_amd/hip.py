@@ -1,0 +1,107 @@
+"""ctypes binding of libofb_hip.so (C ABI: include/ofb_hip.h).
+
+PyTorch is used only as plumbing here: device buffers (`data_ptr()`), the current HIP stream
+and the caching allocator.  All arithmetic happens inside the library's kernels.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libofb_hip.so')
+_lib = None
+
+
+class OfbError(RuntimeError):
+    pass
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [
+        ('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p),
+        ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+        ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32),
+        ('a_kc', C.c_int32), ('b_kc', C.c_int32),
+        ('alpha', C.c_float),
+        ('bias', C.c_void_p), ('colscale', C.c_void_p),
+        ('rowscale', C.c_void_p), ('rs_div', C.c_int32),
+        ('resid', C.c_void_p), ('ldr', C.c_int32),
+        ('aux', C.c_void_p), ('ldaux', C.c_int32),
+        ('act', C.c_int32),
+        ('kscale', C.c_void_p), ('ks_div', C.c_int32),
+        ('split_k', C.c_int32), ('workspace', C.c_void_p),
+    ]
+
+
+ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+
+# every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
+SYMBOLS = [
+    'ofb_gemm_f32', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+]
+
+
+def lib():
+    """Load the HIP library or fail loudly (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OfbError(f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                           '(hipcc --offload-arch=gfx950). once-for-both_amd has no CPU fallback.')
+        _lib = C.CDLL(LIB_PATH)
+        for s in SYMBOLS:
+            getattr(_lib, s).restype = C.c_int
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise OfbError(f'{what} failed with code {rc}' + (' (rejected arguments)' if rc < 0 else ' (hipError_t)'))
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise OfbError('once-for-both_amd kernels need device tensors (no CPU fallback); got a CPU tensor')
+    if t.dtype != torch.float32 and t.dtype not in (torch.int64, torch.int32, torch.uint8, torch.bool):
+        raise OfbError(f'unsupported dtype {t.dtype}')
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _f32c(t, name):
+    if t is not None and (t.dtype != torch.float32 or not t.is_contiguous()):
+        raise OfbError(f'{name} must be a contiguous float32 tensor')
+    return t
+
+
+def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kc, b_kc, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
+         resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, kscale=None, ks_div=1, split_k=1, workspace=None):
+    g = GemmArgs()
+    g.A, g.B, g.C = ptr(A), ptr(B), ptr(C_out)
+    g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
+    g.a_kc, g.b_kc, g.alpha = int(a_kc), int(b_kc), alpha
+    g.bias, g.colscale, g.rowscale, g.rs_div = ptr(bias), ptr(colscale), ptr(rowscale), rs_div
+    g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
+    g.kscale, g.ks_div, g.split_k, g.workspace = ptr(kscale), ks_div, split_k, ptr(workspace)
+    check(lib().ofb_gemm_f32(C.byref(g), stream()), 'ofb_gemm_f32')
+
+
+def splitk_reduce(ws, splits, count, out, accumulate=False):
+    check(lib().ofb_splitk_reduce(ptr(ws), C.c_int32(splits), C.c_int64(count), ptr(out), C.c_int32(int(accumulate)),
+                                  stream()), 'ofb_splitk_reduce')
+
+
+def prof_enable(on):
+    check(lib().ofb_prof_enable(C.c_int32(int(on))), 'ofb_prof_enable')
+
+
+def prof_collect(ntags=8):
+    buf = (C.c_double * (ntags * 3))()
+    check(lib().ofb_prof_collect(buf, C.c_int32(ntags)), 'ofb_prof_collect')
+    return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(ntags)]

@@ -1,0 +1,96 @@
+"""HIP f32-MFMA GEMM (through the C ABI) vs an fp64 CPU product on the same seeded inputs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, seed):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32)
+
+
+def _check(got, exp, tol=2e-6, what=''):
+    err = (got.double().cpu() - exp).abs().max().item()
+    scale = exp.abs().max().item() + 1e-30
+    print(f'{what}: max abs err {err:.3e} (scale {scale:.3e})')
+    assert err <= tol * scale * 40, what
+
+
+# (M, N, K): exact tiles, ragged edges, K not multiple of 16, tiny, pruned-style dims (multiples of 12 / 6), scalar path
+SHAPES = [(256, 256, 64), (394, 384, 384), (197 * 3, 1152, 384), (130, 70, 36), (128, 1000, 384), (77, 13, 5),
+          (591, 288, 204), (200, 102, 102)]
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_gemm_nt_epilogues(M, N, K):
+    from ofb_amd import hip
+    x, w, b = _mk((M, K), 1), _mk((N, K), 2), _mk((N,), 3)
+    cs, res = _mk((N,), 4), _mk((M, N), 5)
+    rs = _mk(((M + 196) // 197,), 6)
+    xd, wd, bd, csd, resd, rsd = (t.cuda() for t in (x, w, b, cs, res, rs))
+    out = torch.empty(M, N, device='cuda')
+    # plain x @ W^T + b
+    hip.gemm(xd, wd, out, M, N, K, K, K, N, 1, 1, bias=bd)
+    ref = x.double() @ w.double().t() + b.double()
+    _check(out, ref, what=f'nt bias {M}x{N}x{K}')
+    # gate column scale + GELU (+ pre-activation side output)
+    aux = torch.empty(M, N, device='cuda')
+    hip.gemm(xd, wd, out, M, N, K, K, K, N, 1, 1, bias=bd, colscale=csd, aux=aux, ldaux=N, act=hip.ACT_GELU)
+    pre = ref * cs.double()
+    _check(aux, pre, what='gelu pre-activation')
+    _check(out, torch.nn.functional.gelu(pre), what='gelu out')
+    # residual + per-sample row scale
+    hip.gemm(xd, wd, out, M, N, K, K, K, N, 1, 1, bias=bd, rowscale=rsd, rs_div=197, resid=resd, ldr=N)
+    rows = torch.arange(M) // 197
+    _check(out, ref * rs.double()[rows].unsqueeze(1) + res.double(), what='residual+rowscale')
+    # DGELU multiply
+    hip.gemm(xd, wd, out, M, N, K, K, K, N, 1, 1, aux=aux, ldaux=N, act=hip.ACT_DGELU)
+    p = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(p).sum().backward()
+    _check(out, (x.double() @ w.double().t()) * p.grad, what='dgelu')
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_gemm_nn_and_tn(M, N, K):
+    """dX = dY @ W (a_kc=1,b_kc=0) and dW = dY^T @ X (a_kc=0,b_kc=0, split-K over tokens)."""
+    from ofb_amd import hip
+    dy, w, x = _mk((M, N), 7), _mk((N, K), 8), _mk((M, K), 9)
+    dyd, wd, xd = dy.cuda(), w.cuda(), x.cuda()
+    dx = torch.empty(M, K, device='cuda')
+    hip.gemm(dyd, wd, dx, M, K, N, N, K, K, 1, 0)
+    _check(dx, dy.double() @ w.double(), what=f'nn {M}x{K}x{N}')
+    ks = _mk(((M + 196) // 197,), 10)
+    rows = torch.arange(M) // 197
+    exp = (dy.double() * ks.double()[rows].unsqueeze(1)).t() @ x.double()
+    for split in (1, 3, 8):
+        dw = torch.empty(N, K, device='cuda')
+        if split == 1:
+            hip.gemm(dyd, xd, dw, N, K, M, N, K, K, 0, 0, kscale=ks.cuda(), ks_div=197)
+        else:
+            ws = torch.empty(split, N, K, device='cuda')
+            hip.gemm(dyd, xd, None, N, K, M, N, K, K, 0, 0, kscale=ks.cuda(), ks_div=197, split_k=split, workspace=ws)
+            hip.splitk_reduce(ws, split, N * K, dw)
+        _check(dw, exp, what=f'tn split{split} {N}x{K}x{M}')
+
+
+def test_gemm_deit_small_shapes():
+    """The real bs=128 DeiT-S layer shapes (25216 tokens): compare a strided sample of rows with fp64."""
+    from ofb_amd import hip
+    M, D = 128 * 197, 384
+    for N in (1152, 384, 1536):
+        x, w, b = _mk((M, D), 11), _mk((N, D), 12) * 0.05, _mk((N,), 13)
+        out = torch.empty(M, N, device='cuda')
+        hip.gemm(x.cuda(), w.cuda(), out, M, N, D, D, D, N, 1, 1, bias=b.cuda())
+        rows = torch.arange(0, M, 97)
+        ref = x[rows].double() @ w.double().t() + b.double()
+        _check(out[rows.cuda()], ref, what=f'deit-s {N}')
+
+
+def test_gemm_rejects_bad_arguments():
+    from ofb_amd import hip
+    a = torch.zeros(4, 4, device='cuda')
+    with pytest.raises(hip.OfbError):
+        hip.gemm(a, a, a, 4, 4, 4, 2, 4, 4, 1, 1)        # lda < K
+    with pytest.raises(hip.OfbError):
+        hip.gemm(a.cpu(), a, a, 4, 4, 4, 4, 4, 4, 1, 1)  # CPU tensor: no fallback
