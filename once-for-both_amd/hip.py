@@ -39,6 +39,8 @@ ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
     'ofb_gemm_f32', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_layernorm_fwd', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_colsum_slabs', 'ofb_colsum',
+    'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd',
 ]
 
 
@@ -105,3 +107,55 @@ def prof_collect(ntags=8):
     buf = (C.c_double * (ntags * 3))()
     check(lib().ofb_prof_collect(buf, C.c_int32(ntags)), 'ofb_prof_collect')
     return [(buf[3 * i], buf[3 * i + 1], buf[3 * i + 2]) for i in range(ntags)]
+
+
+def _i(v):
+    return C.c_int32(int(v))
+
+
+def _f(v):
+    return C.c_float(float(v))
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps):
+    check(lib().ofb_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), _i(rows), _i(D), _f(eps),
+                                  stream()), 'ofb_layernorm_fwd')
+
+
+def layernorm_bwd_blocks(rows):
+    return int(lib().ofb_layernorm_bwd_blocks(_i(rows)))
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dres, dx, partials, rows, D):
+    check(lib().ofb_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(partials),
+                                  _i(rows), _i(D), stream()), 'ofb_layernorm_bwd')
+
+
+def colsum_slabs(M, N):
+    return int(lib().ofb_colsum_slabs(_i(M), _i(N)))
+
+
+def colsum(x, ld, M, N, out, rowscale=None, rs_div=1):
+    slabs = colsum_slabs(M, N)
+    scratch = torch.empty(slabs * N, device=x.device, dtype=torch.float32) if slabs > 1 else None
+    check(lib().ofb_colsum(ptr(x), _i(ld), _i(M), _i(N), ptr(rowscale), _i(rs_div), ptr(out), ptr(scratch), stream()),
+          'ofb_colsum')
+
+
+def scale_rows(W, g, out, N, K):
+    check(lib().ofb_scale_rows(ptr(W), ptr(g), ptr(out), _i(N), _i(K), stream()), 'ofb_scale_rows')
+
+
+def gate_fold_bwd(dWraw, W, g, dbraw, b, dW, db, dg, N, K):
+    check(lib().ofb_gate_fold_bwd(ptr(dWraw), ptr(W), ptr(g), ptr(dbraw), ptr(b), ptr(dW), ptr(db), ptr(dg), _i(N), _i(K),
+                                  stream()), 'ofb_gate_fold_bwd')
+
+
+def attention_fwd(qkv, out, lse, B, N, H, dh, scale):
+    check(lib().ofb_attention_fwd(ptr(qkv), ptr(out), ptr(lse), _i(B), _i(N), _i(H), _i(dh), _f(scale), stream()),
+          'ofb_attention_fwd')
+
+
+def attention_bwd(qkv, out, lse, dout, dqkv, B, N, H, dh, scale):
+    check(lib().ofb_attention_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), _i(B), _i(N), _i(H), _i(dh),
+                                  _f(scale), stream()), 'ofb_attention_bwd')

@@ -1,0 +1,75 @@
+"""Fused attention core (forward + backward) vs the fp64 definition softmax(q k^T * scale) v."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(qkv, B, N, H, dh, scale, dout):
+    x = qkv.double().reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4).detach().requires_grad_(True)
+    q, k, v = x[0], x[1], x[2]
+    s = (q @ k.transpose(-2, -1)) * scale
+    p = torch.softmax(s, -1)
+    o = (p @ v).transpose(1, 2).reshape(B * N, H * dh)
+    lse = torch.logsumexp(s, -1)
+    o.backward(dout.double())
+    dqkv = x.grad.permute(1, 3, 0, 2, 4).reshape(B * N, 3 * H * dh)
+    return o.detach(), lse.detach().reshape(B * H, N), dqkv
+
+
+# (B, N, H, dh): DeiT-S/T/B head shapes, pruned head dims, short and maximal sequences
+CASES = [(2, 197, 6, 64), (3, 197, 3, 64), (2, 197, 4, 40), (1, 197, 2, 16), (2, 50, 2, 32), (1, 224, 2, 64), (2, 33, 1, 24),
+         (1, 1, 1, 8)]
+
+
+@pytest.mark.parametrize('B,N,H,dh', CASES)
+def test_attention_fwd_bwd(B, N, H, dh):
+    from ofb_amd import hip
+    g = torch.Generator().manual_seed(B * 1000 + N + H + dh)
+    qkv = torch.randn(B * N, 3 * H * dh, generator=g) * 1.5
+    dout = torch.randn(B * N, H * dh, generator=g)
+    scale = 0.125
+    o_ref, lse_ref, dqkv_ref = _ref(qkv, B, N, H, dh, scale, dout)
+    qd = qkv.cuda()
+    o = torch.empty(B * N, H * dh, device='cuda')
+    lse = torch.empty(B * H, N, device='cuda')
+    hip.attention_fwd(qd, o, lse, B, N, H, dh, scale)
+    e_o = (o.cpu().double() - o_ref).abs().max().item()
+    e_l = (lse.cpu().double() - lse_ref).abs().max().item()
+    print(f'attn fwd B{B} N{N} H{H} d{dh}: out err {e_o:.2e} lse err {e_l:.2e}')
+    assert e_o < 2e-5 and e_l < 2e-5
+    dqkv = torch.full((B * N, 3 * H * dh), float('nan'), device='cuda')
+    hip.attention_bwd(qd, o, lse, dout.cuda(), dqkv, B, N, H, dh, scale)
+    err = (dqkv.cpu().double() - dqkv_ref).abs()
+    Hd = H * dh
+    print(f'attn bwd: dq {err[:, :Hd].max():.2e} dk {err[:, Hd:2*Hd].max():.2e} dv {err[:, 2*Hd:].max():.2e} '
+          f'(scale {dqkv_ref.abs().max():.2e})')
+    assert not torch.isnan(dqkv).any()
+    assert err.max().item() < 5e-5 * max(1.0, dqkv_ref.abs().max().item())
+
+
+def test_attention_peaked_softmax():
+    """one key dominates each row (large logits): exercises the max-subtraction path."""
+    from ofb_amd import hip
+    B, N, H, dh = 1, 197, 2, 64
+    g = torch.Generator().manual_seed(5)
+    qkv = torch.randn(B * N, 3 * H * dh, generator=g)
+    qkv[:, :H * dh] *= 12.0
+    dout = torch.randn(B * N, H * dh, generator=g)
+    o_ref, lse_ref, dqkv_ref = _ref(qkv, B, N, H, dh, 0.125, dout)
+    o = torch.empty(B * N, H * dh, device='cuda')
+    lse = torch.empty(B * H, N, device='cuda')
+    hip.attention_fwd(qkv.cuda(), o, lse, B, N, H, dh, 0.125)
+    assert (o.cpu().double() - o_ref).abs().max().item() < 5e-5
+    dqkv = torch.empty(B * N, 3 * H * dh, device='cuda')
+    hip.attention_bwd(qkv.cuda(), o, lse, dout.cuda(), dqkv, B, N, H, dh, 0.125)
+    assert (dqkv.cpu().double() - dqkv_ref).abs().max().item() < 2e-4 * dqkv_ref.abs().max().item()
+
+
+def test_attention_rejects_unsupported():
+    from ofb_amd import hip
+    t = torch.zeros(300 * 192, device='cuda')
+    with pytest.raises(hip.OfbError):
+        hip.attention_fwd(t, t, t, 1, 300, 1, 64, 0.125)     # N > 224
+    with pytest.raises(hip.OfbError):
+        hip.attention_fwd(t, t, t, 1, 100, 1, 30, 0.125)     # dh % 4 != 0
