@@ -110,6 +110,106 @@ int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32
 int ofb_attention_bwd(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv, int32_t B,
                       int32_t N, int32_t H, int32_t dh, float scale, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Bi-mask gates of ALL searchable modules in one launch + adaptive one-hot (sparsity) loss + FLOPs loss.
+ *   g[h][c] = w_p*sigmoid(score[h][c]) + (1-w_p)*wm[rank_h[h]][rank_c[h][c]],
+ *   wm[h][c] = sum_{cells(i,j) on} softmax(alpha)[i][j] * [h < head_thr[i]] * [c < chan_thr[j]]
+ * Replaces the per-forward gate micro-ops of MAEPatchEmbed.forward (models/layers.py:179-191),
+ * MAESparseAttention.forward (:494-509), MAESparseMlp.forward (:847-858), the get_weight() re-computation
+ * (:211-216, :548-557, :876-881), MAEBaseModel.get_sparsity_loss / get_flops_loss (models/base_model.py:31-86)
+ * and MIMVisionTransformer.get_flops (models/vision_transformer.py:759-783).
+ * The host keeps one descriptor per module in a device array.  1-D modules (mlp, embed) use H = 1, A0 = 1,
+ * head_thr = {1}.  Limits: A0 <= 8, A1 <= 40, A0*A1 <= 64, H <= 16.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ofb_gate_desc {
+  const float* alpha;        /* [A0*A1] */
+  const float* score;        /* [H*C]   */
+  float* g; float* wr; float* wm;   /* [H*C] gate, restored staircase (weight_restore), staircase (weighted_mask) */
+  float* prob;               /* [A0*A1] softmax(alpha) over the "on" cells */
+  float* wsum;               /* [1] sum of wm (input of the FLOPs model) */
+  float* loss_alpha;         /* [1] entropy + variance terms of this module's one-hot loss */
+  float* dloss_dalpha;       /* [A0*A1] their gradient wrt alpha */
+  float* sig_partial;        /* [ceil(H*C/256)] per-block sums of sigmoid(score) */
+  int32_t* rank;             /* [H*C] (rank_h << 16) | rank_c */
+  int32_t H, C, A0, A1;
+  int32_t kind;              /* 0 attention, 1 mlp, 2 embed (loss bucket) */
+  float w_p;
+  float norm_coef;           /* 4e-4 attention, 1e-4 otherwise (base_model.py:74-78) */
+  int32_t head_thr[8];
+  int32_t chan_thr[40];
+  uint8_t on[64];            /* switch_cell */
+} ofb_gate_desc;
+
+typedef struct ofb_gate_grad {
+  const float* dg;           /* [H*C] or null */
+  const float* dwr;          /* [H*C] or null */
+  const float* dwm;          /* [H*C] or null */
+  const float* dwsum;        /* [1] or null */
+  const float* dspars;       /* [1] or null: d total / d (this module's sparsity loss) */
+  float* dalpha;             /* [A0*A1] */
+  float* dscore;             /* [H*C] */
+} ofb_gate_grad;
+
+typedef struct ofb_flops_cfg {
+  int32_t num_patches, embed_dim, num_heads, head_dim, hidden, patch_area, num_classes, depth;
+  float target;              /* target GMACs */
+  const int32_t* active_heads;   /* [depth] device array or null (= num_heads) */
+} ofb_flops_cfg;
+
+/* spars_out[3] = {attn, mlp, embed} sums, spars_per_module[n_modules]; max_elems = max H*C over modules. */
+int ofb_gates_fwd(const ofb_gate_desc* descs_dev, int32_t n_modules, int32_t max_elems, int32_t entropy, int32_t var,
+                  int32_t norm, float* spars_out, float* spars_per_module, void* stream);
+int ofb_gates_bwd(const ofb_gate_desc* descs_dev, const ofb_gate_grad* grads_dev, int32_t n_modules, void* stream);
+/* wsum[1+2*depth] = {embed, attn_0, mlp_0, ...}; out3 = {((searched-target)/total)^2, total, searched};
+ * dwsum = d out3[0] / d wsum. */
+int ofb_flops_loss(const float* wsum, const ofb_flops_cfg* cfg, float* out3, float* dwsum, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Token assembly after the patch-embedding conv (models/vision_transformer.py:615-651, gate of
+ * models/layers.py:191 factored out):
+ *   tokens[b][0]   = g * (cls + pos[0]);  tokens[b][1+l] = g * ((conv[b][l] + pos[1+l])*(1-m[b][l]) + m[b][l]*mask_token)
+ * conv: [B*L][D] UNGATED conv output (+bias); g/mask_token/mask may be null (no gate / no masking).
+ * bwd writes dconv [B*L][D] and per-chunk partial sums ppos/pg/pmt, each [chunks][L+1][D] with
+ * chunks = ofb_embed_assemble_chunks(B): dpos = sum_z ppos, dcls = dpos[0], dg = sum_{z,t} pg, dmask_token = sum pmt.
+ * ------------------------------------------------------------------------------------------- */
+int ofb_embed_assemble_fwd(const float* conv, const float* g, const float* pos, const float* cls, const float* mask_token,
+                           const float* mask, float* tokens, int32_t B, int32_t L, int32_t D, void* stream);
+int32_t ofb_embed_assemble_chunks(int32_t B);
+int ofb_embed_assemble_bwd(const float* dtokens, const float* conv, const float* g, const float* pos, const float* cls,
+                           const float* mask_token, const float* mask, float* dconv, float* ppos, float* pg, float* pmt,
+                           int32_t B, int32_t L, int32_t D, void* stream);
+
+/* norm_targets(imgs, 47) (models/vision_transformer.py:121-141): (x-mean)/sqrt(max(var*cnt/(cnt-1),0)+1e-6) with
+ * 47x47 box statistics, count_include_pad=False.  imgs/out/scratch1/scratch2: [planes][H][W]. */
+int ofb_norm_targets(const float* imgs, float* out, float* scratch1, float* scratch2, int32_t planes, int32_t Hh, int32_t Ww,
+                     int32_t ksize, void* stream);
+
+/* PMIM masked L1 loss (models/vision_transformer.py:724-729) evaluated in PATCH layout: rec [B*L][C*P*P] is the
+ * decoder 1x1-conv output before PixelShuffle (channel c*P*P+i*P+j <-> pixel (c, P*py+i, P*px+j)), targets
+ * [B][C][P*gw][P*gw], mask [B*L] in {0,1}.  out2 = {loss, 1/((sum(mask)*P*P+1e-5)*C)}; partial: [B*L] scratch.
+ * bwd: drec = upstream[0] * out2[1] * sign(rec - target) * mask. */
+int ofb_pmim_loss_fwd(const float* rec, const float* targets, const float* mask, float* partial, float* out2, int32_t B,
+                      int32_t L, int32_t P, int32_t C, void* stream);
+int ofb_pmim_loss_bwd(const float* rec, const float* targets, const float* mask, const float* out2, const float* upstream,
+                      float* drec, int32_t B, int32_t L, int32_t P, int32_t C, void* stream);
+
+/* Label-smoothing cross entropy (timm LabelSmoothingCrossEntropy as used by search.py:584 / losses.py:38):
+ * loss[0] = mean_b[(1-s)*nll + s*mean_c(-logp)]; grad [B][C] = d loss / d logits; row_loss [B] scratch. */
+int ofb_ls_cross_entropy(const float* logits, const int64_t* labels, float* row_loss, float* loss, float* grad, int32_t B,
+                         int32_t C, float smoothing, void* stream);
+
+/* Per-sample random patch masking (models/vision_transformer.py:586-612): mask[b][l] = 0 for the len_keep patches
+ * with the smallest noise[b][.], 1 for the rest (== gather(mask, argsort(argsort(noise)))). */
+int ofb_patch_mask(const float* noise, float* mask, int32_t B, int32_t L, int32_t len_keep, void* stream);
+
+/* out = x * scalar_dev[0] (chains a device-resident upstream gradient without a host sync) */
+int ofb_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream);
+
+/* Multi-tensor AdamW, one launch per parameter group (optim.py:56-120): decoupled decay, bias-corrected Adam. */
+typedef struct ofb_adamw_tensor { float* p; const float* g; float* m; float* v; int64_t n; } ofb_adamw_tensor;
+int ofb_adamw_step(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,380 @@
+// Token assembly around the patch embedding, PMIM targets/loss, label-smoothing CE and multi-tensor AdamW.
+#include "ofb_common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------------
+// tokens[b][0][c]   = g[c] * (cls[c] + pos[0][c])
+// tokens[b][1+l][c] = g[c] * ((conv[b][l][c] + pos[1+l][c]) * (1 - m[b][l]) + m[b][l] * mask_token[c])
+// (models/vision_transformer.py:615-651 with the embed gate of layers.py:191 factored out of every term)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_assemble_fwd_kernel(const float* __restrict__ conv, const float* __restrict__ g,
+                                                                 const float* __restrict__ pos, const float* __restrict__ cls,
+                                                                 const float* __restrict__ mtok, const float* __restrict__ mask,
+                                                                 float* __restrict__ tok, int B, int L, int D) {
+  const int row = blockIdx.x;               // b*(L+1) + t
+  const int b = row / (L + 1), t = row % (L + 1);
+  const float m = (t > 0 && mask) ? mask[b * L + t - 1] : 0.f;
+  for (int c = threadIdx.x; c < D; c += 256) {
+    float v;
+    if (t == 0) v = cls[c] + pos[c];
+    else v = (conv[((size_t)b * L + t - 1) * D + c] + pos[(size_t)t * D + c]) * (1.0f - m) + m * (mtok ? mtok[c] : 0.f);
+    tok[(size_t)row * D + c] = (g ? g[c] : 1.0f) * v;
+  }
+}
+
+// grid (L+1, chunks): block (t, z) sweeps its batch chunk.  Writes dconv rows and per-(chunk) partials:
+//   ppos[z][t][c] (-> dpos, dcls), pg[z*(L+1)+t][c] (-> dg), pmt[z*(L+1)+t][c] (-> dmask_token)
+__global__ __launch_bounds__(256) void embed_assemble_bwd_kernel(const float* __restrict__ dtok, const float* __restrict__ conv,
+                                                                 const float* __restrict__ g, const float* __restrict__ pos,
+                                                                 const float* __restrict__ cls, const float* __restrict__ mtok,
+                                                                 const float* __restrict__ mask, float* __restrict__ dconv,
+                                                                 float* __restrict__ ppos, float* __restrict__ pg,
+                                                                 float* __restrict__ pmt, int B, int L, int D, int bchunk) {
+  const int t = blockIdx.x, z = blockIdx.y;
+  const int b0 = z * bchunk, b1 = min(B, b0 + bchunk);
+  for (int c = threadIdx.x; c < D; c += 256) {
+    const float gc = g ? g[c] : 1.0f, pc = pos[(size_t)t * D + c];
+    const float mt = mtok ? mtok[c] : 0.f, cl = (t == 0) ? cls[c] : 0.f;
+    float apos = 0.f, ag = 0.f, amt = 0.f;
+    for (int b = b0; b < b1; ++b) {
+      const float d = dtok[((size_t)b * (L + 1) + t) * D + c];
+      if (t == 0) {
+        apos += d * gc;
+        ag += d * (cl + pc);
+      } else {
+        const float m = mask ? mask[b * L + t - 1] : 0.f;
+        const size_t ci = ((size_t)b * L + t - 1) * D + c;
+        const float cv = conv[ci];
+        const float dk = d * gc * (1.0f - m);
+        dconv[ci] = dk;
+        apos += dk;
+        amt += d * gc * m;
+        ag += d * ((cv + pc) * (1.0f - m) + m * mt);
+      }
+    }
+    const size_t o = ((size_t)z * (L + 1) + t) * D + c;
+    ppos[o] = apos; pg[o] = ag; pmt[o] = amt;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// norm_targets (models/vision_transformer.py:121-141): 47x47 box statistics, count_include_pad=False.
+// pass 1: horizontal zero-padded window sums of v and v^2; pass 2: vertical sums + normalisation.
+// ---------------------------------------------------------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void box_h_kernel(const float* __restrict__ img, float* __restrict__ s1, float* __restrict__ s2,
+                                                    int planes, int Hh, int Ww) {
+  constexpr int R = K / 2, SPAN = 8 + K - 1;
+  const int segs = (Ww + 7) / 8;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)planes * Hh * segs) return;
+  const int seg = (int)(id % segs);
+  const int64_t rowid = id / segs;
+  const float* row = img + rowid * Ww;
+  const int x0 = seg * 8;
+  float v[SPAN];
+#pragma unroll
+  for (int k = 0; k < SPAN; ++k) {
+    const int x = x0 - R + k;
+    v[k] = (x >= 0 && x < Ww) ? row[x] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { a += v[i + k]; q += v[i + k] * v[i + k]; }
+    if (x0 + i < Ww) { s1[rowid * Ww + x0 + i] = a; s2[rowid * Ww + x0 + i] = q; }
+  }
+}
+
+template <int K>
+__global__ __launch_bounds__(256) void box_v_norm_kernel(const float* __restrict__ img, const float* __restrict__ s1,
+                                                         const float* __restrict__ s2, float* __restrict__ out, int planes,
+                                                         int Hh, int Ww) {
+  constexpr int R = K / 2, SPAN = 8 + K - 1;
+  const int segs = (Hh + 7) / 8;
+  const int64_t id = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (id >= (int64_t)planes * segs * Ww) return;
+  const int x = (int)(id % Ww);
+  const int seg = (int)((id / Ww) % segs);
+  const int64_t plane = id / ((int64_t)Ww * segs);
+  const float* p1 = s1 + plane * Hh * Ww;
+  const float* p2 = s2 + plane * Hh * Ww;
+  const int y0 = seg * 8;
+  float a[SPAN], q[SPAN];
+#pragma unroll
+  for (int k = 0; k < SPAN; ++k) {
+    const int y = y0 - R + k;
+    const bool in = (y >= 0 && y < Hh);
+    a[k] = in ? p1[(size_t)y * Ww + x] : 0.f;
+    q[k] = in ? p2[(size_t)y * Ww + x] : 0.f;
+  }
+  const float cx = (float)(min(x + R, Ww - 1) - max(x - R, 0) + 1);
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int y = y0 + i;
+    if (y >= Hh) break;
+    float sa = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { sa += a[i + k]; sq += q[i + k]; }
+    const float cnt = cx * (float)(min(y + R, Hh - 1) - max(y - R, 0) + 1);
+    const float mean = sa / cnt, sqm = sq / cnt;
+    float var = (sqm - mean * mean) * (cnt / (cnt - 1.0f));
+    var = fmaxf(var, 0.f);
+    const size_t o = (size_t)plane * Hh * Ww + (size_t)y * Ww + x;
+    out[o] = (img[o] - mean) / sqrtf(var + 1.e-6f);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// PMIM masked L1 (vision_transformer.py:724-729) in PATCH layout: rec[b*L+l][c*P*P + i*P + j] is pixel
+// (c, P*py+i, P*px+j) after PixelShuffle.  One block per patch; unmasked patches contribute exactly 0.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pmim_loss_fwd_kernel(const float* __restrict__ rec, const float* __restrict__ tgt,
+                                                            const float* __restrict__ mask, float* __restrict__ partial,
+                                                            int L, int gw, int P, int C, int img) {
+  __shared__ float red[4];
+  const int patch = blockIdx.x, b = patch / L, l = patch % L, py = l / gw, px = l % gw;
+  const float m = mask[patch];
+  float s = 0.f;
+  if (m != 0.f) {
+    const int PP = P * P;
+    for (int o = threadIdx.x; o < C * PP; o += 256) {
+      const int c = o / PP, i = (o % PP) / P, j = o % P;
+      const float t = tgt[(((size_t)b * C + c) * img + (py * P + i)) * img + px * P + j];
+      s += fabsf(t - rec[(size_t)patch * C * PP + o]) * m;
+    }
+  }
+  s = ofb_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[patch] = red[0] + red[1] + red[2] + red[3];
+}
+
+// out[0] = sum(partial) / (sum(mask) + 1e-5) / C ; out[1] = 1 / ((sum(mask)*P*P + 1e-5) * C)  (gradient scale)
+__global__ __launch_bounds__(1024) void pmim_loss_final_kernel(const float* __restrict__ partial, const float* __restrict__ mask,
+                                                               int n, int PP, int C, float* __restrict__ out) {
+  __shared__ float r1[16], r2[16];
+  float s = 0.f, ms = 0.f;
+  for (int i = threadIdx.x; i < n; i += 1024) { s += partial[i]; ms += mask[i]; }
+  s = ofb_wave_sum(s); ms = ofb_wave_sum(ms);
+  if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s; r2[threadIdx.x >> 6] = ms; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float S = 0.f, M = 0.f;
+    for (int k = 0; k < 16; ++k) { S += r1[k]; M += r2[k]; }
+    const float denom = (M * (float)PP + 1e-5f) * (float)C;      // mask is upsampled PxP before the sum (:724-725,729)
+    out[0] = S / denom;
+    out[1] = 1.0f / denom;
+  }
+}
+
+// drec = upstream * scale * sign(rec - tgt) * m
+__global__ __launch_bounds__(256) void pmim_loss_bwd_kernel(const float* __restrict__ rec, const float* __restrict__ tgt,
+                                                            const float* __restrict__ mask, const float* __restrict__ scale2,
+                                                            const float* __restrict__ upstream, float* __restrict__ drec,
+                                                            int L, int gw, int P, int C, int img) {
+  const int patch = blockIdx.x, b = patch / L, l = patch % L, py = l / gw, px = l % gw;
+  const float m = mask[patch];
+  const int PP = P * P;
+  const float k = scale2[1] * upstream[0] * m;
+  for (int o = threadIdx.x; o < C * PP; o += 256) {
+    float d = 0.f;
+    if (m != 0.f) {
+      const int c = o / PP, i = (o % PP) / P, j = o % P;
+      const float t = tgt[(((size_t)b * C + c) * img + (py * P + i)) * img + px * P + j];
+      const float r = rec[(size_t)patch * C * PP + o];
+      d = (r > t) ? k : ((r < t) ? -k : 0.f);
+    }
+    drec[(size_t)patch * C * PP + o] = d;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// label-smoothing cross entropy (timm LabelSmoothingCrossEntropy; search.py:584 via losses.py:38):
+// loss = mean_b[(1-s)*(lse - x_y) + s*(lse - mean_c x)]; grad (unscaled by upstream) stored alongside.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ls_ce_kernel(const float* __restrict__ logits, const int64_t* __restrict__ labels,
+                                                    float* __restrict__ row_loss, float* __restrict__ grad, int Bn, int Cn,
+                                                    float smoothing) {
+  __shared__ float red[4];
+  __shared__ float bc[2];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const float* x = logits + (size_t)b * Cn;
+  float m = -INFINITY, sx = 0.f;
+  for (int c = t; c < Cn; c += 256) { m = fmaxf(m, x[c]); sx += x[c]; }
+  m = ofb_wave_max(m);
+  if ((t & 63) == 0) red[t >> 6] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  float se = 0.f;
+  for (int c = t; c < Cn; c += 256) se += expf(x[c] - m);
+  se = ofb_wave_sum(se); sx = ofb_wave_sum(sx);
+  if ((t & 63) == 0) red[t >> 6] = se;
+  __syncthreads();
+  if (t == 0) bc[0] = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  if ((t & 63) == 0) red[t >> 6] = sx;
+  __syncthreads();
+  if (t == 0) bc[1] = red[0] + red[1] + red[2] + red[3];
+  __syncthreads();
+  const float lse = m + logf(bc[0]);
+  const int y = (int)labels[b];
+  if (t == 0) row_loss[b] = (1.0f - smoothing) * (lse - x[y]) + smoothing * (lse - bc[1] / (float)Cn);
+  const float invB = 1.0f / (float)Bn;
+  for (int c = t; c < Cn; c += 256) {
+    const float p = expf(x[c] - lse);
+    grad[(size_t)b * Cn + c] = (p - (c == y ? 1.0f - smoothing : 0.f) - smoothing / (float)Cn) * invB;
+  }
+}
+
+__global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, int n, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+  s = ofb_wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) / (float)n;
+}
+
+// mask[b][l] = 1 if patch l is NOT among the len_keep smallest-noise patches of sample b (0 keep / 1 remove):
+// rank by counting == argsort(argsort(noise)) of vision_transformer.py:597-607.
+__global__ __launch_bounds__(256) void patch_mask_kernel(const float* __restrict__ noise, float* __restrict__ mask, int L,
+                                                         int len_keep) {
+  extern __shared__ float nz[];
+  const int b = blockIdx.x;
+  for (int l = threadIdx.x; l < L; l += 256) nz[l] = noise[(size_t)b * L + l];
+  __syncthreads();
+  for (int l = threadIdx.x; l < L; l += 256) {
+    const float v = nz[l];
+    int r = 0;
+    for (int k = 0; k < L; ++k) r += (nz[k] < v) || (nz[k] == v && k < l);
+    mask[(size_t)b * L + l] = (r >= len_keep) ? 1.0f : 0.0f;
+  }
+}
+
+__global__ void scale_by_scalar_kernel(const float* __restrict__ x, const float* __restrict__ s, float* __restrict__ out,
+                                       int64_t n) {
+  const float k = s[0];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[i] * k;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// multi-tensor AdamW (optim.py:56-120): p *= 1 - lr*wd; m,v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void adamw_kernel(const ofb_adamw_tensor* __restrict__ tab, float lr, float beta1, float beta2,
+                                                    float eps, float wd, float bc1, float rsqrt_bc2) {
+  const ofb_adamw_tensor tt = tab[blockIdx.y];
+  const float step = lr / bc1, decay = 1.0f - lr * wd;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tt.n; i += (int64_t)gridDim.x * 256) {
+    const float g = tt.g[i];
+    const float p = tt.p[i] * decay;
+    const float m = tt.m[i] * beta1 + g * (1.0f - beta1);
+    const float v = tt.v[i] * beta2 + g * g * (1.0f - beta2);
+    tt.m[i] = m;
+    tt.v[i] = v;
+    tt.p[i] = p - step * m / (sqrtf(v) * rsqrt_bc2 + eps);
+  }
+}
+
+}  // namespace
+
+extern "C" int ofb_embed_assemble_fwd(const float* conv, const float* g, const float* pos, const float* cls, const float* mask_token,
+                                      const float* mask, float* tokens, int32_t B, int32_t L, int32_t D, void* stream) {
+  if (!conv || !pos || !cls || !tokens || B <= 0 || L <= 0 || D <= 0) return OFB_EINVAL;
+  hipLaunchKernelGGL(embed_assemble_fwd_kernel, dim3(B * (L + 1)), dim3(256), 0, (hipStream_t)stream, conv, g, pos, cls,
+                     mask_token, mask, tokens, B, L, D);
+  return ofb_launch_status();
+}
+
+extern "C" int32_t ofb_embed_assemble_chunks(int32_t B) { return B >= 16 ? 8 : 1; }
+
+// partial buffers: ppos / pg / pmt each [chunks][(L+1)][D]
+extern "C" int ofb_embed_assemble_bwd(const float* dtokens, const float* conv, const float* g, const float* pos, const float* cls,
+                                      const float* mask_token, const float* mask, float* dconv, float* ppos, float* pg,
+                                      float* pmt, int32_t B, int32_t L, int32_t D, void* stream) {
+  if (!dtokens || !conv || !pos || !cls || !dconv || !ppos || !pg || !pmt || B <= 0 || L <= 0 || D <= 0) return OFB_EINVAL;
+  const int chunks = ofb_embed_assemble_chunks(B);
+  hipLaunchKernelGGL(embed_assemble_bwd_kernel, dim3(L + 1, chunks), dim3(256), 0, (hipStream_t)stream, dtokens, conv, g, pos,
+                     cls, mask_token, mask, dconv, ppos, pg, pmt, B, L, D, ofb_cdiv(B, chunks));
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_norm_targets(const float* imgs, float* out, float* scratch1, float* scratch2, int32_t planes, int32_t Hh,
+                                int32_t Ww, int32_t ksize, void* stream) {
+  if (!imgs || !out || !scratch1 || !scratch2 || planes <= 0 || Hh <= 0 || Ww <= 0) return OFB_EINVAL;
+  if (ksize != 47) return OFB_ELIMIT;                   // the reference hard-codes 47 (vision_transformer.py:727)
+  hipStream_t s = (hipStream_t)stream;
+  const int64_t n1 = (int64_t)planes * Hh * ((Ww + 7) / 8), n2 = (int64_t)planes * ((Hh + 7) / 8) * Ww;
+  ofb_prof_pre(5, s, 16.0 * planes * (double)Hh * Ww);
+  hipLaunchKernelGGL(box_h_kernel<47>, dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, s, imgs, scratch1, scratch2, planes, Hh, Ww);
+  hipLaunchKernelGGL(box_v_norm_kernel<47>, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, s, imgs, (const float*)scratch1,
+                     (const float*)scratch2, out, planes, Hh, Ww);
+  ofb_prof_post(5, s);
+  return ofb_launch_status();
+}
+
+// rec [B*L][C*P*P] patch layout, targets [B][C][img][img], mask [B*L] in {0,1}; partial [B*L]; out2 = {loss, grad scale}
+extern "C" int ofb_pmim_loss_fwd(const float* rec, const float* targets, const float* mask, float* partial, float* out2,
+                                 int32_t B, int32_t L, int32_t P, int32_t C, void* stream) {
+  if (!rec || !targets || !mask || !partial || !out2 || B <= 0 || L <= 0 || P <= 0 || C <= 0) return OFB_EINVAL;
+  int gw = 1;
+  while (gw * gw < L) ++gw;
+  if (gw * gw != L) return OFB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(pmim_loss_fwd_kernel, dim3(B * L), dim3(256), 0, s, rec, targets, mask, partial, L, gw, P, C, gw * P);
+  hipLaunchKernelGGL(pmim_loss_final_kernel, dim3(1), dim3(1024), 0, s, (const float*)partial, mask, B * L, P * P, C, out2);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_pmim_loss_bwd(const float* rec, const float* targets, const float* mask, const float* out2,
+                                 const float* upstream, float* drec, int32_t B, int32_t L, int32_t P, int32_t C, void* stream) {
+  if (!rec || !targets || !mask || !out2 || !upstream || !drec || B <= 0 || L <= 0) return OFB_EINVAL;
+  int gw = 1;
+  while (gw * gw < L) ++gw;
+  if (gw * gw != L) return OFB_EINVAL;
+  hipLaunchKernelGGL(pmim_loss_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, rec, targets, mask, out2, upstream,
+                     drec, L, gw, P, C, gw * P);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_ls_cross_entropy(const float* logits, const int64_t* labels, float* row_loss, float* loss, float* grad,
+                                    int32_t B, int32_t C, float smoothing, void* stream) {
+  if (!logits || !labels || !row_loss || !loss || !grad || B <= 0 || C <= 0) return OFB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ls_ce_kernel, dim3(B), dim3(256), 0, s, logits, labels, row_loss, grad, B, C, smoothing);
+  hipLaunchKernelGGL(mean_kernel, dim3(1), dim3(256), 0, s, (const float*)row_loss, B, loss);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_patch_mask(const float* noise, float* mask, int32_t B, int32_t L, int32_t len_keep, void* stream) {
+  if (!noise || !mask || B <= 0 || L <= 0 || len_keep < 0) return OFB_EINVAL;
+  if (L > 8192) return OFB_ELIMIT;
+  hipLaunchKernelGGL(patch_mask_kernel, dim3(B), dim3(256), L * sizeof(float), (hipStream_t)stream, noise, mask, L, len_keep);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream) {
+  if (!x || !scalar_dev || !out || n <= 0) return OFB_EINVAL;
+  const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scalar_dev, out, n);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_adamw_step(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float lr, float beta1,
+                              float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+  if (!table_dev || n_tensors <= 0 || max_numel <= 0 || step <= 0) return OFB_EINVAL;
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  int bx = (int)((max_numel + 256 * 8 - 1) / (256 * 8));
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  hipStream_t s = (hipStream_t)stream;
+  ofb_prof_pre(6, s, 0.0);
+  hipLaunchKernelGGL(adamw_kernel, dim3(bx, n_tensors), dim3(256), 0, s, table_dev, lr, beta1, beta2, eps, weight_decay,
+                     (float)bc1, (float)(1.0 / sqrt(bc2)));
+  ofb_prof_post(6, s);
+  return ofb_launch_status();
+}

@@ -41,6 +41,9 @@ SYMBOLS = [
     'ofb_gemm_f32', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd',
+    'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
+    'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets',
+    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_adamw_step', 'ofb_patch_mask',
 ]
 
 
@@ -159,3 +162,99 @@ def attention_fwd(qkv, out, lse, B, N, H, dh, scale):
 def attention_bwd(qkv, out, lse, dout, dqkv, B, N, H, dh, scale):
     check(lib().ofb_attention_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), _i(B), _i(N), _i(H), _i(dh),
                                   _f(scale), stream()), 'ofb_attention_bwd')
+
+
+# ---- gates / losses -------------------------------------------------------------------------------
+class GateDesc(C.Structure):
+    _fields_ = [
+        ('alpha', C.c_void_p), ('score', C.c_void_p), ('g', C.c_void_p), ('wr', C.c_void_p), ('wm', C.c_void_p),
+        ('prob', C.c_void_p), ('wsum', C.c_void_p), ('loss_alpha', C.c_void_p), ('dloss_dalpha', C.c_void_p),
+        ('sig_partial', C.c_void_p), ('rank', C.c_void_p),
+        ('H', C.c_int32), ('C', C.c_int32), ('A0', C.c_int32), ('A1', C.c_int32), ('kind', C.c_int32),
+        ('w_p', C.c_float), ('norm_coef', C.c_float),
+        ('head_thr', C.c_int32 * 8), ('chan_thr', C.c_int32 * 40), ('on', C.c_uint8 * 64),
+    ]
+
+
+class GateGrad(C.Structure):
+    _fields_ = [('dg', C.c_void_p), ('dwr', C.c_void_p), ('dwm', C.c_void_p), ('dwsum', C.c_void_p), ('dspars', C.c_void_p),
+                ('dalpha', C.c_void_p), ('dscore', C.c_void_p)]
+
+
+class FlopsCfg(C.Structure):
+    _fields_ = [('num_patches', C.c_int32), ('embed_dim', C.c_int32), ('num_heads', C.c_int32), ('head_dim', C.c_int32),
+                ('hidden', C.c_int32), ('patch_area', C.c_int32), ('num_classes', C.c_int32), ('depth', C.c_int32),
+                ('target', C.c_float), ('active_heads', C.c_void_p)]
+
+
+class AdamwTensor(C.Structure):
+    _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64)]
+
+
+def upload_structs(array, device):
+    """ctypes struct array -> device byte tensor (pinned staging, async on the current stream)."""
+    raw = bytes(array)
+    host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
+    return host.to(device, non_blocking=True), host
+
+
+def gates_fwd(descs_dev, n, max_elems, entropy, var, norm, spars_out, spars_per_module):
+    check(lib().ofb_gates_fwd(ptr(descs_dev), _i(n), _i(max_elems), _i(entropy), _i(var), _i(norm), ptr(spars_out),
+                              ptr(spars_per_module), stream()), 'ofb_gates_fwd')
+
+
+def gates_bwd(descs_dev, grads_dev, n):
+    check(lib().ofb_gates_bwd(ptr(descs_dev), ptr(grads_dev), _i(n), stream()), 'ofb_gates_bwd')
+
+
+def flops_loss(wsum, cfg, out3, dwsum):
+    check(lib().ofb_flops_loss(ptr(wsum), C.byref(cfg), ptr(out3), ptr(dwsum), stream()), 'ofb_flops_loss')
+
+
+# ---- embed / PMIM / CE / AdamW --------------------------------------------------------------------
+def embed_assemble_fwd(conv, g, pos, cls, mask_token, mask, tokens, B, L, D):
+    check(lib().ofb_embed_assemble_fwd(ptr(conv), ptr(g), ptr(pos), ptr(cls), ptr(mask_token), ptr(mask), ptr(tokens), _i(B),
+                                       _i(L), _i(D), stream()), 'ofb_embed_assemble_fwd')
+
+
+def embed_assemble_chunks(B):
+    return int(lib().ofb_embed_assemble_chunks(_i(B)))
+
+
+def embed_assemble_bwd(dtokens, conv, g, pos, cls, mask_token, mask, dconv, ppos, pg, pmt, B, L, D):
+    check(lib().ofb_embed_assemble_bwd(ptr(dtokens), ptr(conv), ptr(g), ptr(pos), ptr(cls), ptr(mask_token), ptr(mask),
+                                       ptr(dconv), ptr(ppos), ptr(pg), ptr(pmt), _i(B), _i(L), _i(D), stream()),
+          'ofb_embed_assemble_bwd')
+
+
+def norm_targets(imgs, out, s1, s2, planes, H, W, k=47):
+    check(lib().ofb_norm_targets(ptr(imgs), ptr(out), ptr(s1), ptr(s2), _i(planes), _i(H), _i(W), _i(k), stream()),
+          'ofb_norm_targets')
+
+
+def pmim_loss_fwd(rec, targets, mask, partial, out2, B, L, P, Cc):
+    check(lib().ofb_pmim_loss_fwd(ptr(rec), ptr(targets), ptr(mask), ptr(partial), ptr(out2), _i(B), _i(L), _i(P), _i(Cc),
+                                  stream()), 'ofb_pmim_loss_fwd')
+
+
+def pmim_loss_bwd(rec, targets, mask, out2, upstream, drec, B, L, P, Cc):
+    check(lib().ofb_pmim_loss_bwd(ptr(rec), ptr(targets), ptr(mask), ptr(out2), ptr(upstream), ptr(drec), _i(B), _i(L),
+                                  _i(P), _i(Cc), stream()), 'ofb_pmim_loss_bwd')
+
+
+def ls_cross_entropy(logits, labels, row_loss, loss, grad, B, Cn, smoothing):
+    check(lib().ofb_ls_cross_entropy(ptr(logits), ptr(labels), ptr(row_loss), ptr(loss), ptr(grad), _i(B), _i(Cn),
+                                     _f(smoothing), stream()), 'ofb_ls_cross_entropy')
+
+
+def scale_by_scalar(x, scalar_dev, out, n):
+    check(lib().ofb_scale_by_scalar(ptr(x), ptr(scalar_dev), ptr(out), C.c_int64(n), stream()), 'ofb_scale_by_scalar')
+
+
+def adamw_step(table_dev, n_tensors, max_numel, lr, beta1, beta2, eps, wd, step):
+    check(lib().ofb_adamw_step(ptr(table_dev), _i(n_tensors), C.c_int64(max_numel), _f(lr), _f(beta1), _f(beta2), _f(eps),
+                               _f(wd), _i(step), stream()), 'ofb_adamw_step')
+
+
+def patch_mask(noise, mask, B, L, len_keep):
+    check(lib().ofb_patch_mask(ptr(noise), ptr(mask), _i(B), _i(L), _i(len_keep), stream()), 'ofb_patch_mask')

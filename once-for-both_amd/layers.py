@@ -1,0 +1,420 @@
+"""Host-side mirror of the reference's `models/layers.py` module API on top of the HIP ops.
+
+Same class names, constructor arguments, attribute names and state_dict keys as the reference
+ so reference-style search.py / finetune.py drivers can be pointed at this package.
+nn.Linear / nn.Conv2d are used purely as parameter containers; their torch forwards are never
+called.  No CPU fallback: forwards need device tensors and the HIP library.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+def to_2tuple(x):
+    return tuple(x) if isinstance(x, (tuple, list)) else (x, x)
+
+
+def trunc_normal_(t, std=1.0):
+    return nn.init.trunc_normal_(t, mean=0.0, std=std, a=-2.0, b=2.0)
+
+
+def reduce_tensor(tensor):
+    """average over ranks (reference models/layers.py:9-14)."""
+    rt = tensor.clone()
+    torch.distributed.all_reduce(rt, op=torch.distributed.ReduceOp.SUM)
+    rt /= torch.distributed.get_world_size()
+    return rt
+
+
+class DropPath(nn.Module):
+    """Stochastic depth (timm definition): per-sample Bernoulli(keep)/keep scaling of a residual branch.
+    The fused blocks only ask it for the per-sample scale vector."""
+
+    def __init__(self, drop_prob=0.0):
+        super().__init__()
+        self.drop_prob = float(drop_prob)
+
+    def row_scale(self, batch, device, u=None):
+        if self.drop_prob == 0.0 or not self.training:
+            return None
+        keep = 1.0 - self.drop_prob
+        u = torch.rand(batch, device=device) if u is None else u
+        return torch.floor(keep + u) / keep
+
+    def forward(self, x):
+        s = self.row_scale(x.shape[0], x.device)
+        return x if s is None else x * s.view(-1, *([1] * (x.dim() - 1)))
+
+
+class LayerNorm(nn.Module):
+    """reference models/layers.py:17-102: F.layer_norm over the last dim; `normalized_shape` is a mutable list so
+    compress() can shrink it."""
+
+    def __init__(self, normalized_shape, eps=1e-5, elementwise_affine=True):
+        super().__init__()
+        if isinstance(normalized_shape, int):
+            normalized_shape = [normalized_shape]
+        self.normalized_shape = list(normalized_shape)
+        self.eps = eps
+        self.elementwise_affine = elementwise_affine
+        if not elementwise_affine:
+            raise NotImplementedError('the OFB path only uses affine LayerNorm')
+        self.weight = nn.Parameter(torch.ones(*normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(*normalized_shape))
+
+    def forward(self, x):
+        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+    def extra_repr(self):
+        return f'{self.normalized_shape}, eps={self.eps}'
+
+
+class PatchEmbed(nn.Module):
+    """2D image -> patch tokens (reference models/layers.py:105-128)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None):
+        super().__init__()
+        self.img_size, self.patch_size = to_2tuple(img_size), to_2tuple(patch_size)
+        self.grid_size = (self.img_size[0] // self.patch_size[0], self.img_size[1] // self.patch_size[1])
+        self.num_patches = self.grid_size[0] * self.grid_size[1]
+        self.norm_layer = norm_layer
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size)   # parameter container
+        self.norm = norm_layer(embed_dim) if norm_layer else nn.Identity()
+
+    def _check(self, x):
+        assert x.shape[2] == self.img_size[0] and x.shape[3] == self.img_size[1], \
+            f"Input image size ({x.shape[2]}*{x.shape[3]}) doesn't match model ({self.img_size[0]}*{self.img_size[1]})."
+
+    def conv_tokens(self, x, gate=None):
+        """(B, L, D) conv output, optionally gated; built from the token-assembly op with zero pos/cls."""
+        self._check(x)
+        D = self.proj.out_channels
+        zeros_pos = torch.zeros(self.num_patches + 1, D, device=x.device)
+        tok = ops.PatchEmbedTokens.apply(x, self.proj.weight, self.proj.bias, gate, zeros_pos, zeros_pos[0], None, None,
+                                         self.patch_size[0])
+        return tok[:, 1:]
+
+    def forward(self, x):
+        return self.norm(self.conv_tokens(x).contiguous())
+
+
+def _staircase_state(n_rows, n_cols, head_list, chan_list, dim_rows, dim_cols):
+    """reference `mask` tensors: (A0, H, A1, d) for attention, (A1, dim) for 1-D modules."""
+    if n_rows is None:
+        m = torch.zeros(len(chan_list), dim_cols)
+        for j, c in enumerate(chan_list):
+            m[j, :c] = 1
+        return m
+    m = torch.zeros(len(head_list), dim_rows, len(chan_list), dim_cols)
+    for i, h in enumerate(head_list):
+        for j, c in enumerate(chan_list):
+            m[i, :h, j, :c] = 1
+    return m
+
+
+class _Searchable:
+    """Shared bi-mask state of the three searchable module kinds (plain attributes, exactly as the reference keeps
+    them: not buffers, so they are pickled with the module but absent from state_dict)."""
+
+    def _init_search_state(self):
+        self.finish_search = False
+        self.execute_prune = False
+        self.fused = False
+        self.w_p = 0.99
+
+    def update_w(self, cur_epoch, warmup_epochs, max=0.99, min=0.1):
+        if cur_epoch <= warmup_epochs:                      # reference layers.py:169-171
+            self.w_p = (min - max) / warmup_epochs * cur_epoch + max
+
+    def get_alpha(self):
+        return self.alpha, self.switch_cell.to(self.alpha.device)
+
+    def gate_plan(self):
+        """static + current description of this module's gate for ops.BiMaskGates."""
+        raise NotImplementedError
+
+    def _single_gate(self):
+        """gate of this module alone (used when the module is called outside the fused model forward)."""
+        plan = [self.gate_plan()]
+        outs = ops.BiMaskGates.apply(plan, (1, 1, 1), self.alpha, self.score)
+        self._set_gate_outputs(outs[0], outs[1], outs[2])
+        return outs[0]
+
+    def _set_gate_outputs(self, g, wr, wm):
+        self._g, self._wr = g, wr
+        self.weighted_mask = self._shape_wm(wm)
+
+    def get_weight(self):
+        """(weight_restore, prob_score) of the CURRENT forward (reference get_weight re-derives the same values)."""
+        if getattr(self, '_wr', None) is None:
+            self._single_gate()
+        return self._wr_view(), self._prob_view()
+
+
+class MAEPatchEmbed(PatchEmbed, _Searchable):
+    """reference models/layers.py:131-365 (search state + embed gate)."""
+
+    def __init__(self, patchmodule, embed_search=True):
+        super().__init__(patchmodule.img_size[0], patchmodule.patch_size[0], patchmodule.proj.in_channels,
+                         patchmodule.proj.out_channels, patchmodule.norm_layer)
+        self._init_search_state()
+        D = patchmodule.proj.out_channels
+        self.embed_dim = D
+        if embed_search:
+            self.embed_ratio_list = [i / D for i in range(D // 2, D + 1, min(D // 32, 12))]
+            self.alpha = nn.Parameter(torch.rand(1, len(self.embed_ratio_list)))
+            self.switch_cell = self.alpha > 0
+            self.mask = _staircase_state(None, None, None, self._chan_thr(), None, D)
+            self.score = nn.Parameter(torch.rand(1, D))
+            trunc_normal_(self.score, std=.2)
+        else:
+            self.embed_ratio_list = [1.0]
+            self.alpha = nn.Parameter(torch.tensor([1.]))
+            self.switch_cell = self.alpha > 0
+            self.weighted_mask = self.mask = torch.ones(1, D)
+            self.score = torch.ones(1, D)
+            self.finish_search = True
+
+    def _chan_thr(self):
+        return [int(r * self.embed_dim) for r in self.embed_ratio_list]
+
+    def gate_plan(self):
+        return dict(H=1, C=self.score.shape[-1], A0=1, A1=len(self.embed_ratio_list), kind=2, head_thr=[1],
+                    chan_thr=self._chan_thr(), norm_coef=1e-4, w_p=float(self.w_p),
+                    on=[int(v) for v in self.switch_cell.reshape(-1).tolist()])
+
+    def _shape_wm(self, wm):
+        return wm.view(1, -1)
+
+    def _wr_view(self):
+        return self._wr.view(1, -1)
+
+    def _prob_view(self):
+        return self.score.sigmoid()
+
+    def forward(self, x):
+        if not self.finish_search:
+            g = self._single_gate()
+        elif not self.fused:
+            g = self.score
+        else:
+            g = None
+        return self.norm(self.conv_tokens(x, g).contiguous())
+
+    @staticmethod
+    def from_patchembed(patchmodule, embed_search=True):
+        return MAEPatchEmbed(patchmodule, embed_search)
+
+
+class Attention(nn.Module):
+    """plain multi-head attention (reference models/layers.py:368-414); head_dim inferred from qkv width so
+    pruned checkpoints work (finetune path)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, qk_scale=None, attn_drop=0., proj_drop=0., num_patches=197):
+        super().__init__()
+        self.num_heads = num_heads
+        self.num_patches = num_patches
+        self.head_dim = dim // num_heads
+        self.qk_scale = qk_scale
+        self.scale = qk_scale or self.head_dim ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = nn.Dropout(attn_drop)
+        self.proj = nn.Linear(dim, dim)
+        self.proj_drop = nn.Dropout(proj_drop)
+        if attn_drop or proj_drop:
+            raise NotImplementedError('attention/projection dropout is 0 on the OFB path')
+
+    def _branch(self, x, resid, gate, rowscale, heads):
+        return ops.AttnBranch.apply(x, resid, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, gate, rowscale,
+                                    heads, float(self.scale))
+
+    def forward(self, x):
+        zero = torch.zeros_like(x)
+        return self._branch(x, zero, None, None, self.num_heads)
+
+
+class MAESparseAttention(Attention, _Searchable):
+    """reference models/layers.py:416-771: joint head x channel (default), head-only or channel-only bi-mask."""
+
+    def __init__(self, attn_module, head_search=False, channel_search=False, attn_search=True):
+        super().__init__(attn_module.qkv.in_features, attn_module.num_heads, True, attn_module.scale,
+                         attn_module.attn_drop.p, attn_module.proj_drop.p)
+        self._init_search_state()
+        H, d = self.num_heads, self.head_dim
+        self._score_shape = (H, d)
+        if attn_search:
+            heads = list(range(2, H + 1, 2))
+            ratios = [i / d for i in range(d // 4, d + 1, max(d // 8, 1))]
+            if head_search:
+                self.head_num_list = heads
+                self._heads, self._chans, self._score_shape = heads, [d], (H, 1)
+                raise NotImplementedError('head-only search space: not on the default OFB path')
+            elif channel_search:
+                self.qkv_channel_ratio_list = ratios
+                raise NotImplementedError('channel-only search space: not on the default OFB path')
+            self.head_num_list, self.qkv_channel_ratio_list = heads, ratios
+            self.alpha = nn.Parameter(torch.rand(len(heads), len(ratios)))
+            self.switch_cell = self.alpha > 0
+            self.mask = _staircase_state(len(heads), len(ratios), heads, self._chan_thr(), H, d)
+            self.score = nn.Parameter(torch.rand(H, d))
+            trunc_normal_(self.score, std=.2)
+        else:
+            self.head_num_list, self.qkv_channel_ratio_list = [H], [1.0]
+            self.alpha = nn.Parameter(torch.ones(1, 1))
+            self.switch_cell = self.alpha > 0
+            self.weighted_mask = self.mask = torch.ones(1, H, 1, d)
+            self.finish_search = True
+            self.score = torch.ones(H, d)
+        self.in_features = self.qkv.in_features
+
+    def _chan_thr(self):
+        return [int(self.head_dim * r) for r in self.qkv_channel_ratio_list]
+
+    def gate_plan(self):
+        H, d = self.score.shape
+        return dict(H=H, C=d, A0=len(self.head_num_list), A1=len(self.qkv_channel_ratio_list), kind=0,
+                    head_thr=list(self.head_num_list), chan_thr=self._chan_thr(), norm_coef=4e-4, w_p=float(self.w_p),
+                    on=[int(v) for v in self.switch_cell.reshape(-1).tolist()])
+
+    def _shape_wm(self, wm):
+        return wm.view(wm.shape[0], 1, wm.shape[1])            # (H, 1, d) as the reference stores it
+
+    def _wr_view(self):
+        return self._wr
+
+    def _prob_view(self):
+        return self.score.sigmoid()
+
+    def active_heads(self):
+        return self.head_num if hasattr(self, 'head_num') else self.num_heads
+
+    def current_gate(self):
+        if not self.finish_search:
+            return self._single_gate()
+        return None if self.fused else self.score.to(self.qkv.weight.device)
+
+    def forward(self, x, mask_embed=None, weighted_embed=None):
+        self.weighted_mask_embed = mask_embed
+        return self._branch(x, torch.zeros_like(x), self.current_gate(), None, self.active_heads())
+
+    @staticmethod
+    def from_attn(attn_module, head_search=False, channel_search=False, attn_search=True):
+        return MAESparseAttention(attn_module, head_search, channel_search, attn_search)
+
+
+class Mlp(nn.Module):
+    """reference models/layers.py:774-801."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=nn.GELU, drop=0.):
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.act = act_layer()
+        self.fc2 = nn.Linear(hidden_features, out_features)
+        self.drop = nn.Dropout(drop)
+        if drop:
+            raise NotImplementedError('MLP dropout is 0 on the OFB path')
+
+    def _branch(self, x, resid, gate, rowscale):
+        return ops.MlpBranch.apply(x, resid, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, gate, rowscale)
+
+    def forward(self, x):
+        return self._branch(x, torch.zeros_like(x), None, None)
+
+
+class MAESparseMlp(Mlp, _Searchable):
+    """reference models/layers.py:804-1049: hidden-channel bi-mask applied to fc1's output before GELU."""
+
+    def __init__(self, mlp_module, mlp_search=True):
+        super().__init__(mlp_module.fc1.in_features, mlp_module.fc1.out_features, mlp_module.fc2.out_features,
+                         act_layer=nn.GELU, drop=mlp_module.drop.p)
+        self._init_search_state()
+        hid = self.fc1.out_features
+        self.hidden_features = hid
+        if mlp_search:
+            self.hidden_ratio_list = [i / hid for i in range(hid // 4, hid + 1, hid // 8)]
+            self.alpha = nn.Parameter(torch.rand(1, len(self.hidden_ratio_list)))
+            self.switch_cell = self.alpha > 0
+            self.mask = _staircase_state(None, None, None, self._chan_thr(), None, hid)
+            self.score = nn.Parameter(torch.rand(1, hid))
+            trunc_normal_(self.score, std=.2)
+        else:
+            self.hidden_ratio_list = [1.0]
+            self.alpha = nn.Parameter(torch.ones(1, 1))
+            self.switch_cell = self.alpha > 0
+            self.weighted_mask = self.mask = torch.ones(1, hid)
+            self.finish_search = True
+            self.score = torch.ones(1, hid)
+        self.in_features = self.fc1.in_features
+
+    def _chan_thr(self):
+        return [int(r * self.hidden_features) for r in self.hidden_ratio_list]
+
+    def gate_plan(self):
+        return dict(H=1, C=self.score.shape[-1], A0=1, A1=len(self.hidden_ratio_list), kind=1, head_thr=[1],
+                    chan_thr=self._chan_thr(), norm_coef=1e-4, w_p=float(self.w_p),
+                    on=[int(v) for v in self.switch_cell.reshape(-1).tolist()])
+
+    def _shape_wm(self, wm):
+        return wm.view(1, -1)
+
+    def _wr_view(self):
+        return self._wr.view(1, -1)
+
+    def _prob_view(self):
+        return self.score.sigmoid()
+
+    def current_gate(self):
+        if not self.finish_search:
+            return self._single_gate()
+        return None if self.fused else self.score.to(self.fc1.weight.device)
+
+    def forward(self, x, mask_embed=None, weighted_embed=None):
+        self.weighted_mask_embed = mask_embed
+        return self._branch(x, torch.zeros_like(x), self.current_gate(), None)
+
+    @staticmethod
+    def from_mlp(mlp_module, mlp_search=True):
+        return MAESparseMlp(mlp_module, mlp_search)
+
+
+class ModuleInjection:
+    """construction-time class swap (reference models/layers.py:1052-1081)."""
+    method = 'full'
+    searchable_modules = []
+
+    @staticmethod
+    def make_searchable_patchembed(patchmodule, embed_search=True):
+        if ModuleInjection.method == 'full':
+            return patchmodule
+        m = MAEPatchEmbed.from_patchembed(patchmodule, embed_search)
+        if embed_search:
+            ModuleInjection.searchable_modules.append(m)
+        return m
+
+    @staticmethod
+    def make_searchable_maeattn(attn_module, head_search=False, channel_search=False, attn_search=True):
+        if ModuleInjection.method == 'full':
+            return attn_module
+        m = MAESparseAttention.from_attn(attn_module, head_search, channel_search, attn_search)
+        if attn_search:
+            ModuleInjection.searchable_modules.append(m)
+        return m
+
+    @staticmethod
+    def make_searchable_maemlp(mlp_module, mlp_search=True):
+        if ModuleInjection.method == 'full':
+            return mlp_module
+        m = MAESparseMlp.from_mlp(mlp_module, mlp_search)
+        if mlp_search:
+            ModuleInjection.searchable_modules.append(m)
+        return m
+
+
+# north_star aliases (the names in BASELINE.json do not exist in the reference)
+SearchableAttention = MAESparseAttention
+SearchableMlp = MAESparseMlp

@@ -1,0 +1,58 @@
+"""Loss modules with the reference's call signatures (reference losses.py:10-106; timm LabelSmoothingCrossEntropy)."""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class LabelSmoothingCrossEntropy(nn.Module):
+    """0.9*nll + 0.1*mean(-logp) (timm definition; search.py:584), one fused forward+gradient kernel."""
+
+    def __init__(self, smoothing=0.1):
+        super().__init__()
+        self.smoothing = smoothing
+
+    def forward(self, x, target):
+        return ops.LabelSmoothingCE.apply(x.float(), target, float(self.smoothing))
+
+
+class DistillationLoss(nn.Module):
+    """reference losses.py:10-64; only distillation_type='none' is on the OFB path (search.py:624-631)."""
+
+    def __init__(self, base_criterion, teacher_model, distillation_type, alpha, tau):
+        super().__init__()
+        assert distillation_type in ['none', 'soft', 'hard']
+        if distillation_type != 'none':
+            raise NotImplementedError('knowledge distillation is off in the OFB workflow')
+        self.base_criterion, self.teacher_model = base_criterion, teacher_model
+        self.distillation_type, self.alpha, self.tau = distillation_type, alpha, tau
+
+    def forward(self, inputs, outputs, labels):
+        if not isinstance(outputs, torch.Tensor):
+            outputs, _ = outputs
+        return self.base_criterion(outputs, labels)
+
+
+class OFBSearchLOSS(nn.Module):
+    """reference losses.py:66-106: (base, w1*attn + w2*mlp + w3*patch + w4*embed + w5*flops)."""
+
+    def __init__(self, base_criterion, device, attn_w=0.0001, mlp_w=0.0001, patch_w=0.0001, embedding_w=0.0001, flops_w=0.0001,
+                 entropy=True, var=True, norm=True):
+        super().__init__()
+        self.base_criterion = base_criterion
+        self.w1, self.w2, self.w3, self.w4, self.w5 = attn_w, mlp_w, patch_w, embedding_w, flops_w
+        self.entropy, self.var, self.norm, self.device = entropy, var, norm, device
+
+    def forward(self, inputs, outputs, labels, model, phase: str, target_flops=1.0, finish_search=False):
+        if isinstance(outputs, tuple):
+            raise NotImplementedError('decoder-prediction outputs are not produced by the OFB search model')
+        base_loss = self.base_criterion(inputs, outputs, labels)
+        if finish_search or 'arch' not in phase:
+            return base_loss
+        net = model.module if hasattr(model, 'module') else model
+        loss_flops = net.get_flops_loss(target_flops)
+        loss_attn, loss_mlp, loss_patch, loss_embedding = net.get_sparsity_loss(self.device, self.entropy, self.var, self.norm)
+        arch = self.w1 * loss_attn + self.w2 * loss_mlp + self.w4 * loss_embedding + self.w5 * loss_flops
+        if self.w3 != 0:
+            arch = arch + self.w3 * loss_patch
+        return base_loss, arch

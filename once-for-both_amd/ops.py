@@ -1,0 +1,420 @@
+"""torch.autograd.Function wrappers around the C-ABI kernels (hip.py).
+
+Each Function is one fused op group of SURVEY.md 2.3 with a hand-written backward; torch only
+allocates buffers and orders the graph.  All tensors are contiguous fp32 device tensors.
+"""
+import ctypes as C
+
+import torch
+
+from . import hip
+
+
+def _new(like, *shape):
+    return torch.empty(shape, device=like.device, dtype=torch.float32)
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------
+# GEMM helpers (nn.Linear forward / input-grad / weight-grad on the f32 MFMA kernel)
+# ---------------------------------------------------------------------------------------------------
+def linear_fwd(x2d, W, b, colscale=None, act=hip.ACT_NONE, aux=None, rowscale=None, rs_div=1, resid=None):
+    M, K = x2d.shape
+    N = W.shape[0]
+    y = _new(x2d, M, N)
+    hip.gemm(x2d, W, y, M, N, K, K, K, N, 1, 1, bias=b, colscale=colscale, act=act, aux=aux, ldaux=N, rowscale=rowscale,
+             rs_div=rs_div, resid=resid, ldr=N)
+    return y
+
+
+def linear_bwd_input(dy2d, W, resid=None, rowscale=None, rs_div=1, act=hip.ACT_NONE, aux=None):
+    """dX[M,K] = dY[M,N] @ W[N,K] (+ fused epilogue)."""
+    M, N = dy2d.shape
+    K = W.shape[1]
+    dx = _new(dy2d, M, K)
+    hip.gemm(dy2d, W, dx, M, K, N, N, K, K, 1, 0, resid=resid, ldr=K, rowscale=rowscale, rs_div=rs_div, act=act, aux=aux,
+             ldaux=K)
+    return dx
+
+
+def _splits(n_out, k_out, m):
+    tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
+    s = max(1, min(64, 1536 // tiles, m // 128))
+    return s
+
+
+def linear_bwd_weight(dy2d, x2d, kscale=None, ks_div=1, out=None):
+    """dW[N,K] = dY[M,N]^T @ X[M,K], reduction over tokens split across workgroups (deterministic slabs)."""
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    dW = out if out is not None else _new(dy2d, N, K)
+    s = _splits(N, K, M)
+    if s == 1:
+        hip.gemm(dy2d, x2d, dW, N, K, M, N, K, K, 0, 0, kscale=kscale, ks_div=ks_div)
+    else:
+        ws = _new(dy2d, s, N, K)
+        hip.gemm(dy2d, x2d, None, N, K, M, N, K, K, 0, 0, kscale=kscale, ks_div=ks_div, split_k=s, workspace=ws)
+        hip.splitk_reduce(ws, s, N * K, dW)
+    return dW
+
+
+def bias_grad(dy2d, rowscale=None, rs_div=1):
+    M, N = dy2d.shape
+    db = _new(dy2d, N)
+    hip.colsum(dy2d, N, M, N, db, rowscale=rowscale, rs_div=rs_div)
+    return db
+
+
+def _gated_linear_bwd(dy2d, x2d, W, b, gvec, resid=None):
+    """Backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None).
+    Returns dx (+resid fused), dW, db, dg."""
+    N, K = W.shape
+    if gvec is None:
+        dx = linear_bwd_input(dy2d, W, resid=resid)
+        return dx, linear_bwd_weight(dy2d, x2d), (bias_grad(dy2d) if b is not None else None), None
+    Weff = _new(W, N, K)
+    hip.scale_rows(W, gvec, Weff, N, K)
+    dx = linear_bwd_input(dy2d, Weff, resid=resid)
+    dWraw = linear_bwd_weight(dy2d, x2d)
+    dbraw = bias_grad(dy2d) if b is not None else None
+    dW, db, dg = Weff, (_new(W, N) if b is not None else None), _new(W, N)     # reuse Weff storage for dW
+    hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K)
+    return dx, dW, db, dg
+
+
+class Linear(torch.autograd.Function):
+    """y = x W^T + b on 2-D inputs (head: vision_transformer.py:744; decoder 1x1 conv :723)."""
+
+    @staticmethod
+    def forward(ctx, x2d, W, b):
+        x2d, W = _c(x2d), _c(W)
+        ctx.save_for_backward(x2d, W, b)
+        return linear_fwd(x2d, W, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, W, b = ctx.saved_tensors
+        dx, dW, db, _ = _gated_linear_bwd(_c(dy), x2d, W, b, None)
+        return dx, dW, db
+
+
+class LayerNorm(torch.autograd.Function):
+    """layers.py:96-98 (F.layer_norm, eps inside the sqrt).  Optional `dres` fork: the op also returns its input
+    unchanged so that the residual stream's gradient is added inside the backward kernel."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, fork):
+        x = _c(x)
+        D = x.shape[-1]
+        rows = x.numel() // D
+        y, mean, rstd = torch.empty_like(x), _new(x, rows), _new(x, rows)
+        hip.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.fork = fork
+        if fork:
+            return y, x.view_as(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dres=None):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        D = x.shape[-1]
+        rows = x.numel() // D
+        nb = hip.layernorm_bwd_blocks(rows)
+        part = _new(x, nb, 2 * D)
+        dx = torch.empty_like(x)
+        hip.layernorm_bwd(_c(dy), x, gamma, mean, rstd, _c(dres) if dres is not None else None, dx, part, rows, D)
+        dgb = _new(x, 2 * D)
+        hip.colsum(part, 2 * D, nb, 2 * D, dgb)
+        return dx, dgb[:D], dgb[D:], None, None
+
+
+def layer_norm(x, gamma, beta, eps):
+    return LayerNorm.apply(x, gamma, beta, eps, False)
+
+
+def layer_norm_fork(x, gamma, beta, eps):
+    """returns (LN(x), x): use the second output as the residual input of the following branch."""
+    return LayerNorm.apply(x, gamma, beta, eps, True)
+
+
+class AttnBranch(torch.autograd.Function):
+    """out = resid + rowscale[b] * proj(attention(g * qkv(x)))   (layers.py:488-517 + residual/DropPath of
+    vision_transformer.py:197,203).  If `resid` is None the branch input is also the residual (the search
+    path, where LN output replaces the stream) and its gradient add is fused into the qkv input-grad GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale):
+        x = _c(x)
+        B, N, D = x.shape
+        M = B * N
+        x2d = x.view(M, D)
+        g3 = None if g is None else g.reshape(-1).repeat(3).contiguous()
+        qkv = linear_fwd(x2d, wqkv, bqkv, colscale=g3)
+        Hd = qkv.shape[1] // 3
+        dh = Hd // heads
+        o, lse = _new(x, M, Hd), _new(x, B * heads, N)
+        hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
+        r2d = x2d if resid is None else _c(resid).view(M, D)
+        out = linear_fwd(o, wproj, bproj, rowscale=rowscale, rs_div=N, resid=r2d)
+        ctx.save_for_backward(x2d, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale)
+        ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None)
+        return out.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2d, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale = ctx.saved_tensors
+        B, N, D, heads, dh, scale, self_resid, has_pb = ctx.meta
+        M = B * N
+        d2 = _c(dout).view(M, D)
+        do = linear_bwd_input(d2, wproj, rowscale=rowscale, rs_div=N)
+        dwp = linear_bwd_weight(d2, o, kscale=rowscale, ks_div=N)
+        dbp = bias_grad(d2, rowscale=rowscale, rs_div=N) if has_pb else None
+        dqkv = torch.empty_like(qkv)
+        hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
+        dx, dwq, dbq, dg3 = _gated_linear_bwd(dqkv, x2d, wqkv, bqkv, g3, resid=d2 if self_resid else None)
+        dg = None if dg3 is None else dg3.view(3, heads, dh).sum(0)
+        dres = None if self_resid else dout
+        return dx.view(B, N, D), dres, dwq, dbq, dwp, dbp, dg, None, None, None
+
+
+class MlpBranch(torch.autograd.Function):
+    """out = resid + rowscale[b] * fc2(gelu(g * fc1(x)))   (layers.py:843-865 + residual/DropPath)."""
+
+    @staticmethod
+    def forward(ctx, x, resid, w1, b1, w2, b2, g, rowscale):
+        x = _c(x)
+        B, N, D = x.shape
+        M = B * N
+        x2d = x.view(M, D)
+        gv = None if g is None else _c(g.reshape(-1))
+        hid = w1.shape[0]
+        hpre = _new(x, M, hid)
+        h = linear_fwd(x2d, w1, b1, colscale=gv, act=hip.ACT_GELU, aux=hpre)
+        r2d = x2d if resid is None else _c(resid).view(M, D)
+        out = linear_fwd(h, w2, b2, rowscale=rowscale, rs_div=N, resid=r2d)
+        ctx.save_for_backward(x2d, hpre, h, w1, b1, w2, gv, rowscale)
+        ctx.meta = (B, N, D, resid is None, b2 is not None)
+        return out.view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        x2d, hpre, h, w1, b1, w2, gv, rowscale = ctx.saved_tensors
+        B, N, D, self_resid, has_b2 = ctx.meta
+        M = B * N
+        d2 = _c(dout).view(M, D)
+        dhpre = linear_bwd_input(d2, w2, rowscale=rowscale, rs_div=N, act=hip.ACT_DGELU, aux=hpre)
+        dw2 = linear_bwd_weight(d2, h, kscale=rowscale, ks_div=N)
+        db2 = bias_grad(d2, rowscale=rowscale, rs_div=N) if has_b2 else None
+        dx, dw1, db1, dg = _gated_linear_bwd(dhpre, x2d, w1, b1, gv, resid=d2 if self_resid else None)
+        dres = None if self_resid else dout
+        return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None
+
+
+class PatchEmbedTokens(torch.autograd.Function):
+    """imgs -> (B, L+1, D) token buffer: conv16/16 as a GEMM over patchified pixels (layers.py:177), embed gate
+    (:191), pos-embed, patch masking + mask token, cls row (vision_transformer.py:615-651)."""
+
+    @staticmethod
+    def forward(ctx, imgs, wconv, bconv, g, pos, cls, mask_token, mask, patch):
+        B, Cin, Hh, Ww = imgs.shape
+        gh, gw = Hh // patch, Ww // patch
+        L, D = gh * gw, wconv.shape[0]
+        # patchify = pure data movement (one strided copy): rows (b, py, px), columns (c, i, j)
+        patches = imgs.reshape(B, Cin, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * L, Cin * patch * patch)
+        patches = _c(patches)
+        w2d = wconv.reshape(D, -1)
+        conv = linear_fwd(patches, w2d, bconv)
+        tok = _new(imgs, B, L + 1, D)
+        gv = None if g is None else _c(g.reshape(-1))
+        posv, clsv = _c(pos.reshape(L + 1, D)), _c(cls.reshape(-1))
+        mt = None if mask_token is None else _c(mask_token.reshape(-1))
+        mk = None if mask is None else _c(mask.reshape(-1))
+        hip.embed_assemble_fwd(conv, gv, posv, clsv, mt, mk, tok, B, L, D)
+        ctx.save_for_backward(patches, conv, gv, posv, clsv, mt, mk, w2d)
+        ctx.meta = (B, L, D, tuple(wconv.shape), tuple(pos.shape), tuple(cls.shape), None if g is None else tuple(g.shape),
+                    None if mask_token is None else tuple(mask_token.shape))
+        return tok
+
+    @staticmethod
+    def backward(ctx, dtok):
+        patches, conv, gv, posv, clsv, mt, mk, w2d = ctx.saved_tensors
+        B, L, D, wshape, pshape, cshape, gshape, mshape = ctx.meta
+        chunks = hip.embed_assemble_chunks(B)
+        dconv = torch.empty_like(conv)
+        part = _new(conv, 3, chunks, L + 1, D)
+        hip.embed_assemble_bwd(_c(dtok), conv, gv, posv, clsv, mt, mk, dconv, part[0], part[1], part[2], B, L, D)
+        dpos = _new(conv, L + 1, D)
+        hip.splitk_reduce(part[0], chunks, (L + 1) * D, dpos)
+        dgm = _new(conv, 2, D)
+        hip.colsum(part[1], D, chunks * (L + 1), D, dgm[0])
+        hip.colsum(part[2], D, chunks * (L + 1), D, dgm[1])
+        dw = linear_bwd_weight(dconv, patches)
+        db = bias_grad(dconv)
+        dcls = dpos[0].reshape(cshape)
+        return (None, dw.view(wshape), db, None if gshape is None else dgm[0].view(gshape), dpos.view(pshape), dcls,
+                None if mshape is None else dgm[1].view(mshape), None, None)
+
+
+def norm_targets(imgs, ksize=47):
+    """vision_transformer.py:121-141 (no gradient flows through the targets)."""
+    imgs = _c(imgs)
+    B, Cc, Hh, Ww = imgs.shape
+    out, s1, s2 = torch.empty_like(imgs), torch.empty_like(imgs), torch.empty_like(imgs)
+    hip.norm_targets(imgs, out, s1, s2, B * Cc, Hh, Ww, ksize)
+    return out
+
+
+class PmimLoss(torch.autograd.Function):
+    """sum(|t - x_rec| * M) / (sum(M) + 1e-5) / C evaluated in patch layout (vision_transformer.py:724-729)."""
+
+    @staticmethod
+    def forward(ctx, rec, targets, mask, B, L, P, Cc):
+        rec, mask = _c(rec), _c(mask.reshape(-1))
+        partial, out2 = _new(rec, B * L), _new(rec, 2)
+        hip.pmim_loss_fwd(rec, targets, mask, partial, out2, B, L, P, Cc)
+        ctx.save_for_backward(rec, targets, mask, out2)
+        ctx.meta = (B, L, P, Cc)
+        return out2[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        rec, targets, mask, out2 = ctx.saved_tensors
+        B, L, P, Cc = ctx.meta
+        drec = torch.empty_like(rec)
+        hip.pmim_loss_bwd(rec, targets, mask, out2, _c(up).reshape(1), drec, B, L, P, Cc)
+        return drec, None, None, None, None, None, None
+
+
+class LabelSmoothingCE(torch.autograd.Function):
+    """timm LabelSmoothingCrossEntropy (search.py:584): mean_b[(1-s) nll + s mean_c(-logp)]."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, smoothing):
+        logits = _c(logits)
+        Bn, Cn = logits.shape
+        row, loss, grad = _new(logits, Bn), _new(logits, 1), torch.empty_like(logits)
+        hip.ls_cross_entropy(logits, labels, row, loss, grad, Bn, Cn, smoothing)
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        (grad,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        hip.scale_by_scalar(grad, _c(up).reshape(1), out, grad.numel())
+        return out, None, None
+
+
+class FlopsLoss(torch.autograd.Function):
+    """((searched - target) / total)^2 over the MAC model of vision_transformer.py:759-783 (base_model.py:31-35)."""
+
+    @staticmethod
+    def forward(ctx, wsum, cfg):
+        out3, dws = _new(wsum, 3), torch.empty_like(wsum)
+        hip.flops_loss(wsum, cfg, out3, dws)
+        ctx.save_for_backward(dws)
+        ctx.mark_non_differentiable(out3)
+        return out3[0].clone(), out3
+
+    @staticmethod
+    def backward(ctx, up, _unused):
+        (dws,) = ctx.saved_tensors
+        out = torch.empty_like(dws)
+        hip.scale_by_scalar(dws, _c(up).reshape(1), out, dws.numel())
+        return out, None
+
+
+class BiMaskGates(torch.autograd.Function):
+    """All bi-mask gates + adaptive one-hot loss in one launch.  plan: list of dicts (static per module:
+    H, C, A0, A1, kind, head_thr, chan_thr, norm_coef) plus per-call `on` (uint8 list) and `w_p`.
+    Inputs: alpha_0, score_0, alpha_1, score_1, ...  Outputs: g_0.., wr_0.., wm_0.., wsum[n], spars[3]."""
+
+    @staticmethod
+    def forward(ctx, plan, flags, *params):
+        n = len(plan)
+        dev = params[0].device
+        sizes_hc = [p['H'] * p['C'] for p in plan]
+        cells = [p['A0'] * p['A1'] for p in plan]
+        nblk = [(hc + 255) // 256 for hc in sizes_hc]
+        # one flat fp32 buffer for every per-module output, carved below (offsets in floats)
+        off, total = [], 0
+        for hc, ce, nb in zip(sizes_hc, cells, nblk):
+            off.append(total)
+            total += 3 * hc + 2 * ce + 2 + nb
+        buf = torch.empty(total + n + 3 + n, device=dev, dtype=torch.float32)
+        rank = torch.empty(sum(sizes_hc), device=dev, dtype=torch.int32)
+        base, rbase = buf.data_ptr(), rank.data_ptr()
+        descs = (hip.GateDesc * n)()
+        gs, wrs, wms, roff = [], [], [], 0
+        wsum_off = total
+        for i, p in enumerate(plan):
+            a, s = params[2 * i], params[2 * i + 1]
+            hc, ce, o = sizes_hc[i], cells[i], off[i]
+            d = descs[i]
+            d.alpha, d.score = a.data_ptr(), s.data_ptr()
+            d.g, d.wr, d.wm = base + 4 * o, base + 4 * (o + hc), base + 4 * (o + 2 * hc)
+            d.prob = base + 4 * (o + 3 * hc)
+            d.dloss_dalpha = base + 4 * (o + 3 * hc + ce)
+            d.loss_alpha = base + 4 * (o + 3 * hc + 2 * ce)
+            d.sig_partial = base + 4 * (o + 3 * hc + 2 * ce + 2)
+            d.wsum = base + 4 * (wsum_off + i)
+            d.rank = rbase + 4 * roff
+            d.H, d.C, d.A0, d.A1, d.kind = p['H'], p['C'], p['A0'], p['A1'], p['kind']
+            d.w_p, d.norm_coef = p['w_p'], (p['norm_coef'] if flags[2] else 0.0)
+            for k, v in enumerate(p['head_thr']):
+                d.head_thr[k] = v
+            for k, v in enumerate(p['chan_thr']):
+                d.chan_thr[k] = v
+            for k, v in enumerate(p['on']):
+                d.on[k] = v
+            shape = (p['H'], p['C'])
+            gs.append(buf[o:o + hc].view(shape))
+            wrs.append(buf[o + hc:o + 2 * hc].view(shape))
+            wms.append(buf[o + 2 * hc:o + 3 * hc].view(shape))
+            roff += hc
+        descs_dev, host = hip.upload_structs(descs, dev)
+        wsum = buf[wsum_off:wsum_off + n]
+        spars = buf[wsum_off + n:wsum_off + n + 3]
+        per_module = buf[wsum_off + n + 3:wsum_off + 2 * n + 3]
+        hip.gates_fwd(descs_dev, n, max(sizes_hc), flags[0], flags[1], flags[2], spars, per_module)
+        ctx.keep = (descs_dev, host, buf, rank, plan)
+        ctx.shapes = [(params[2 * i].shape, params[2 * i + 1].shape) for i in range(n)]
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(per_module)
+        return (*gs, *wrs, *wms, wsum, spars, per_module)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        descs_dev, _, buf, rank, plan = ctx.keep
+        n = len(plan)
+        dgs, dwrs, dwms = grads[:n], grads[n:2 * n], grads[2 * n:3 * n]
+        dwsum, dspars = grads[3 * n], grads[3 * n + 1]
+        dev = buf.device
+        dwsum = None if dwsum is None else _c(dwsum)
+        dspars = None if dspars is None else _c(dspars)
+        gtab = (hip.GateGrad * n)()
+        outs, keep = [], []
+        for i, p in enumerate(plan):
+            ashape, sshape = ctx.shapes[i]
+            da = torch.empty(ashape, device=dev, dtype=torch.float32)
+            ds = torch.empty(sshape, device=dev, dtype=torch.float32)
+            t = gtab[i]
+            for name, src in (('dg', dgs[i]), ('dwr', dwrs[i]), ('dwm', dwms[i])):
+                if src is not None:
+                    src = _c(src)
+                    keep.append(src)
+                    setattr(t, name, src.data_ptr())
+            if dwsum is not None:
+                t.dwsum = dwsum.data_ptr() + 4 * i
+            if dspars is not None:
+                t.dspars = dspars.data_ptr() + 4 * p['kind']
+            t.dalpha, t.dscore = da.data_ptr(), ds.data_ptr()
+            outs += [da, ds]
+        gdev, ghost = hip.upload_structs(gtab, dev)
+        hip.gates_bwd(descs_dev, gdev, n)
+        ctx.keep2 = (gdev, ghost, keep)
+        return (None, None, *outs)

@@ -1,0 +1,404 @@
+"""Host-side mirror of the reference's `models/vision_transformer.py` (+ `models/base_model.py`) for the OFB
+search path: MIMVisionTransformer / MAEBlock (search model) and VisionTransformer / Block (pruned-subnet
+finetune model), driving the fused HIP ops.  Class / attribute / state_dict names follow the reference.
+"""
+import math
+from functools import partial
+
+import torch
+import torch.nn as nn
+
+from . import hip, ops
+from .layers import (Attention, DropPath, LayerNorm, MAEPatchEmbed, MAESparseAttention, MAESparseMlp, Mlp, ModuleInjection,
+                     PatchEmbed, reduce_tensor, trunc_normal_)
+
+
+def norm_targets(targets, patch_size):
+    """reference vision_transformer.py:121-141 (box size must be 47, the only value the reference uses)."""
+    assert patch_size % 2 == 1
+    return ops.norm_targets(targets, patch_size)
+
+
+def _init_vit_weights(m, n='', head_bias=0.):
+    """DeiT-style init (reference :953-984, non-jax branch)."""
+    if isinstance(m, nn.Linear):
+        if n.startswith('head'):
+            nn.init.zeros_(m.weight)
+            nn.init.constant_(m.bias, head_bias)
+        else:
+            trunc_normal_(m.weight, std=.02)
+            if m.bias is not None:
+                nn.init.zeros_(m.bias)
+    elif isinstance(m, (nn.LayerNorm, LayerNorm)):
+        nn.init.zeros_(m.bias)
+        nn.init.ones_(m.weight)
+
+
+class MAEBaseModel(nn.Module):
+    """reference models/base_model.py: loss / bookkeeping API over `searchable_modules`."""
+
+    def __init__(self):
+        super().__init__()
+        self.searchable_modules = []
+
+    def give_alphas(self):
+        attn, mlp, embed = [], [], []
+        patch = self.alpha_patch.detach().cpu().reshape(-1).tolist()
+        for m in self.searchable_modules:
+            a = m.alpha.detach().cpu().reshape(-1).tolist()
+            (attn if hasattr(m, 'num_heads') else embed if hasattr(m, 'embed_ratio_list') else mlp).append(a)
+        return attn, mlp, patch, embed
+
+    def get_flops(self):
+        raise NotImplementedError
+
+    def correct_require_grad(self, w_head, w_mlp, w_patch, w_embedding):
+        for m in self.searchable_modules:
+            is_attn, is_embed = hasattr(m, 'num_heads'), hasattr(m, 'embed_ratio_list')
+            if (is_attn and w_head == 0) or (is_embed and w_embedding == 0) or (not is_attn and not is_embed and w_mlp == 0):
+                m.alpha.requires_grad = False
+        if w_patch == 0:
+            self.alpha_patch.requires_grad = False
+
+    def get_params(self):
+        total = sum(p.numel() for p in self.parameters() if p.requires_grad)
+        return total, total
+
+
+class Block(nn.Module):
+    """plain pre-LN block of the finetune model (reference :144-170); residual adds and their gradients are
+    fused into the branch GEMMs / LayerNorm backward."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=LayerNorm):
+        super().__init__()
+        self.norm1 = norm_layer(dim)
+        self.attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+
+    def _row_scale(self, x, u=None):
+        return self.drop_path.row_scale(x.shape[0], x.device, u) if isinstance(self.drop_path, DropPath) else None
+
+    def forward(self, x):
+        y, xr = ops.layer_norm_fork(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self.attn._branch(y, xr, None, self._row_scale(x), self.attn.num_heads)
+        y, xr = ops.layer_norm_fork(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self.mlp._branch(y, xr, None, self._row_scale(x))
+
+
+class MAEBlock(nn.Module):
+    """reference :173-220.  While the embed search is live the reference normalises the residual stream itself
+    (x <- LN1(x); x <- x + dp(attn(x)); x <- LN2(x); x <- x + dp(mlp(x)), :193-201); afterwards it is the usual
+    pre-LN block (:203-204)."""
+
+    def __init__(self, dim, num_heads, mlp_ratio=4., qkv_bias=False, qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
+                 act_layer=nn.GELU, norm_layer=LayerNorm, head_search=False, channel_search=False, attn_search=True,
+                 mlp_search=True):
+        super().__init__()
+        self.in_feature = dim
+        self.norm1 = norm_layer(dim)
+        attn = Attention(dim, num_heads=num_heads, qkv_bias=qkv_bias, qk_scale=qk_scale, attn_drop=attn_drop, proj_drop=drop)
+        self.attn = ModuleInjection.make_searchable_maeattn(attn, head_search, channel_search, attn_search)
+        self.drop_path = DropPath(drop_path) if drop_path > 0. else nn.Identity()
+        self.norm2 = norm_layer(dim)
+        mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
+        self.mlp = ModuleInjection.make_searchable_maemlp(mlp, mlp_search)
+
+    def run(self, x, replace_stream, g_attn, g_mlp, rs_attn, rs_mlp):
+        heads = self.attn.active_heads() if hasattr(self.attn, 'active_heads') else self.attn.num_heads
+        if replace_stream:
+            y = ops.layer_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            x = self.attn._branch(y, None, g_attn, rs_attn, heads)
+            y = ops.layer_norm(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            return self.mlp._branch(y, None, g_mlp, rs_mlp)
+        y, xr = ops.layer_norm_fork(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        x = self.attn._branch(y, xr, g_attn, rs_attn, heads)
+        y, xr = ops.layer_norm_fork(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+        return self.mlp._branch(y, xr, g_mlp, rs_mlp)
+
+    def forward(self, input):
+        x, weighted_mask_embed, weighted_embed = input
+        self.weighted_mask_embed = weighted_mask_embed
+        replace = weighted_mask_embed is not None and bool(((weighted_mask_embed < 1) & (weighted_mask_embed > 0)).any())
+        rs = (lambda: self.drop_path.row_scale(x.shape[0], x.device)) if isinstance(self.drop_path, DropPath) else (lambda: None)
+        g_a = self.attn.current_gate() if hasattr(self.attn, 'current_gate') else None
+        g_m = self.mlp.current_gate() if hasattr(self.mlp, 'current_gate') else None
+        return self.run(x, replace, g_a, g_m, rs(), rs()), weighted_mask_embed
+
+
+class VisionTransformer(nn.Module):
+    """pruned-subnet / plain ViT of the finetune path (reference :222-377)."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4., qkv_bias=True, qk_scale=None, representation_size=None, distilled=False, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., embed_layer=PatchEmbed, norm_layer=None, act_layer=None, weight_init=''):
+        super().__init__()
+        if distilled or representation_size:
+            raise NotImplementedError('distilled / representation_size variants are not on the OFB path')
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 1
+        norm_layer = norm_layer or partial(LayerNorm, eps=1e-6)
+        self.patch_embed = embed_layer(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = None
+        self.pos_embed = nn.Parameter(torch.zeros(1, num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.Sequential(*[
+            Block(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
+                  attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, act_layer=act_layer or nn.GELU)
+            for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.head_dist = None
+        trunc_normal_(self.pos_embed, std=.02)
+        trunc_normal_(self.cls_token, std=.02)
+        self.apply(_init_vit_weights)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return ['pos_embed', 'cls_token', 'dist_token']
+
+    def forward_features(self, x):
+        pe = self.patch_embed
+        x = ops.PatchEmbedTokens.apply(x, pe.proj.weight, pe.proj.bias, None, self.pos_embed, self.cls_token, None, None,
+                                       pe.patch_size[0])
+        x = self.blocks(x)
+        x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x[:, 0].contiguous()
+
+    def forward(self, x):
+        x = self.forward_features(x)
+        return ops.Linear.apply(x, self.head.weight, self.head.bias)
+
+
+class MIMVisionTransformer(MAEBaseModel):
+    """The OFB search model (reference :380-950): bi-mask gated DeiT + PMIM reconstruction branch."""
+
+    def __init__(self, img_size=224, patch_size=16, in_chans=3, num_classes=1000, embed_dim=768, depth=12, num_heads=12,
+                 mlp_ratio=4., qkv_bias=True, qk_scale=None, representation_size=None, distilled=False, drop_rate=0.,
+                 attn_drop_rate=0., drop_path_rate=0., embed_layer=PatchEmbed, norm_layer=None, act_layer=None, weight_init='',
+                 head_search=False, channel_search=False, attn_search=True, mlp_search=True, embed_search=True,
+                 patch_search=True, mae=True, norm_pix_loss=False, mask_ratio=1.0):
+        super().__init__()
+        if distilled or representation_size:
+            raise NotImplementedError('distilled / representation_size variants are not on the OFB path')
+        if patch_search:
+            raise NotImplementedError('patch-number search (alpha_patch cells) is off in the reference workflow (w_patch=0)')
+        self.num_classes = num_classes
+        self.num_features = self.embed_dim = embed_dim
+        self.num_tokens = 1
+        norm_layer = norm_layer or partial(LayerNorm, eps=1e-6)
+        self.patch_size, self.in_chans = patch_size, in_chans
+        self.finish_search = self.execute_prune = self.fused = False
+
+        pe = embed_layer(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim)
+        self.patch_embed = ModuleInjection.make_searchable_patchembed(pe, embed_search)
+        self.num_patches = self.patch_embed.num_patches
+        self.cls_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+        self.dist_token = None
+        self.pos_embed = nn.Parameter(torch.zeros(1, self.num_patches + 1, embed_dim))
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        dpr = [x.item() for x in torch.linspace(0, drop_path_rate, depth)]
+        self.blocks = nn.ModuleList([
+            MAEBlock(dim=embed_dim, num_heads=num_heads, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias, qk_scale=qk_scale, drop=drop_rate,
+                     attn_drop=attn_drop_rate, drop_path=dpr[i], norm_layer=norm_layer, act_layer=act_layer or nn.GELU,
+                     head_search=head_search, channel_search=channel_search, attn_search=attn_search, mlp_search=mlp_search)
+            for i in range(depth)])
+        self.norm = norm_layer(embed_dim)
+        self.pre_logits = nn.Identity()
+        self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
+        self.head_dist = None
+
+        # patch-number "search space" with a single cell (reference :478-485)
+        self.mae = mae
+        self.patch_ratio_list = [mask_ratio]
+        self.alpha_patch = nn.Parameter(torch.tensor([[1.]]))
+        self.switch_cell_patch = self.alpha_patch > 0
+        self.patch_search_mask = torch.zeros(1, 1, self.num_patches, 1)
+        self.patch_search_mask[0, :, :int(self.num_patches * mask_ratio), :] = 1
+        if self.mae:
+            self.mask_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
+            self.decoder = nn.Sequential(nn.Conv2d(self.num_features, patch_size ** 2 * 3, kernel_size=1), nn.PixelShuffle(patch_size))
+            self.norm_pix_loss = norm_pix_loss
+        else:
+            self.mask_token = None
+
+        trunc_normal_(self.pos_embed, std=.02)
+        trunc_normal_(self.cls_token, std=.02)
+        if self.mae:
+            trunc_normal_(self.mask_token, std=.02)
+        self.apply(_init_vit_weights)
+        w = self.patch_embed.proj.weight.data
+        nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        self._gate_flags = (1, 1, 1)
+        self._forced = None         # parity tests: dict(patch_noise=(B,L), droppath_u=(2*depth,B))
+        self._gate_out = None
+
+    # ---- small reference API -------------------------------------------------------------------
+    def adjust_masking_ratio(self, epoch, warmup_epochs, total_epochs, min_ratio=0.75, max_ratio=0.95, method='linear'):
+        if epoch <= warmup_epochs:
+            self.patch_ratio_list = [max_ratio - (max_ratio - min_ratio) * epoch / warmup_epochs]
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return ['pos_embed', 'cls_token', 'dist_token', 'scale_weight', 'mask_token', 'score']
+
+    def freeze_decoder(self):
+        if self.mask_token is not None:
+            self.mask_token.requires_grad = False
+        for name, p in self.named_parameters():
+            if 'decoder' in name:
+                p.requires_grad = False
+
+    def reset_mask_ratio(self, mask_ratio):
+        self.patch_ratio_list = [mask_ratio]
+
+    def get_classifier(self):
+        return self.head
+
+    # ---- gates (all searchable modules, one launch) ---------------------------------------------
+    def _live_modules(self):
+        return [m for m in self.searchable_modules if not m.finish_search]
+
+    def _compute_gates(self):
+        live = self._live_modules()
+        if not live:
+            self._gate_out = None
+            return
+        plan, params = [], []
+        for m in live:
+            plan.append(m.gate_plan())
+            params += [m.alpha, m.score]
+        outs = ops.BiMaskGates.apply(plan, self._gate_flags, *params)
+        n = len(live)
+        for i, m in enumerate(live):
+            m._set_gate_outputs(outs[i], outs[n + i], outs[2 * n + i])
+        self._gate_out = dict(live=live, wsum=outs[3 * n], spars=outs[3 * n + 1], per_module=outs[3 * n + 2])
+
+    def _module_gate(self, m):
+        """gate tensor the fused block should apply for module m (None = no gate)."""
+        if not hasattr(m, 'finish_search'):
+            return None
+        if not m.finish_search:
+            return m._g
+        return None if m.fused else m.score.to(self.pos_embed.device)
+
+    # ---- forward -------------------------------------------------------------------------------
+    def patch_masking_mask(self, B, device):
+        """0 keep / 1 remove mask (reference :586-612) or None when every patch is kept."""
+        L = self.num_patches
+        len_keep = int(L * self.patch_ratio_list[0])
+        if len_keep == L:
+            return None
+        forced = self._forced
+        noise = forced['patch_noise'] if forced and 'patch_noise' in forced else torch.rand(B, L, device=device)
+        mask = torch.empty(B, L, device=device)
+        hip.patch_mask(noise.contiguous(), mask, B, L, len_keep)
+        return mask
+
+    def forward_features(self, x):
+        B = x.shape[0]
+        dev = x.device
+        self._compute_gates()
+        pe = self.patch_embed
+        g_e = self._module_gate(pe)
+        mask = self.patch_masking_mask(B, dev) if self.training else None
+        x = ops.PatchEmbedTokens.apply(x, pe.proj.weight, pe.proj.bias, g_e, self.pos_embed, self.cls_token,
+                                       self.mask_token if mask is not None else None, mask, self.patch_size)
+        # the reference tests the embed staircase for entries strictly inside (0,1) on the device every block
+        # (:193); that is equivalent to "more than one embed cell is still on", which is host state.
+        replace = (not pe.finish_search) and int(pe.switch_cell.sum()) > 1 if hasattr(pe, 'switch_cell') else False
+        depth = len(self.blocks)
+        rates = [b.drop_path.drop_prob if isinstance(b.drop_path, DropPath) else 0.0 for b in self.blocks]
+        u = None
+        if self.training and any(r > 0 for r in rates):
+            forced = self._forced
+            u = forced['droppath_u'] if forced and 'droppath_u' in forced else torch.rand(2 * depth, B, device=dev)
+        call = 0
+        for i, blk in enumerate(self.blocks):
+            rs = [None, None]
+            if u is not None and rates[i] > 0:
+                keep = 1.0 - rates[i]
+                sc = torch.floor(keep + u[call:call + 2]) / keep
+                rs = [sc[0].contiguous(), sc[1].contiguous()]
+                call += 2
+            x = blk.run(x, replace, self._module_gate(blk.attn), self._module_gate(blk.mlp), rs[0], rs[1])
+        x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x, mask, None, None
+
+    def forward(self, imgs):
+        latent, mask, _, _ = self.forward_features(imgs)
+        B, T, D = latent.shape
+        if self.mae and mask is not None:
+            L, P, Cc = T - 1, self.patch_size, self.in_chans
+            z = latent[:, 1:, :].reshape(B * L, D)
+            dec = self.decoder[0]
+            rec = ops.Linear.apply(z, dec.weight.view(dec.weight.shape[0], -1), dec.bias)      # 1x1 conv, patch layout
+            targets = norm_targets(imgs, 47)
+            decoder_loss = ops.PmimLoss.apply(rec, targets, mask, B, L, P, Cc)
+        else:
+            decoder_loss = 0.
+        x = ops.Linear.apply(latent[:, 0].contiguous(), self.head.weight, self.head.bias)
+        return x, (decoder_loss, None)
+
+    # ---- losses (reference base_model.py:31-86) -------------------------------------------------
+    def _flops_cfg(self, target):
+        cfg = hip.FlopsCfg()
+        a0 = self.blocks[0].attn
+        cfg.num_patches, cfg.embed_dim, cfg.num_heads, cfg.head_dim = self.num_patches, self.embed_dim, a0.num_heads, a0.head_dim
+        cfg.hidden, cfg.patch_area = self.blocks[0].mlp.hidden_features, self.patch_size ** 2
+        cfg.num_classes, cfg.depth, cfg.target = self.num_classes, len(self.blocks), float(target)
+        cfg.active_heads = None
+        return cfg
+
+    def _wsum_all(self):
+        go = self._gate_out
+        if go is None or len(go['live']) != len(self.searchable_modules):
+            raise NotImplementedError('FLOPs model with finished modules arrives with compress() (SURVEY 8f-1)')
+        return go['wsum']
+
+    def get_flops(self):
+        if self._gate_out is None:
+            self._compute_gates()
+        _, out3 = ops.FlopsLoss.apply(self._wsum_all(), self._flops_cfg(0.0))
+        total = self._total_flops()
+        return total / 1e9, out3[2]
+
+    def _total_flops(self):
+        N, D, H, d = self.num_patches, self.embed_dim, self.blocks[0].attn.num_heads, self.blocks[0].attn.head_dim
+        hid, P2 = self.blocks[0].mlp.hidden_features, self.patch_size ** 2
+        per_block = 2 * D * N + N * (H * d * 3 * H * d) + 3 * N * H * d + H * N * d * N + H * N * N + 5 * H * N * N \
+            + H * N * N * d + N * (H * d * H * d) + N * H * d + (2 * D * hid + D + hid) * N
+        return N * D * 3 * P2 + len(self.blocks) * per_block + D * self.num_classes
+
+    def get_flops_loss(self, target_flops):
+        if self._gate_out is None:
+            self._compute_gates()
+        loss, _ = ops.FlopsLoss.apply(self._wsum_all(), self._flops_cfg(target_flops))
+        return loss
+
+    def get_sparsity_loss(self, device, entropy=True, var=True, norm=True):
+        flags = (int(entropy), int(var), int(norm))
+        if self._gate_out is None or flags != self._gate_flags:
+            self._gate_flags = flags
+            self._compute_gates()
+        zero = torch.zeros((), device=device)
+        if self._gate_out is None:
+            return zero, zero.clone(), zero.clone(), zero.clone()
+        sp = self._gate_out['spars']
+        return sp[0], sp[1], zero, sp[2]
+
+    def compress(self, thresh=0.2, optimizer_params=None, optimizer_decoder=None, optimizer_archs=None):
+        raise NotImplementedError('compress() is SURVEY 8(f)-1, scheduled after the hot path')
+
+    def fuse(self):
+        raise NotImplementedError('fuse() is SURVEY 8(f)-2, scheduled after the hot path')
+
+
+VisionTransformerSearched = MIMVisionTransformer      # north_star alias

@@ -1,0 +1,156 @@
+"""End-to-end parity of the HIP search step (forward + OFBSearchLOSS + backward + 3x AdamW) against
+(a) golden vectors generated from the imported reference and (b) the CPU oracle on the same inputs.
+Tolerance: north_star's 1e-3 relative (the HIP path computes in exact f32 and is usually ~1e-5)."""
+from functools import partial
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import ofb_oracle as O
+from tests.golden_util import load_case, sample, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def build_product(cfg, st, inputs, dev='cuda'):
+    import ofb_amd
+    from ofb_amd.layers import ModuleInjection, LayerNorm, PatchEmbed
+    ModuleInjection.method = 'search'
+    ModuleInjection.searchable_modules = []
+    m = ofb_amd.MIMVisionTransformer(
+        patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4, qkv_bias=True,
+        norm_layer=partial(LayerNorm, eps=1e-6), embed_layer=PatchEmbed, mae=True, num_classes=cfg.num_classes,
+        drop_path_rate=cfg.drop_path_rate, attn_search=True, mlp_search=True, embed_search=True, patch_search=False, mask_ratio=1.0)
+    m.searchable_modules = [x for x in m.modules() if hasattr(x, 'alpha')]
+    sd = {k: v.float() for k, v in O.formula_params(cfg, torch.float32).items()}
+    m.load_state_dict(sd, strict=True)
+    m.correct_require_grad(0.5, 0.5, 0, 0.5)
+    for mod, name in zip(m.searchable_modules, O.module_names(cfg)):
+        mod.w_p = st.w_p
+        if name in st.switch:
+            mod.switch_cell = st.switch[name].clone()
+    m.patch_ratio_list = [st.keep_ratio]
+    m.to(dev).train()
+    m._forced = dict(patch_noise=inputs['patch_noise'].to(dev), droppath_u=inputs['droppath_u'].to(dev))
+    return m
+
+
+def run_step(m, inputs, dev='cuda'):
+    from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
+    crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), torch.device(dev),
+                         attn_w=0.5, mlp_w=0.5, patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+    imgs, labels = inputs['imgs'].to(dev), inputs['labels'].to(dev)
+    logits, (dec, _) = m(imgs)
+    base, arch = crit(imgs, logits, labels, m, 'arch', 1.0, False)
+    total = base + arch + (base / dec).detach() * dec            # engine.py:134-144
+    total.backward()
+    torch.cuda.synchronize()
+    return dict(logits=logits, decoder_loss=dec, base=base, arch=arch, loss_total=total)
+
+
+def _scalar_close(got, exp, what, tol=TOL):
+    got, exp = float(got), float(exp)
+    print(f'  {what}: got {got:.7g} ref {exp:.7g} rel {abs(got - exp) / max(abs(exp), 1e-12):.2e}')
+    assert abs(got - exp) <= tol * max(1.0, abs(exp)), what
+
+
+@pytest.mark.parametrize('tag', ['micro_a', 'micro_b', 'tiny_a', 'small_a'])
+def test_search_step_matches_reference_golden(tag):
+    z, cfg, st, inputs, lr = load_case(tag)
+    m = build_product(cfg, st, inputs)
+    out = run_step(m, inputs)
+    for k in ['base', 'arch', 'decoder_loss', 'loss_total']:
+        _scalar_close(out[k], z[k], k)
+    la, lm, lp, le = m.get_sparsity_loss(torch.device('cuda'))
+    _scalar_close(la, z['loss_attn'], 'loss_attn'); _scalar_close(lm, z['loss_mlp'], 'loss_mlp'); _scalar_close(le, z['loss_embed'], 'loss_embed')
+    tot, sea = m.get_flops()
+    _scalar_close(tot, z['flops_total'], 'flops_total', 1e-6); _scalar_close(sea, z['flops_searched'], 'flops_searched', 1e-5)
+    e = rel_err(out['logits'].detach().cpu(), z['logits'])
+    print(f'  logits rel err {e:.2e}')
+    assert e < TOL
+    for mod, name in zip(m.searchable_modules, O.module_names(cfg)):
+        wr, prob = mod.get_weight()
+        assert rel_err(wr.detach().cpu().reshape(-1), z[f'gate.{name}.wr'].reshape(-1)) < 1e-5, name
+        assert rel_err(mod.weighted_mask.detach().cpu().reshape(-1), z[f'gate.{name}.wm'].reshape(-1)) < 1e-5, name
+        assert rel_err(mod._g.detach().cpu().reshape(-1), z[f'gate.{name}.g'].reshape(-1)) < 1e-5, name
+    worst, worst_k = 0.0, ''
+    for k, p in m.named_parameters():
+        if f'gnorm.{k}' not in z.files:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        assert p.grad is not None, f'no gradient for {k}'
+        g = p.grad.detach().cpu()
+        gn = float(z[f'gnorm.{k}'])
+        full = f'grad.{k}' in z.files
+        exp = z[f'grad.{k}'] if full else z[f'gsamp.{k}']
+        got = g if full else sample(g)
+        # key-bias gradients are identically 0 in exact arithmetic (softmax shift invariance): absolute check
+        if gn < 1e-6 * max(1.0, float(p.detach().norm())):
+            assert float(g.norm()) < 1e-4, k
+            continue
+        e = rel_err(got.reshape(-1), exp.reshape(-1))
+        if e > worst:
+            worst, worst_k = e, k
+        assert abs(float(g.double().norm()) - gn) <= TOL * gn, (k, float(g.norm()), gn)
+        assert e < 3 * TOL, (k, e)
+    print(f'  {tag}: worst grad rel err {worst:.2e} ({worst_k})')
+
+    # one step of the three fused AdamW optimizers (search.py:486-559 grouping)
+    from ofb_amd.optim import AdamW
+    groups = {g: [] for g in ('nodecay', 'decay', 'decoder_nodecay', 'decoder_decay', 'arch')}
+    for k, p in m.named_parameters():
+        if p.requires_grad:
+            groups[O.optimizer_group(k, tuple(p.shape))].append(p)
+    opts = [AdamW([{'params': groups['nodecay'], 'weight_decay': 0.}, {'params': groups['decay'], 'weight_decay': 1e-3}], None, lr=lr),
+            AdamW([{'params': groups['decoder_nodecay'], 'weight_decay': 0.}, {'params': groups['decoder_decay'], 'weight_decay': 1e-3}], None, lr=lr),
+            AdamW(groups['arch'], None, lr=lr, betas=(0.5, 0.999), weight_decay=1e-3)]
+    grads = {k: p.grad.detach().cpu().clone() for k, p in m.named_parameters() if p.grad is not None}
+    for o in opts:
+        o.step()
+    torch.cuda.synchronize()
+    for k, p in m.named_parameters():
+        if k not in grads:
+            continue
+        full = f'after.{k}' in z.files
+        exp = torch.from_numpy(z[f'after.{k}'] if full else z[f'asamp.{k}']).reshape(-1)
+        got = (p.detach().cpu() if full else sample(p.detach().cpu())).reshape(-1)
+        gsel = (grads[k] if full else sample(grads[k])).reshape(-1)
+        ok = gsel.abs() > 1e-4 * float(grads[k].abs().max()) + 1e-9       # Adam amplifies rounding-noise gradients to +-lr
+        if ok.any():
+            assert float((got[ok] - exp[ok]).abs().max()) < 5e-5 + 0.05 * lr, k
+
+
+def test_micro_matches_oracle_tightly():
+    """same inputs through the fp64 oracle: the f32-exact HIP path should agree to ~1e-5."""
+    z, cfg, st, inputs, lr = load_case('micro_b')
+    p = {k: v.requires_grad_(True) for k, v in O.formula_params(cfg, torch.float64).items()}
+    p['alpha_patch'].requires_grad_(False)
+    ref = O.search_step_loss(cfg, p, st, inputs['imgs'].double(), inputs['labels'], inputs['patch_noise'].double(),
+                             inputs['droppath_u'].double())
+    ref['loss_total'].backward()
+    m = build_product(cfg, st, inputs)
+    out = run_step(m, inputs)
+    assert rel_err(out['logits'].detach().cpu(), ref['logits'].detach()) < 2e-5
+    for k in ['base', 'arch', 'decoder_loss', 'loss_total']:
+        _scalar_close(out[k], ref[k].detach(), k, 2e-5)
+    worst = 0.0
+    for k, prm in m.named_parameters():
+        if p[k].grad is None or float(p[k].grad.norm()) < 1e-9:
+            continue
+        e = rel_err(prm.grad.detach().cpu(), p[k].grad)
+        worst = max(worst, e)
+        assert e < 2e-4, (k, e)
+    print(f'  worst grad rel err vs fp64 oracle: {worst:.2e}')
+
+
+def test_eval_forward():
+    z, cfg, st, inputs, lr = load_case('micro_a')
+    m = build_product(cfg, st, inputs).eval()
+    with torch.no_grad():
+        logits, (dec, _) = m(inputs['imgs'].cuda())
+    assert dec == 0.
+    p = O.formula_params(cfg, torch.float64)
+    ref = O.search_forward(cfg, p, st, inputs['imgs'].double(), training=False)
+    assert rel_err(logits.cpu(), ref['logits']) < 2e-5
