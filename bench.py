@@ -1,0 +1,176 @@
+"""bench.py — OFB search-step throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one search micro-step (engine.py:131-184 of the reference): forward of the bi-mask gated
+DeiT-S + PMIM branch, OFBSearchLOSS, backward, gradient all-reduce (N > 1), 3x AdamW — on one synthetic
+batch of 128 images per GPU that is resident in HBM before the timed region.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMG = {'deit_small': 27.83, 'deit_tiny': 7.64, 'deit_base': 105.85}      # BASELINE.md section 2 (fwd+bwd)
+PEAK_F32_MFMA_TFLOPS = 157.3                                                       # MI355X_MICROARCH.md, f32-input MFMA
+PROF_TAGS = ['gemm_f32', 'attention_fwd', 'layernorm_fwd', 'layernorm_bwd', 'attention_bwd', 'norm_targets', 'adamw']
+
+
+def cpu_baseline(log):
+    """The CPU oracle (a parity-pinned port of the reference's engine.py search step) timed on this host's cores on a
+    bounded sample of the same workload: DeiT-S, bs 8, fp32, forward + loss + backward."""
+    from oracle import ofb_oracle as O
+    torch.manual_seed(0)
+    cfg = O.Config(**O.DEIT_SMALL, num_classes=1000, drop_path_rate=0.1)
+    p = {k: v.requires_grad_(True) for k, v in O.formula_params(cfg, torch.float32).items()}
+    p['alpha_patch'].requires_grad_(False)
+    st = O.SearchState(w_p=0.99, keep_ratio=0.95)
+    bs = 8
+    g = torch.Generator().manual_seed(1234)
+    imgs = torch.randn(bs, 3, 224, 224, generator=g)
+    labels = torch.randint(0, 1000, (bs,), generator=g)
+
+    def step():
+        for v in p.values():
+            v.grad = None
+        out = O.search_step_loss(cfg, p, st, imgs, labels, torch.rand(bs, 196, generator=g), torch.rand(24, bs, generator=g))
+        out['loss_total'].backward()
+
+    step()
+    t0 = time.time()
+    n = 2
+    for _ in range(n):
+        step()
+    dt = (time.time() - t0) / n
+    log(f'cpu_baseline: {dt:.2f} s/step at bs {bs} on {torch.get_num_threads()} threads')
+    return dict(value=round(bs / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
+                sample=f'DeiT-S OFB search step (fwd+loss+bwd), bs {bs}, fp32, 1 warm-up + {n} timed steps of the oracle')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=128, help='images per GPU (BASELINE config: 128)')
+    ap.add_argument('--model', default='deit_small', choices=list(GFLOP_PER_IMG))
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true', help='skip per-kernel HIP-event timing')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    world = int(os.environ.get('WORLD_SIZE', 1))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the once-for-both_amd hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group('nccl', init_method='env://', device_id=dev)
+
+    def log(*a):
+        if rank == 0:
+            print(*a, file=sys.stderr, flush=True)
+
+    import ofb_amd
+    from ofb_amd import engine, hip
+    from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
+
+    torch.manual_seed(0)                                     # identical init on every rank (DDP would broadcast rank 0)
+    ncls = 1000
+    model = ofb_amd.create_model(f'{args.model}_patch16_224_mim', method='search', num_classes=ncls, drop_path_rate=0.1,
+                                 attn_search=True, mlp_search=True, embed_search=True, patch_search=False, mae=True,
+                                 mask_ratio=1.0)
+    model.correct_require_grad(0.5, 0.5, 0, 0.5)
+    model.adjust_masking_ratio(0.0, 20, 100)                 # epoch-0 state: keep ratio 0.95, w_p 0.99
+    model.to(dev).train()
+    eff_bs = args.batch * world
+    lr = 2.5e-4 * eff_bs / 256
+    opt_p, opt_a, opt_d = engine.build_optimizers(model, lr)
+    crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, attn_w=0.5, mlp_w=0.5,
+                         patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+    reducer = ofb_amd.dp.GradAllReducer(list(model.parameters())) if world > 1 else None
+
+    torch.manual_seed(1234 + rank)                           # per-rank data / mask / DropPath streams (search.py:381)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    imgs = torch.randn(args.batch, 3, 224, 224, device=dev, generator=gen)
+    labels = torch.randint(0, ncls, (args.batch,), device=dev, generator=gen)
+
+    def step():
+        return engine.search_step(model, crit, imgs, labels, 1.0, (opt_p, opt_a, opt_d), reducer=reducer)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if not args.no_prof:
+        hip.prof_enable(True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = None
+    if not args.no_prof:
+        prof = hip.prof_collect(len(PROF_TAGS))
+        hip.prof_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+    loss_val = float(out[3])
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_step = dt / args.steps * 1e3
+    value = eff_bs * args.steps / dt
+    roof = None
+    if prof is not None:
+        for name, (n, ms, work) in zip(PROF_TAGS, prof):
+            if n:
+                log(f'  {name:14s} launches/step {n / args.steps:7.1f}  ms/step {ms / args.steps:8.3f}  '
+                    f'{(work / (ms * 1e-3) / 1e12) if ms and name != "adamw" else 0:7.2f} T(FLOP|B)/s')
+        n, ms, work = prof[0]
+        if n:
+            ach = work / (ms * 1e-3) / 1e12
+            roof = dict(bound='mfma', kernel='gemm_f32_kernel (v_mfma_f32_32x32x2_f32)', achieved=round(ach, 2),
+                        peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s', frac=round(ach / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                        launches_per_step=round(n / args.steps, 1), avg_launch_us=round(ms / n * 1e3, 2),
+                        share_of_step=round(ms / args.steps / ms_step, 3))
+    step_tflops = value * GFLOP_PER_IMG[args.model] / 1e3 / world
+    log(f'loss_total {loss_val:.4f}; step {ms_step:.2f} ms; whole-step {step_tflops:.1f} TFLOP/s/GPU '
+        f'({step_tflops / PEAK_F32_MFMA_TFLOPS:.1%} of the f32 MFMA peak)')
+    res = dict(metric='images/sec OFB-search step, DeiT-S bs=128/GPU', value=round(value, 2), unit='images/s', n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling='weak',
+               vs_baseline=None, dtype='f32', data='synthetic',
+               config=dict(workload=f'{args.model} OFB search step + PMIM branch (configs[1]): bs {args.batch}/GPU, 224x224 synthetic '
+                                    'images, fwd + OFBSearchLOSS + bwd + 3x AdamW, drop_path 0.1, w_p 0.99, keep ratio 0.95',
+                           global_batch=eff_bs, parallelism=f'dp{world}', step_tflops_per_gpu=round(step_tflops, 2),
+                           step_frac_of_f32_mfma_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)),
+               roofline=roof)
+    if world == 1 and not args.no_cpu_baseline:
+        res['cpu_baseline'] = cpu_baseline(log)
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,172 @@
+"""Epoch engines with the reference's protocol (reference engine.py:18-219) on the fused HIP path.
+
+`search_step` is one micro-step without any host synchronisation; `search_one_epoch` wraps it in the
+reference's per-iteration schedule (progressive masking ratio, w_p warm-up, 3 optimizers, periodic compress).
+"""
+import math
+import sys
+import time
+
+import torch
+
+
+def mix_losses(loss, decoder_loss):
+    """engine.py:134-144: base + arch + stopgrad(base / decoder_loss) * decoder_loss."""
+    if isinstance(loss, tuple):
+        base, arch = loss
+        total = base + arch
+    else:
+        base, arch, total = loss, None, loss
+    if not isinstance(decoder_loss, float):
+        total = total + (base / decoder_loss).detach() * decoder_loss
+    return base, arch, total
+
+
+def search_step(model, criterion, samples, targets, target_flops, optimizers, finish_search=False, accum_iter=1,
+                do_step=True, reducer=None):
+    """forward + OFBSearchLOSS + backward (+ DP exchange) + optimizer steps.  Returns device scalars."""
+    outputs, (decoder_loss, _) = model(samples)
+    loss = criterion(samples, outputs, targets, model, 'arch', target_flops, finish_search)
+    base, arch, total = mix_losses(loss, decoder_loss)
+    (total / accum_iter if accum_iter != 1 else total).backward()
+    if reducer is not None:
+        reducer.finalize()
+    if do_step:
+        for opt in optimizers:
+            if opt is not None:
+                opt.step()
+        for opt in optimizers:
+            if opt is not None:
+                opt.zero_grad(set_to_none=True)
+    return base, arch, decoder_loss, total
+
+
+def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_param, optimizer_decoder, optimizer_arch,
+                     lr_scheduler_param, lr_scheduler_arch, lr_scheduler_decoder, device, epoch, max_norm=0, model_ema=None,
+                     mixup_fn=None, set_training_mode=True, use_amp=False, finish_search=False, args=None, progressive=True,
+                     max_ratio=0.95, min_ratio=0.75, reducer=None, print_freq=10):
+    """reference engine.py:75-219 (fp32 path; --use-amp is not supported)."""
+    if use_amp:
+        raise NotImplementedError('apex AMP path is off in the reference workflow')
+    model.train(set_training_mode)
+    net = model.module if hasattr(model, 'module') else model
+    accum_iter = args.accum_iter
+    n_iter = len(data_loader)
+    for opt in (optimizer_param, optimizer_decoder, optimizer_arch):
+        if opt is not None:
+            opt.zero_grad(set_to_none=True)
+    execute_pruned = False
+    stats, t0 = {}, time.time()
+    for it, (samples, targets) in enumerate(data_loader):
+        samples = samples.to(device, non_blocking=True)
+        targets = targets.to(device, non_blocking=True)
+        if mixup_fn is not None:
+            samples, targets = mixup_fn(samples, targets)
+        if it % accum_iter == 0:
+            t = it / n_iter + epoch
+            if progressive:
+                net.adjust_masking_ratio(t, args.warmup_epochs, args.epochs, max_ratio=max_ratio, min_ratio=min_ratio)
+            for m in net.searchable_modules:
+                if not m.finish_search:
+                    m.update_w(t, args.warmup_epochs)
+        boundary = (it + 1) % accum_iter == 0
+        opts = (optimizer_param, optimizer_arch if not finish_search else None, optimizer_decoder)
+        base, arch, dec, total = search_step(net, criterion, samples, targets, target_flops, opts, finish_search, accum_iter,
+                                             do_step=boundary, reducer=reducer)
+        if boundary:
+            gstep = epoch * n_iter + it
+            lr_scheduler_param.step_update(gstep)
+            if optimizer_arch is not None and not finish_search:
+                lr_scheduler_arch.step_update(gstep)
+            if optimizer_decoder is not None:
+                lr_scheduler_decoder.step_update(gstep)
+        if model_ema is not None:
+            model_ema.update(model)
+        if it % print_freq == 0 or it == n_iter - 1:          # the only host syncs of the loop
+            lv = float(total)
+            if not math.isfinite(lv):
+                print('Loss is {}, stopping training'.format(lv))
+                sys.exit(1)
+            stats = dict(loss_total=lv, loss_param=float(base), loss_arch=float(arch) if arch is not None else 0.0,
+                         loss_decoder=float(dec) if not isinstance(dec, float) else 0.0,
+                         lr_param=optimizer_param.param_groups[0]['lr'])
+            print(f'Epoch: [{epoch}] [{it}/{n_iter}] ' + ' '.join(f'{k}: {v:.5f}' for k, v in stats.items())
+                  + f' time: {(time.time() - t0) / (it + 1):.4f}')
+        every = max(1, n_iter // 3 // accum_iter)
+        if not finish_search and boundary and ((it + 1) // accum_iter) % every == 0 and hasattr(net, 'compress'):
+            try:
+                finish_search, execute_prune, optimizer_param, optimizer_decoder, optimizer_arch = net.compress(
+                    0.2, optimizer_param, optimizer_decoder, optimizer_arch)
+                execute_pruned |= execute_prune
+                if reducer is not None and execute_prune:
+                    reducer.rebuild([p for p in net.parameters()])
+                if finish_search:
+                    optimizer_arch, lr_scheduler_arch = None, None
+            except NotImplementedError:
+                pass
+    return stats, finish_search, execute_pruned, optimizer_param, optimizer_decoder, optimizer_arch
+
+
+def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, device, epoch, loss_scaler=None, max_norm=0,
+                    model_ema=None, mixup_fn=None, set_training_mode=True, use_amp=False, args=None, reducer=None, print_freq=10):
+    """reference engine.py:18-72 (finetune of the pruned subnet)."""
+    if use_amp:
+        raise NotImplementedError('apex AMP path is off in the reference workflow')
+    model.train(set_training_mode)
+    accum_iter = args.accum_iter
+    optimizer.zero_grad(set_to_none=True)
+    n_iter, stats = len(data_loader), {}
+    for it, (samples, targets) in enumerate(data_loader):
+        samples, targets = samples.to(device, non_blocking=True), targets.to(device, non_blocking=True)
+        if mixup_fn is not None:
+            samples, targets = mixup_fn(samples, targets)
+        loss = criterion(samples, model(samples), targets)
+        (loss / accum_iter if accum_iter != 1 else loss).backward()
+        if reducer is not None:
+            reducer.finalize()
+        if (it + 1) % accum_iter == 0:
+            optimizer.step()
+            optimizer.zero_grad(set_to_none=True)
+            lr_schedule.step_update(epoch * n_iter + it)
+        if model_ema is not None:
+            model_ema.update(model)
+        if it % print_freq == 0 or it == n_iter - 1:
+            lv = float(loss)
+            if not math.isfinite(lv):
+                print('Loss is {}, stopping training'.format(lv))
+                sys.exit(1)
+            stats = dict(loss=lv, lr=optimizer.param_groups[0]['lr'])
+    return stats
+
+
+def param_groups(model, weight_decay=1e-3):
+    """search.py:486-508 grouping -> dict of lists (params / decoder / archs optimizers)."""
+    skip = model.no_weight_decay() if hasattr(model, 'no_weight_decay') else []
+    g = dict(nodecay=[], decay=[], decoder_nodecay=[], decoder_decay=[], arch=[])
+    names = {k: [] for k in g}
+    for name, p in model.named_parameters():
+        if not p.requires_grad:
+            continue
+        if len(p.shape) == 1 or name.endswith('.bias') or any(s in name for s in skip):
+            key = 'decoder_nodecay' if 'decoder' in name else 'nodecay'
+        elif 'alpha' in name:
+            key = 'arch'
+        else:
+            key = 'decoder_decay' if 'decoder' in name else 'decay'
+        g[key].append(p)
+        names[key].append(name)
+    return g, names
+
+
+def build_optimizers(model, lr, lr_arch=None, lr_decoder=None, weight_decay=1e-3):
+    """the three AdamW instances of search.py:549-559."""
+    from .optim import AdamW
+    g, names = param_groups(model)
+    opt_p = AdamW([{'params': g['nodecay'], 'weight_decay': 0.}, {'params': g['decay'], 'weight_decay': weight_decay}],
+                  {0: names['nodecay'], 1: names['decay']}, lr=lr)
+    opt_d = None
+    if g['decoder_decay']:
+        opt_d = AdamW([{'params': g['decoder_nodecay'], 'weight_decay': 0.}, {'params': g['decoder_decay'], 'weight_decay': weight_decay}],
+                      {0: names['decoder_nodecay'], 1: names['decoder_decay']}, lr=lr_decoder or lr)
+    opt_a = AdamW(g['arch'], {0: names['arch']}, lr=lr_arch or lr, betas=(0.5, 0.999), weight_decay=1e-3) if g['arch'] else None
+    return opt_p, opt_a, opt_d
