@@ -38,8 +38,11 @@ extern "C" {
  * dY^T @ X (weight gradient, reduction over tokens) of the same Linear layers.
  * kscale (a_kc == 0 only): A's reduction rows are scaled by kscale[k / ks_div] (per-sample
  * DropPath factor inside a weight gradient).
- * split_k > 1: grid.z slices K; raw partial sums go to workspace[split_k][M][N] and the epilogue
- * is skipped — follow with ofb_splitk_reduce.
+ * Scheduling is hybrid stream-K over persistent workgroups (see csrc/gemm.hip): the tiles that do not fill a whole
+ * round of workgroups are cut along K and summed (fixed order, deterministic) by a fix-up launch, so long-K
+ * weight gradients and ragged tile counts both keep every CU busy.  `workspace` must hold
+ * ofb_gemm_workspace_bytes(args) bytes (0 when no tile is streamed); it may be shared by successive calls on
+ * one stream.
  * ------------------------------------------------------------------------------------------- */
 typedef struct ofb_gemm_args {
   const float* A; const float* B; float* C;
@@ -54,12 +57,13 @@ typedef struct ofb_gemm_args {
   float* aux; int32_t ldaux;
   int32_t act;
   const float* kscale; int32_t ks_div;
-  int32_t split_k; float* workspace;
+  float* workspace; int64_t workspace_bytes;
 } ofb_gemm_args;
 
+int64_t ofb_gemm_workspace_bytes(const ofb_gemm_args* args);
 int ofb_gemm_f32(const ofb_gemm_args* args, void* stream);
 
-/* out[i] = sum_s workspace[s*count + i] (+ out[i] if accumulate) */
+/* out[i] = sum_s workspace[s*count + i] (+ out[i] if accumulate): sums per-chunk partial buffers (embed assembly) */
 int ofb_splitk_reduce(const float* workspace, int32_t splits, int64_t count, float* out, int32_t accumulate,
                       void* stream);
 
@@ -70,6 +74,8 @@ int ofb_splitk_reduce(const float* workspace, int32_t splits, int64_t count, flo
  * ------------------------------------------------------------------------------------------- */
 int ofb_prof_enable(int32_t on);
 int ofb_prof_collect(double* out, int32_t ntags);
+/* diagnostic: `blocks` workgroups x 4 waves each issue 4*iters back-to-back f32 MFMAs (measures the sustained roof) */
+int ofb_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps inside the sqrt), one wavefront per token row; D <= 1024.

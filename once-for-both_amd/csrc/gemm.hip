@@ -1,26 +1,44 @@
 // f32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32 fma chains) with fused epilogues.
 // Block tile 128x128x16, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).
-// Both operands are staged k-major in LDS ([k][mn], row pitch 132 floats) through registers with a
-// one-tile global prefetch, so the three storage combinations the Linear layers need (x@W^T, dY@W,
-// dY^T@X) share one inner loop of ds_read_b32 + MFMA.
+// Both operands are staged [mn][k] in LDS (row pitch 20 floats) through registers with a one-tile global
+// prefetch; K-contiguous operands are written with ds_write_b128, MN-contiguous ones are transposed on the
+// way in, so the three storage combinations the Linear layers need (x@W^T, dY@W, dY^T@X) share one inner
+// loop of 8 ds_read_b128 + 32 MFMA per wave and K-tile.
+//
+// Scheduling (hybrid stream-K): W = CUs x 3 persistent workgroups.  Output tiles that fill whole rounds of W are
+// computed data-parallel with the epilogue fused; the R = tiles mod W remaining tiles are cut along K into W equal
+// runs of K-iterations (a run touches at most two tiles), written as raw partial tiles to a workspace and summed
+// by a small fix-up kernel that applies the same epilogue.  Every workgroup therefore issues the same number of
+// MFMAs (within one K-iteration) whatever the tile count, and weight gradients (few tiles, long K = all tokens) need
+// no separate split-K path.  Partials are summed in a fixed order: results are run-to-run deterministic.
 #include "ofb_common.h"
 
 #define BM 128
 #define BN 128
+#ifndef BK
 #define BK 16
-#define LDP 132   // LDS row pitch (floats): 16-B aligned rows, transposed b32 writes at most 2-way conflicted
+#endif
+#define LDP (BK + 4)   // LDS row pitch in floats ([mn][k] layout): 80-B / 144-B rows keep b128 fragment reads conflict-free
+#define NLD (BM * BK / 4 / 256)   // float4 loads per thread and operand tile
+#ifndef GEMM_WAVES_PER_SIMD
+#define GEMM_WAVES_PER_SIMD 2
+#endif
 
 namespace {
 
-struct TileRegs { f32x4 v[2]; };
+struct TileRegs { f32x4 v[NLD]; };
 
-// K-contiguous storage: X[o*ld + k].  512 float4 per tile, 2 per thread: o = idx>>2, kq = idx&3.
-template <bool VEC>
+// K-contiguous storage X[o*ld + k]: 512 float4 per tile, 2 per thread (o = idx>>2, kq = idx&3) -> one ds_write_b128 each.
+template <bool VEC, bool GUARD>
 __device__ __forceinline__ void load_kc(TileRegs& r, const float* __restrict__ X, int ld, int o0, int O, int k0, int kend,
                                         int t) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = t + 256 * i, o = o0 + (idx >> 2), k = k0 + ((idx & 3) << 2);
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = t + 256 * i, o = o0 + idx / (BK / 4), k = k0 + ((idx % (BK / 4)) << 2);
+    if (!GUARD) {      // full tiles only (M, N multiples of 128, K multiple of BK): no bounds checks at all
+      r.v[i] = *reinterpret_cast<const f32x4*>(X + (size_t)o * ld + k);
+      continue;
+    }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (o < O) {
       const float* p = X + (size_t)o * ld + k;
@@ -37,19 +55,25 @@ __device__ __forceinline__ void load_kc(TileRegs& r, const float* __restrict__ X
 }
 __device__ __forceinline__ void store_kc(const TileRegs& r, float* __restrict__ S, int t) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = t + 256 * i, o = idx >> 2, kk = (idx & 3) << 2;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) S[(kk + j) * LDP + o] = r.v[i][j];
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = t + 256 * i;
+    *reinterpret_cast<f32x4*>(&S[(idx / (BK / 4)) * LDP + ((idx % (BK / 4)) << 2)]) = r.v[i];
   }
 }
-// MN-contiguous storage: X[k*ld + o].  kk = idx>>5, oq = idx&31.
-template <bool VEC>
+// MN-contiguous storage X[k*ld + o]: kk = idx&15, oq = idx>>4 (consecutive lanes take consecutive k rows so that the
+// transposing b32 writes S[(4oq+j)][kk] hit 32 distinct banks).
+template <bool VEC, bool GUARD>
 __device__ __forceinline__ void load_mc(TileRegs& r, const float* __restrict__ X, int ld, int o0, int O, int k0, int kend,
                                         int t, const float* __restrict__ kscale, int ks_div) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = t + 256 * i, k = k0 + (idx >> 5), o = o0 + ((idx & 31) << 2);
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = t + 256 * i, k = k0 + (idx % BK), o = o0 + ((idx / BK) << 2);
+    if (!GUARD) {
+      f32x4 u = *reinterpret_cast<const f32x4*>(X + (size_t)k * ld + o);
+      if (kscale) u *= kscale[k / ks_div];
+      r.v[i] = u;
+      continue;
+    }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     if (k < kend) {
       const float* p = X + (size_t)k * ld + o;
@@ -67,32 +91,86 @@ __device__ __forceinline__ void load_mc(TileRegs& r, const float* __restrict__ X
 }
 __device__ __forceinline__ void store_mc(const TileRegs& r, float* __restrict__ S, int t) {
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int idx = t + 256 * i;
-    *reinterpret_cast<f32x4*>(&S[(idx >> 5) * LDP + ((idx & 31) << 2)]) = r.v[i];
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = t + 256 * i, kk = idx % BK, o = (idx / BK) << 2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) S[(o + j) * LDP + kk] = r.v[i][j];
   }
 }
 
-template <bool A_KC, bool B_KC, bool VEC>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const ofb_gemm_args g) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BK * LDP];
-  float* As = lds;                    // [2][BK][LDP]
-  float* Bs = lds + 2 * BK * LDP;     // [2][BK][LDP]
+struct Plan { int mt, nt, ntiles, I, W, full_rounds, R, q; };
+
+__host__ __device__ inline Plan make_plan(int M, int N, int K, int W) {
+  Plan p;
+  p.mt = (M + BM - 1) / BM;
+  p.nt = (N + BN - 1) / BN;
+  p.ntiles = p.mt * p.nt;
+  p.I = (K + BK - 1) / BK;
+  p.W = W;
+  p.full_rounds = p.ntiles / W;
+  p.R = p.ntiles - p.full_rounds * W;
+  p.q = p.R ? (int)(((long long)p.R * p.I + W - 1) / W) : 0;      // K-iterations per workgroup in the streamed tail (q <= I)
+  return p;
+}
+
+// One unit of work: K-iterations [it0, it1) of output tile `tile`; slot < 0 -> full tile, fused epilogue to C;
+// slot >= 0 -> raw partial tile to workspace[slot].
+struct Seg { int m0, n0, it0, it1, slot; bool ok; };
+
+template <bool TAIL>
+__device__ __forceinline__ Seg get_seg(const Plan p, int v, int idx) {
+  Seg s;
+  s.m0 = s.n0 = s.it0 = s.it1 = 0; s.slot = -1; s.ok = false;
+  if (!TAIL) {
+    if (idx >= p.full_rounds) return s;
+    const int tile = v + idx * p.W;
+    s.m0 = (tile / p.nt) * BM; s.n0 = (tile % p.nt) * BN; s.it0 = 0; s.it1 = p.I; s.ok = true;
+    return s;
+  }
+  const int part = idx;
+  if (part > 1 || p.R == 0) return s;
+  // R * I < W * I <= 768 * (K/16): fits 32 bits for every K the host accepts (checked in ofb_gemm_f32)
+  const int beg = v * p.q, tot = p.R * p.I;
+  const int end = min(beg + p.q, tot);
+  if (beg >= end) return s;
+  const int a = beg / p.I, it0 = beg - a * p.I;
+  const int n0 = end - beg;
+  const int first = min(p.I - it0, n0);
+  int tl, i0, i1;
+  if (part == 0) { tl = a; i0 = it0; i1 = it0 + first; }
+  else {
+    if (n0 - first <= 0) return s;
+    tl = a + 1; i0 = 0; i1 = n0 - first;
+  }
+  const int tile = p.full_rounds * p.W + tl;
+  s.m0 = (tile / p.nt) * BM; s.n0 = (tile % p.nt) * BN; s.it0 = i0; s.it1 = i1; s.slot = 2 * v + part; s.ok = true;
+  return s;
+}
+
+// v = alpha*acc (+bias)(*colscale); act; (*rowscale); (+resid)   -- shared by the fused epilogue and the fix-up kernel
+__device__ __forceinline__ float epilogue_value(float alpha, int act, float* __restrict__ aux, int ldaux, float accv, int row,
+                                                int col, float bias, float cs, float rsv, float rv, float av) {
+  float v = (accv * alpha + bias) * cs;
+  if (act == OFB_ACT_GELU) {
+    if (aux) aux[(size_t)row * ldaux + col] = v;
+    v = ofb_gelu(v);
+  } else if (act == OFB_ACT_DGELU) {
+    v *= ofb_dgelu(av);
+  }
+  return v * rsv + rv;
+}
+
+// TAIL = false: the full rounds (tile = v, v + W, ...; fused epilogue).  TAIL = true: the streamed remainder (<= 2 runs of
+// K-iterations per workgroup, raw partial tiles to the workspace).  Same main loop; launched back to back.
+template <bool A_KC, bool B_KC, bool VEC, bool GUARD, bool FULL_EPI, bool TAIL>
+__global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(const ofb_gemm_args g, const Plan p) {
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BM * LDP];
+  float* As = lds;                    // [2][BM][LDP]
+  float* Bs = lds + 2 * BM * LDP;     // [2][BN][LDP]
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
-  const int mt = (g.M + BM - 1) / BM, nt = (g.N + BN - 1) / BN;
-  const int tile = ofb_xcd_remap(blockIdx.x, mt * nt);
-  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  const int v = ofb_xcd_remap(blockIdx.x, p.W);     // consecutive v share an XCD (and thus A/B panels in its L2)
   const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
-
-  // K range of this split
-  int kbeg = 0, kend = g.K;
-  if (g.split_k > 1) {
-    const int chunk = ((g.K + BK - 1) / BK + g.split_k - 1) / g.split_k * BK;
-    kbeg = blockIdx.y * chunk;
-    kend = min(g.K, kbeg + chunk);
-  }
-  const int ntile = (kend > kbeg) ? (kend - kbeg + BK - 1) / BK : 0;
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -103,76 +181,202 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const ofb_gemm_args g) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   TileRegs ra, rb;
-  auto gload = [&](int kt) {
-    const int k0 = kbeg + kt * BK;
-    if (A_KC) load_kc<VEC>(ra, g.A, g.lda, m0, g.M, k0, kend, t);
-    else load_mc<VEC>(ra, g.A, g.lda, m0, g.M, k0, kend, t, g.kscale, g.ks_div);
-    if (B_KC) load_kc<VEC>(rb, g.B, g.ldb, n0, g.N, k0, kend, t);
-    else load_mc<VEC>(rb, g.B, g.ldb, n0, g.N, k0, kend, t, nullptr, 1);
+  auto gload = [&](const Seg& sg, int it) {
+    const int k0 = it * BK;
+    if (A_KC) load_kc<VEC, GUARD>(ra, g.A, g.lda, sg.m0, g.M, k0, g.K, t);
+    else load_mc<VEC, GUARD>(ra, g.A, g.lda, sg.m0, g.M, k0, g.K, t, g.kscale, g.ks_div);
+    if (B_KC) load_kc<VEC, GUARD>(rb, g.B, g.ldb, sg.n0, g.N, k0, g.K, t);
+    else load_mc<VEC, GUARD>(rb, g.B, g.ldb, sg.n0, g.N, k0, g.K, t, nullptr, 1);
   };
   auto lstore = [&](int buf) {
-    if (A_KC) store_kc(ra, As + buf * BK * LDP, t); else store_mc(ra, As + buf * BK * LDP, t);
-    if (B_KC) store_kc(rb, Bs + buf * BK * LDP, t); else store_mc(rb, Bs + buf * BK * LDP, t);
+    if (A_KC) store_kc(ra, As + buf * BM * LDP, t); else store_mc(ra, As + buf * BM * LDP, t);
+    if (B_KC) store_kc(rb, Bs + buf * BN * LDP, t); else store_mc(rb, Bs + buf * BN * LDP, t);
+  };
+  auto compute = [&](int buf) {
+    // fragment reads: lane (row l31, half h) takes k = 8q + 4h + j (q < BK/8; j = 0..3) with one b128 per q; A and B
+    // use the same k <-> (q, h, j) map, so each MFMA step (q, j) multiplies matching k's.
+    const float* a_s = As + buf * BM * LDP + (wm0 + l31) * LDP + 4 * h;
+    const float* b_s = Bs + buf * BN * LDP + (wn0 + l31) * LDP + 4 * h;
+    f32x4 af[2][BK / 8], bf[2][BK / 8];
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q) {
+      af[0][q] = *reinterpret_cast<const f32x4*>(a_s + 8 * q);
+      af[1][q] = *reinterpret_cast<const f32x4*>(a_s + 32 * LDP + 8 * q);
+      bf[0][q] = *reinterpret_cast<const f32x4*>(b_s + 8 * q);
+      bf[1][q] = *reinterpret_cast<const f32x4*>(b_s + 32 * LDP + 8 * q);
+    }
+#pragma unroll
+    for (int q = 0; q < BK / 8; ++q)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][q][j], bf[0][q][j], acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][q][j], bf[1][q][j], acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][q][j], bf[0][q][j], acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][q][j], bf[1][q][j], acc[1][1], 0, 0, 0);
+      }
   };
 
-  if (ntile > 0) {
-    gload(0);
-    lstore(0);
-  }
+  int sidx = 0;
+  Seg cur = get_seg<TAIL>(p, v, 0);
+  if (!cur.ok) return;
+  gload(cur, cur.it0);
+  lstore(0);
   __syncthreads();
-  for (int kt = 0; kt < ntile; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < ntile) gload(kt + 1);
-    const float* a_s = As + buf * BK * LDP + (h * (BK / 2)) * LDP + wm0 + l31;
-    const float* b_s = Bs + buf * BK * LDP + (h * (BK / 2)) * LDP + wn0 + l31;
-#pragma unroll
-    for (int s = 0; s < BK / 2; ++s) {
-      // lane half h supplies k = h*8 + s for both operands: any k<->(step,half) bijection is a valid MFMA feed
-      const float a0 = a_s[s * LDP], a1 = a_s[s * LDP + 32];
-      const float b0 = b_s[s * LDP], b1 = b_s[s * LDP + 32];
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+  int buf = 0;
+  while (true) {
+    // all K-iterations of this unit but the last: prefetch the next K-tile of the same unit
+    for (int it = cur.it0; it + 1 < cur.it1; ++it) {
+#ifndef LAB_NO_GLOAD
+      gload(cur, it + 1);
+#endif
+      compute(buf);
+      // keep every MFMA of this K-tile ahead of the vmcnt wait / LDS refill / barrier
+      __builtin_amdgcn_sched_barrier(0);
+      lstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
     }
-    if (kt + 1 < ntile) lstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue: C/D layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  const bool partial = g.split_k > 1;
-  float* Cout = partial ? g.workspace + (size_t)blockIdx.y * g.M * g.N : g.C;
-  const int ldc = partial ? g.N : g.ldc;
+    // last K-iteration: the NEXT unit's first K-tile goes in flight before this unit's stores
+    const Seg nxt = get_seg<TAIL>(p, v, sidx + 1);
+    const bool has_next = nxt.ok;
+#ifndef LAB_NO_GLOAD
+    if (has_next) gload(nxt, nxt.it0);
+#endif
+    compute(buf);
+    __builtin_amdgcn_sched_barrier(0);
+    if (TAIL) {
+      // raw partial tile -> workspace[slot][128][128] (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+      float* ws = g.workspace + (size_t)cur.slot * (BM * BN);
 #pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int col = n0 + wn0 + 32 * ni + l31;
-    if (col >= g.N) continue;
-    float bias = 0.f, cs = 1.f;
-    if (!partial) {
-      if (g.bias) bias = g.bias[col];
-      if (g.colscale) cs = g.colscale[col];
-    }
+      for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi) {
+        for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm0 + 32 * mi + (r & 3) + 8 * (r >> 2) + 4 * h;
-        if (row >= g.M) continue;
-        float v = acc[mi][ni][r];
-        if (!partial) {
-          v = (v * g.alpha + bias) * cs;
-          if (g.act == OFB_ACT_GELU) {
-            if (g.aux) g.aux[(size_t)row * g.ldaux + col] = v;
-            v = ofb_gelu(v);
-          } else if (g.act == OFB_ACT_DGELU) {
-            v *= ofb_dgelu(g.aux[(size_t)row * g.ldaux + col]);
+          for (int r = 0; r < 16; ++r) {
+            ws[(wm0 + 32 * mi + 4 * h + (r & 3) + 8 * (r >> 2)) * BN + wn0 + 32 * ni + l31] = acc[mi][ni][r];
+            acc[mi][ni][r] = 0.f;
           }
-          if (g.rowscale) v *= g.rowscale[row / g.rs_div];
-          if (g.resid) v += g.resid[(size_t)row * g.ldr + col];
         }
-        Cout[(size_t)row * ldc + col] = v;
+    } else if (!GUARD) {
+      // unguarded build (every tile is full): no per-element guards, so the stores issue back to back behind ONE wait
+      // (hipcc otherwise brackets every guarded store with s_waitcnt vmcnt(0), serialising 64 round trips per wave)
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = cur.n0 + wn0 + 32 * ni + l31;
+        const float bias = g.bias ? g.bias[col] : 0.f, cs = g.colscale ? g.colscale[col] : 1.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
+          if (FULL_EPI) {
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              f32x4 rv = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f}, rsv = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = rbase + r4 + 8 * rg;
+                if (g.resid) rv[r4] = g.resid[(size_t)row * g.ldr + col];
+                if (g.act == OFB_ACT_DGELU) av[r4] = g.aux[(size_t)row * g.ldaux + col];
+                if (g.rowscale) rsv[r4] = g.rowscale[row / g.rs_div];
+              }
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = rbase + r4 + 8 * rg;
+                g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][4 * rg + r4], row, col, bias,
+                                                                cs, rsv[r4], rv[r4], av[r4]);
+              }
+              __builtin_amdgcn_sched_barrier(0);   // bound the side-input loads in flight (register pressure)
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              g.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * g.ldc + col] = (acc[mi][ni][r] * g.alpha + bias) * cs;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+        const int col = cur.n0 + wn0 + 32 * ni + l31;
+        const bool colok = col < g.N;
+        float bias = 0.f, cs = 1.f;
+        if (colok) {
+          if (g.bias) bias = g.bias[col];
+          if (g.colscale) cs = g.colscale[col];
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+          const int rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
+          if (FULL_EPI) {
+            // per group of 4 rows: gather the side inputs first (independent loads in flight together), then compute + store
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+              f32x4 rv, av, rsv;     // vector types: register-resident with the static indices below
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = rbase + r4 + 8 * rg;
+                const bool ok = colok && row < g.M;
+                rv[r4] = (g.resid && ok) ? g.resid[(size_t)row * g.ldr + col] : 0.f;
+                av[r4] = (g.act == OFB_ACT_DGELU && ok) ? g.aux[(size_t)row * g.ldaux + col] : 0.f;
+                rsv[r4] = (g.rowscale && row < g.M) ? g.rowscale[row / g.rs_div] : 1.f;
+              }
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4) {
+                const int row = rbase + r4 + 8 * rg;
+                if (colok && row < g.M)
+                  g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][4 * rg + r4], row, col, bias, cs, rsv[r4], rv[r4], av[r4]);
+              }
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = rbase + (r & 3) + 8 * (r >> 2);
+              if (colok && row < g.M) g.C[(size_t)row * g.ldc + col] = (acc[mi][ni][r] * g.alpha + bias) * cs;
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
       }
     }
+    if (!has_next) break;
+    lstore(buf ^ 1);
+    __syncthreads();
+    buf ^= 1;
+    ++sidx;
+    cur = nxt;
+  }
+}
+
+// Sums the partial tiles of each streamed tail tile in workgroup order and applies the epilogue.
+// grid (R, 4): block (r, part) handles rows [32*part, 32*part+32) of tail tile r.
+__global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, const Plan p) {
+  const int r = blockIdx.x, part = blockIdx.y, t = threadIdx.x;
+  const int tile = p.full_rounds * p.W + r;
+  const int m0 = (tile / p.nt) * BM, n0 = (tile % p.nt) * BN;
+  const int lo = r * p.I, hi = lo + p.I;         // this tile's run of flattened K-iterations
+  const int v0 = lo / p.q, v1 = (hi - 1) / p.q;
+  const int c = t & 127, col = n0 + c;
+  float sum[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) sum[j] = 0.f;
+  for (int v = v0; v <= v1; ++v) {
+    const int slot = (v * p.q < lo) ? 2 * v + 1 : 2 * v;   // second segment if the run started in the previous tile
+    const float* ws = g.workspace + (size_t)slot * (BM * BN) + (size_t)(32 * part + (t >> 7)) * BN + c;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) sum[j] += ws[(size_t)(2 * j) * BN];
+  }
+  if (col >= g.N) return;
+  const float bias = g.bias ? g.bias[col] : 0.f, cs = g.colscale ? g.colscale[col] : 1.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int row = m0 + 32 * part + (t >> 7) + 2 * j;
+    if (row >= g.M) continue;
+    const float rv = g.resid ? g.resid[(size_t)row * g.ldr + col] : 0.f;
+    const float av = (g.act == OFB_ACT_DGELU) ? g.aux[(size_t)row * g.ldaux + col] : 0.f;
+    const float rsv = g.rowscale ? g.rowscale[row / g.rs_div] : 1.f;
+    g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, sum[j], row, col, bias, cs, rsv, rv, av);
   }
 }
 
@@ -185,38 +389,81 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, i
   }
 }
 
+template <bool A_KC, bool B_KC, bool VEC, bool GUARD>
+void launch2(const ofb_gemm_args& g, const Plan& p, bool full, hipStream_t s) {
+  const dim3 grid(p.W);
+  if (p.full_rounds > 0) {
+    if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, true, false>), grid, dim3(256), 0, s, g, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, false, false>), grid, dim3(256), 0, s, g, p);
+  }
+  if (p.R > 0) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, false, true>), grid, dim3(256), 0, s, g, p);
+}
+
 template <bool A_KC, bool B_KC>
-int launch(const ofb_gemm_args& g, bool vec, dim3 grid, hipStream_t s) {
-  if (vec) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, true>), grid, dim3(256), 0, s, g);
-  else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, false>), grid, dim3(256), 0, s, g);
+int launch(const ofb_gemm_args& g, const Plan& p, bool vec, hipStream_t s) {
+  const bool full = g.act != OFB_ACT_NONE || g.rowscale || g.resid;
+  // unguarded kernels need every tile full: M, N multiples of 128 and K a multiple of the K-step
+  const bool guard = !vec || (g.M % BM) || (g.N % BN) || (g.K % BK);
+  if (!vec) launch2<A_KC, B_KC, false, true>(g, p, full, s);
+  else if (guard) launch2<A_KC, B_KC, true, true>(g, p, full, s);
+  else launch2<A_KC, B_KC, true, false>(g, p, full, s);
   return ofb_launch_status();
+}
+
+int worker_count() {
+  static int W = 0;
+  if (W == 0) {
+    hipDeviceProp_t prop;
+    int devid = 0;
+    W = 256 * GEMM_WAVES_PER_SIMD;
+    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.multiProcessorCount > 0)
+      W = prop.multiProcessorCount * GEMM_WAVES_PER_SIMD;
+  }
+  return W;
+}
+
+Plan plan_for(const ofb_gemm_args& g) {
+  int W = worker_count();
+  const int tiles = ofb_cdiv(g.M, BM) * ofb_cdiv(g.N, BN);
+  const long long iters = (long long)tiles * ofb_cdiv(g.K, BK);
+  if (iters < W) W = (int)iters;                    // tiny problems: one K-iteration per workgroup
+  return make_plan(g.M, g.N, g.K, W);
 }
 
 }  // namespace
 
+extern "C" int64_t ofb_gemm_workspace_bytes(const ofb_gemm_args* args) {
+  if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+  const Plan p = plan_for(*args);
+  return p.R ? (int64_t)2 * p.W * BM * BN * (int64_t)sizeof(float) : 0;
+}
+
 extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream) {
   if (!args) return OFB_EINVAL;
   const ofb_gemm_args& g = *args;
-  if (!g.A || !g.B || g.M <= 0 || g.N <= 0 || g.K <= 0) return OFB_EINVAL;
-  if (g.split_k > 1 ? !g.workspace : !g.C) return OFB_EINVAL;
+  if (!g.A || !g.B || !g.C || g.M <= 0 || g.N <= 0 || g.K <= 0) return OFB_EINVAL;
   if (g.a_kc == 0 && g.b_kc == 1) return OFB_ELIMIT;           // A^T * B^T is not on the path
   if (g.kscale && (g.a_kc != 0 || g.ks_div <= 0)) return OFB_EINVAL;
   if (g.rowscale && g.rs_div <= 0) return OFB_EINVAL;
   if (g.act == OFB_ACT_DGELU && !g.aux) return OFB_EINVAL;
   // minimum leading dimensions for the declared storage
-  if (g.lda < (g.a_kc ? g.K : g.M) || g.ldb < (g.b_kc ? g.K : g.N)) return OFB_EINVAL;
-  if (g.split_k <= 1 && g.ldc < g.N) return OFB_EINVAL;
+  if (g.lda < (g.a_kc ? g.K : g.M) || g.ldb < (g.b_kc ? g.K : g.N) || g.ldc < g.N) return OFB_EINVAL;
+  const Plan p = plan_for(g);
+  if ((long long)p.W * p.I > 0x7fffffffLL / 2) return OFB_ELIMIT;
+  if (p.R && (!g.workspace || g.workspace_bytes < ofb_gemm_workspace_bytes(args))) return OFB_EINVAL;
   // vector (16-B) staging needs aligned bases, ld % 4 == 0 and a contiguous extent that is a multiple of 4
   bool vec = ofb_aligned16(g.A) && ofb_aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0);
   vec = vec && ((g.a_kc ? g.K : g.M) % 4 == 0) && ((g.b_kc ? g.K : g.N) % 4 == 0);
-  const int mt = ofb_cdiv(g.M, BM), nt = ofb_cdiv(g.N, BN);
-  dim3 grid(mt * nt, g.split_k > 1 ? g.split_k : 1);
   hipStream_t s = (hipStream_t)stream;
   ofb_prof_pre(0, s, 2.0 * g.M * g.N * (double)g.K);
   int rc;
-  if (g.a_kc && g.b_kc) rc = launch<true, true>(g, vec, grid, s);
-  else if (g.a_kc) rc = launch<true, false>(g, vec, grid, s);
-  else rc = launch<false, false>(g, vec, grid, s);
+  if (g.a_kc && g.b_kc) rc = launch<true, true>(g, p, vec, s);
+  else if (g.a_kc) rc = launch<true, false>(g, p, vec, s);
+  else rc = launch<false, false>(g, p, vec, s);
+  if (rc == 0 && p.R) {
+    hipLaunchKernelGGL(gemm_fixup_kernel, dim3(p.R, 4), dim3(256), 0, s, g, p);
+    rc = ofb_launch_status();
+  }
   ofb_prof_post(0, s);
   return rc;
 }

@@ -46,3 +46,26 @@ extern "C" int ofb_prof_collect(double* out, int32_t ntags) {
   g_recs.clear();
   return OFB_OK;
 }
+
+// Diagnostic: back-to-back v_mfma_f32_32x32x2_f32 on every SIMD (4 independent accumulators per wave); used by
+// scripts/ to read the f32-MFMA rate this device sustains (the practical roof next to the 157.3 TF datasheet peak).
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+  f32x16 acc[4];
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a = (float)threadIdx.x * 1e-3f, b = (float)blockIdx.x * 1e-3f + 1.0f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < 4; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 123.456f) out[0] = s;
+}
+
+extern "C" int ofb_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, void* stream) {
+  if (!out || blocks <= 0 || iters <= 0) return OFB_EINVAL;
+  hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
+  return (int)hipGetLastError();
+}

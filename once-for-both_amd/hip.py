@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
         ('aux', C.c_void_p), ('ldaux', C.c_int32),
         ('act', C.c_int32),
         ('kscale', C.c_void_p), ('ks_div', C.c_int32),
-        ('split_k', C.c_int32), ('workspace', C.c_void_p),
+        ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
     ]
 
 
@@ -38,12 +38,12 @@ ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_f32', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_gemm_f32', 'ofb_gemm_workspace_bytes', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets',
-    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_adamw_step', 'ofb_patch_mask',
+    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
 ]
 
 
@@ -85,15 +85,32 @@ def _f32c(t, name):
     return t
 
 
+_gemm_ws = {}
+
+
+def _workspace(device, nbytes):
+    """one shared stream-K workspace per device (successive GEMMs on a stream may reuse it)."""
+    ws = _gemm_ws.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _gemm_ws[device] = ws
+    return ws
+
+
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kc, b_kc, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
-         resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, kscale=None, ks_div=1, split_k=1, workspace=None):
+         resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, kscale=None, ks_div=1):
     g = GemmArgs()
     g.A, g.B, g.C = ptr(A), ptr(B), ptr(C_out)
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
     g.a_kc, g.b_kc, g.alpha = int(a_kc), int(b_kc), alpha
     g.bias, g.colscale, g.rowscale, g.rs_div = ptr(bias), ptr(colscale), ptr(rowscale), rs_div
     g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
-    g.kscale, g.ks_div, g.split_k, g.workspace = ptr(kscale), ks_div, split_k, ptr(workspace)
+    g.kscale, g.ks_div = ptr(kscale), ks_div
+    lib().ofb_gemm_workspace_bytes.restype = C.c_int64
+    need = lib().ofb_gemm_workspace_bytes(C.byref(g))
+    if need > 0:
+        ws = _workspace(A.device, need)
+        g.workspace, g.workspace_bytes = ptr(ws), ws.numel() * 4
     check(lib().ofb_gemm_f32(C.byref(g), stream()), 'ofb_gemm_f32')
 
 
@@ -258,3 +275,7 @@ def adamw_step(table_dev, n_tensors, max_numel, lr, beta1, beta2, eps, wd, step)
 
 def patch_mask(noise, mask, B, L, len_keep):
     check(lib().ofb_patch_mask(ptr(noise), ptr(mask), _i(B), _i(L), _i(len_keep), stream()), 'ofb_patch_mask')
+
+
+def diag_mfma_peak(out, blocks, iters):
+    check(lib().ofb_diag_mfma_peak(ptr(out), _i(blocks), _i(iters), stream()), 'ofb_diag_mfma_peak')

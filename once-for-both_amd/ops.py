@@ -40,24 +40,12 @@ def linear_bwd_input(dy2d, W, resid=None, rowscale=None, rs_div=1, act=hip.ACT_N
     return dx
 
 
-def _splits(n_out, k_out, m):
-    tiles = ((n_out + 127) // 128) * ((k_out + 127) // 128)
-    s = max(1, min(64, 1536 // tiles, m // 128))
-    return s
-
-
 def linear_bwd_weight(dy2d, x2d, kscale=None, ks_div=1, out=None):
-    """dW[N,K] = dY[M,N]^T @ X[M,K], reduction over tokens split across workgroups (deterministic slabs)."""
+    """dW[N,K] = dY[M,N]^T @ X[M,K]: few output tiles, reduction over all tokens -> the GEMM's stream-K tail."""
     M, N = dy2d.shape
     K = x2d.shape[1]
     dW = out if out is not None else _new(dy2d, N, K)
-    s = _splits(N, K, M)
-    if s == 1:
-        hip.gemm(dy2d, x2d, dW, N, K, M, N, K, K, 0, 0, kscale=kscale, ks_div=ks_div)
-    else:
-        ws = _new(dy2d, s, N, K)
-        hip.gemm(dy2d, x2d, None, N, K, M, N, K, K, 0, 0, kscale=kscale, ks_div=ks_div, split_k=s, workspace=ws)
-        hip.splitk_reduce(ws, s, N * K, dW)
+    hip.gemm(dy2d, x2d, dW, N, K, M, N, K, K, 0, 0, kscale=kscale, ks_div=ks_div)
     return dW
 
 

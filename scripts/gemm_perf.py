@@ -21,12 +21,8 @@ for N, K in [(1152, 384), (384, 384), (1536, 384), (384, 1536), (768, 384)]:
     run(f'NT  {M}x{N}x{K}', lambda: hip.gemm(x, w, y, M, N, K, K, K, N, 1, 1, bias=b), 2.0 * M * N * K)
     dy = torch.randn(M, N, device='cuda'); dx = torch.empty(M, K, device='cuda')
     run(f'NN  {M}x{K}x{N}', lambda: hip.gemm(dy, w, dx, M, K, N, N, K, K, 1, 0), 2.0 * M * N * K)
-    for split in (16, 32, 64):
-        ws = torch.empty(split, N, K, device='cuda'); dw = torch.empty(N, K, device='cuda')
-        def f():
-            hip.gemm(dy, x, None, N, K, M, N, K, K, 0, 0, split_k=split, workspace=ws)
-            hip.splitk_reduce(ws, split, N * K, dw)
-        run(f'TN  {N}x{K}x{M} split{split}', f, 2.0 * M * N * K)
+    dw = torch.empty(N, K, device='cuda')
+    run(f'TN  {N}x{K}x{M}', lambda: hip.gemm(dy, x, dw, N, K, M, N, K, K, 0, 0), 2.0 * M * N * K)
 B, N, H, dh = 128, 197, 6, 64
 qkv = torch.randn(B * N, 3 * H * dh, device='cuda'); o = torch.empty(B * N, H * dh, device='cuda')
 lse = torch.empty(B * H, N, device='cuda'); do = torch.randn_like(o); dqkv = torch.empty_like(qkv)

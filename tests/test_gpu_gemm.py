@@ -63,15 +63,24 @@ def test_gemm_nn_and_tn(M, N, K):
     ks = _mk(((M + 196) // 197,), 10)
     rows = torch.arange(M) // 197
     exp = (dy.double() * ks.double()[rows].unsqueeze(1)).t() @ x.double()
-    for split in (1, 3, 8):
-        dw = torch.empty(N, K, device='cuda')
-        if split == 1:
-            hip.gemm(dyd, xd, dw, N, K, M, N, K, K, 0, 0, kscale=ks.cuda(), ks_div=197)
-        else:
-            ws = torch.empty(split, N, K, device='cuda')
-            hip.gemm(dyd, xd, None, N, K, M, N, K, K, 0, 0, kscale=ks.cuda(), ks_div=197, split_k=split, workspace=ws)
-            hip.splitk_reduce(ws, split, N * K, dw)
-        _check(dw, exp, what=f'tn split{split} {N}x{K}x{M}')
+    dw = torch.empty(N, K, device='cuda')
+    hip.gemm(dyd, xd, dw, N, K, M, N, K, K, 0, 0, kscale=ks.cuda(), ks_div=197)
+    _check(dw, exp, what=f'tn {N}x{K}x{M}')
+
+
+def test_gemm_stream_k_tail_shapes():
+    """tile counts around the workgroup count (full rounds + streamed tail, tail only, exact rounds)."""
+    from ofb_amd import hip
+    for (M, N, K) in [(128 * 40, 128 * 13, 80), (128 * 64, 128 * 8, 48), (128 * 33, 128 * 16, 200), (25216, 384, 64)]:
+        x, w, b, res = _mk((M, K), 21), _mk((N, K), 22), _mk((N,), 23), _mk((M, N), 24)
+        out = torch.empty(M, N, device='cuda')
+        hip.gemm(x.cuda(), w.cuda(), out, M, N, K, K, K, N, 1, 1, bias=b.cuda(), resid=res.cuda(), ldr=N)
+        rows = torch.arange(0, M, 37)
+        ref = x[rows].double() @ w.double().t() + b.double() + res[rows].double()
+        _check(out[rows.cuda()], ref, what=f'stream-k {M}x{N}x{K}')
+        out2 = torch.empty(M, N, device='cuda')
+        hip.gemm(x.cuda(), w.cuda(), out2, M, N, K, K, K, N, 1, 1, bias=b.cuda(), resid=res.cuda(), ldr=N)
+        assert torch.equal(out, out2), 'stream-K partial sums must be summed in a fixed order (deterministic)'
 
 
 def test_gemm_deit_small_shapes():
