@@ -210,6 +210,8 @@ class AdamwTensor(C.Structure):
 
 def upload_structs(array, device):
     """ctypes struct array -> device byte tensor (pinned staging, async on the current stream)."""
+    if torch.device(device).type != 'cuda':
+        raise OfbError('once-for-both_amd kernels need device tensors (no CPU fallback); got a CPU tensor')
     raw = bytes(array)
     host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
     return host.to(device, non_blocking=True), host

@@ -1,0 +1,93 @@
+"""CPU tests of the host-side mirror of the reference API: names, shapes, search-space state, grouping,
+schedules.  No compute kernels are called (there is no CPU fallback to call)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import ofb_amd
+from oracle import ofb_oracle as O
+
+
+def build(name='deit_small_patch16_224_mim', **kw):
+    return ofb_amd.create_model(name, method='search', num_classes=kw.pop('num_classes', 1000), drop_path_rate=0.1,
+                                attn_search=True, mlp_search=True, embed_search=True, patch_search=False, mae=True, mask_ratio=1.0,
+                                drop_block_rate=None, **kw)
+
+
+def test_state_dict_names_and_shapes_match_reference_abi():
+    m = build()
+    cfg = O.Config(**O.DEIT_SMALL, num_classes=1000)
+    exp = O.param_shapes(cfg)                      # probed from the reference
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == exp
+    assert sum(p.numel() for p in m.parameters()) == 22370506
+    assert len(list(m.buffers())) == 0                                 # mask/switch_cell are plain attributes
+    assert len(m.searchable_modules) == 25
+    kinds = ['embed'] + ['attn', 'mlp'] * 12
+    for mod, k in zip(m.searchable_modules, kinds):
+        got_k = 'attn' if hasattr(mod, 'num_heads') else ('embed' if hasattr(mod, 'embed_ratio_list') else 'mlp')
+        assert got_k == k
+
+
+@pytest.mark.parametrize('name,D,H', [('deit_tiny_patch16_224_mim', 192, 3), ('deit_base_patch16_224_mim', 768, 12)])
+def test_search_spaces(name, D, H):
+    m = build(name, num_classes=2)
+    cfg = O.Config(embed_dim=D, depth=12, num_heads=H, num_classes=2)
+    a = m.blocks[0].attn
+    assert a.head_num_list == cfg.attn_heads()
+    assert [int(a.head_dim * r) for r in a.qkv_channel_ratio_list] == cfg.attn_channels()
+    assert tuple(a.mask.shape) == (len(cfg.attn_heads()), H, 7, 64)
+    assert float(a.mask.sum()) == sum(h * c for h in cfg.attn_heads() for c in cfg.attn_channels())
+    assert [int(r * m.blocks[0].mlp.hidden_features) for r in m.blocks[0].mlp.hidden_ratio_list] == cfg.mlp_channels()
+    assert [int(r * D) for r in m.patch_embed.embed_ratio_list] == cfg.embed_channels()
+    plan = a.gate_plan()
+    assert plan['A0'] * plan['A1'] <= 64 and plan['H'] == H and plan['C'] == 64
+
+
+def test_param_groups_follow_search_py_rules():
+    from ofb_amd import engine
+    m = build('deit_tiny_patch16_224_mim', num_classes=2)
+    m.correct_require_grad(0.5, 0.5, 0, 0.5)
+    groups, names = engine.param_groups(m)
+    for grp, ns in names.items():
+        for n in ns:
+            assert O.optimizer_group(n, tuple(dict(m.named_parameters())[n].shape)) == grp
+    # SURVEY R14 (probed on the reference): 128 no-decay + 50 decay + 2 decoder + 25 arch tensors
+    assert len(names['nodecay']) == 128 and len(names['decay']) == 50
+    assert len(names['decoder_nodecay']) + len(names['decoder_decay']) == 2 and len(names['arch']) == 25
+    assert 'alpha_patch' not in sum(names.values(), [])
+
+
+def test_warmup_schedules():
+    m = build('deit_tiny_patch16_224_mim', num_classes=2)
+    a = m.blocks[3].attn
+    a.update_w(10, 20)
+    assert abs(a.w_p - (0.99 - 0.89 * 0.5)) < 1e-12
+    a.update_w(25, 20)                                   # frozen after warm-up
+    assert abs(a.w_p - 0.545) < 1e-12
+    m.adjust_masking_ratio(0, 20, 100)
+    assert m.patch_ratio_list == [0.95]
+    m.adjust_masking_ratio(20, 20, 100)
+    assert abs(m.patch_ratio_list[0] - 0.75) < 1e-12
+    m.reset_mask_ratio(1.0)
+    assert m.patch_ratio_list == [1.0]
+
+
+def test_total_flops_matches_reference_probe():
+    m = build()
+    assert abs(m._total_flops() / 1e9 - 4.600557) < 1e-5          # un-pruned DeiT-S "4.60 GFLOPs" 
+
+
+def test_forward_without_gpu_fails_loudly():
+    m = build('deit_tiny_patch16_224_mim', num_classes=2)
+    with pytest.raises(ofb_amd.hip.OfbError):
+        m(torch.zeros(1, 3, 224, 224))
+
+
+def test_unsupported_options_are_explicit():
+    with pytest.raises(NotImplementedError):
+        ofb_amd.create_model('deit_small_patch16_224_mim', method='search', patch_search=True)
+    with pytest.raises(NotImplementedError):
+        ofb_amd.create_model('deit_small_patch16_224_mim', pretrained=True, method='search', patch_search=False)
