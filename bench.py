@@ -63,6 +63,7 @@ def main():
     ap.add_argument('--model', default='deit_small', choices=list(GFLOP_PER_IMG))
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip per-kernel HIP-event timing')
+    ap.add_argument('--force-dp', action='store_true', help='exercise the DP bucket path even with one rank (debug)')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0))
@@ -99,7 +100,7 @@ def main():
     opt_p, opt_a, opt_d = engine.build_optimizers(model, lr)
     crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, attn_w=0.5, mlp_w=0.5,
                          patch_w=0.0, embedding_w=0.5, flops_w=5.0)
-    reducer = ofb_amd.dp.GradAllReducer(list(model.parameters())) if world > 1 else None
+    reducer = ofb_amd.dp.GradAllReducer(list(model.parameters())) if (world > 1 or args.force_dp) else None
 
     torch.manual_seed(1234 + rank)                           # per-rank data / mask / DropPath streams (search.py:381)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -157,7 +158,7 @@ def main():
     step_tflops = value * GFLOP_PER_IMG[args.model] / 1e3 / world
     log(f'loss_total {loss_val:.4f}; step {ms_step:.2f} ms; whole-step {step_tflops:.1f} TFLOP/s/GPU '
         f'({step_tflops / PEAK_F32_MFMA_TFLOPS:.1%} of the f32 MFMA peak)')
-    res = dict(metric='images/sec OFB-search step, DeiT-S bs=128/GPU', value=round(value, 2), unit='images/s', n_gpus=world,
+    res = dict(metric='images/sec OFB-search step, DeiT-S bs=128/GPU @1/2/4/8 MI355X', value=round(value, 2), unit='images/s', n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling='weak',
                vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload=f'{args.model} OFB search step + PMIM branch (configs[1]): bs {args.batch}/GPU, 224x224 synthetic '

@@ -58,9 +58,12 @@ typedef struct ofb_gemm_args {
   int32_t act;
   const float* kscale; int32_t ks_div;
   float* workspace; int64_t workspace_bytes;
+  float* a_colsum;          /* a_kc == 0 only: a_colsum[m] = sum_k A[k][m] (*kscale): the bias gradient fused into a weight-gradient
+                               launch; valid only when ofb_gemm_is_streamed(args) (few output tiles), else OFB_ELIMIT */
 } ofb_gemm_args;
 
 int64_t ofb_gemm_workspace_bytes(const ofb_gemm_args* args);
+int32_t ofb_gemm_is_streamed(const ofb_gemm_args* args);   /* 1 when every output tile goes through the stream-K tail */
 int ofb_gemm_f32(const ofb_gemm_args* args, void* stream);
 
 /* out[i] = sum_s workspace[s*count + i] (+ out[i] if accumulate): sums per-chunk partial buffers (embed assembly) */

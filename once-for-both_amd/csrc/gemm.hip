@@ -219,6 +219,19 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
   int sidx = 0;
   Seg cur = get_seg<TAIL>(p, v, 0);
   if (!cur.ok) return;
+  // fused bias gradient (weight-gradient launches): column sums of the stored A (= dY), taken from the staged A tile
+  // by the workgroups that own the first column tile; thread t < 128 owns output row t of the tile.
+  float bsum = 0.f;
+  auto colsum_acc = [&](int buf) {
+    if (TAIL && !A_KC && g.a_colsum && cur.n0 == 0 && t < BM) {
+      const float* row = As + buf * BM * LDP + t * LDP;
+#pragma unroll
+      for (int q = 0; q < BK / 4; ++q) {
+        const f32x4 u = *reinterpret_cast<const f32x4*>(row + 4 * q);
+        bsum += (u[0] + u[1]) + (u[2] + u[3]);
+      }
+    }
+  };
   gload(cur, cur.it0);
   lstore(0);
   __syncthreads();
@@ -229,6 +242,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
 #ifndef LAB_NO_GLOAD
       gload(cur, it + 1);
 #endif
+      colsum_acc(buf);      // its LDS reads / adds are issued ahead of (and overlap) the MFMA block
       compute(buf);
       // keep every MFMA of this K-tile ahead of the vmcnt wait / LDS refill / barrier
       __builtin_amdgcn_sched_barrier(0);
@@ -242,9 +256,14 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
 #ifndef LAB_NO_GLOAD
     if (has_next) gload(nxt, nxt.it0);
 #endif
+    colsum_acc(buf);
     compute(buf);
     __builtin_amdgcn_sched_barrier(0);
     if (TAIL) {
+      if (!A_KC && g.a_colsum && cur.n0 == 0 && t < BM) {
+        g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)cur.slot * BM + t] = bsum;
+        bsum = 0.f;
+      }
       // raw partial tile -> workspace[slot][128][128] (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
       float* ws = g.workspace + (size_t)cur.slot * (BM * BN);
 #pragma unroll
@@ -367,6 +386,14 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, 
 #pragma unroll
     for (int j = 0; j < 16; ++j) sum[j] += ws[(size_t)(2 * j) * BN];
   }
+  if (g.a_colsum && n0 == 0 && part == 0 && t < BM && m0 + t < g.M) {
+    float bs = 0.f;
+    for (int v = v0; v <= v1; ++v) {
+      const int slot = (v * p.q < lo) ? 2 * v + 1 : 2 * v;
+      bs += g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)slot * BM + t];
+    }
+    g.a_colsum[m0 + t] = bs;
+  }
   if (col >= g.N) return;
   const float bias = g.bias ? g.bias[col] : 0.f, cs = g.colscale ? g.colscale[col] : 1.f;
 #pragma unroll
@@ -435,7 +462,12 @@ Plan plan_for(const ofb_gemm_args& g) {
 extern "C" int64_t ofb_gemm_workspace_bytes(const ofb_gemm_args* args) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
   const Plan p = plan_for(*args);
-  return p.R ? (int64_t)2 * p.W * BM * BN * (int64_t)sizeof(float) : 0;
+  return p.R ? (int64_t)2 * p.W * (BM * BN + BM) * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int32_t ofb_gemm_is_streamed(const ofb_gemm_args* args) {
+  if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+  return plan_for(*args).full_rounds == 0 ? 1 : 0;
 }
 
 extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream) {
@@ -446,10 +478,12 @@ extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream) {
   if (g.kscale && (g.a_kc != 0 || g.ks_div <= 0)) return OFB_EINVAL;
   if (g.rowscale && g.rs_div <= 0) return OFB_EINVAL;
   if (g.act == OFB_ACT_DGELU && !g.aux) return OFB_EINVAL;
+  if (g.a_colsum && g.a_kc != 0) return OFB_EINVAL;
   // minimum leading dimensions for the declared storage
   if (g.lda < (g.a_kc ? g.K : g.M) || g.ldb < (g.b_kc ? g.K : g.N) || g.ldc < g.N) return OFB_EINVAL;
   const Plan p = plan_for(g);
   if ((long long)p.W * p.I > 0x7fffffffLL / 2) return OFB_ELIMIT;
+  if (g.a_colsum && p.full_rounds > 0) return OFB_ELIMIT;   // fused column sums ride on the streamed tail only (see ofb_gemm_is_streamed)
   if (p.R && (!g.workspace || g.workspace_bytes < ofb_gemm_workspace_bytes(args))) return OFB_EINVAL;
   // vector (16-B) staging needs aligned bases, ld % 4 == 0 and a contiguous extent that is a multiple of 4
   bool vec = ofb_aligned16(g.A) && ofb_aligned16(g.B) && (g.lda % 4 == 0) && (g.ldb % 4 == 0);

@@ -33,8 +33,10 @@ class GradAllReducer:
         self._works = []
         self._flat = [None] * len(self.buckets)
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
-        backend = dist.get_backend(process_group) if dist.is_initialized() else None
-        self._avg = backend == 'nccl'
+        # averaging: callers scale the loss by `grad_scale` (= 1/world, exact for power-of-two worlds) before backward and
+        # the exchange is a plain SUM, so no extra pass over the gradients is needed; prescaled=False divides afterwards.
+        self.grad_scale = 1.0 / self.world
+        self.prescaled = False
 
     def rebuild(self, params):
         """call after compress() replaced Parameters (fixes the reference's silent de-sync, SURVEY D-6)."""
@@ -48,8 +50,7 @@ class GradAllReducer:
             return
         flat = torch.cat([p.grad.reshape(-1) for p in ps])
         if self.world > 1:
-            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-            work = dist.all_reduce(flat, op=op, group=self.group, async_op=True)
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             work = None
         self._works.append((bi, ps, flat, work))
@@ -68,7 +69,7 @@ class GradAllReducer:
         for bi, ps, flat, work in self._works:
             if work is not None:
                 work.wait()
-                if not self._avg:
+                if not self.prescaled:
                     flat.div_(self.world)
             off = 0
             for p in ps:

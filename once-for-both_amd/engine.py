@@ -28,7 +28,11 @@ def search_step(model, criterion, samples, targets, target_flops, optimizers, fi
     outputs, (decoder_loss, _) = model(samples)
     loss = criterion(samples, outputs, targets, model, 'arch', target_flops, finish_search)
     base, arch, total = mix_losses(loss, decoder_loss)
-    (total / accum_iter if accum_iter != 1 else total).backward()
+    scale = 1.0 / accum_iter
+    if reducer is not None:
+        reducer.prescaled = True
+        scale *= reducer.grad_scale                      # SUM all-reduce of (loss / world) gradients == average
+    (total * scale if scale != 1.0 else total).backward()
     if reducer is not None:
         reducer.finalize()
     if do_step:

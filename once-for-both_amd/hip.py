@@ -30,7 +30,7 @@ class GemmArgs(C.Structure):
         ('aux', C.c_void_p), ('ldaux', C.c_int32),
         ('act', C.c_int32),
         ('kscale', C.c_void_p), ('ks_div', C.c_int32),
-        ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
+        ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('a_colsum', C.c_void_p),
     ]
 
 
@@ -38,7 +38,7 @@ ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_f32', 'ofb_gemm_workspace_bytes', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_gemm_f32', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
@@ -98,7 +98,9 @@ def _workspace(device, nbytes):
 
 
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kc, b_kc, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
-         resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, kscale=None, ks_div=1):
+         resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, kscale=None, ks_div=1, a_colsum=None):
+    """a_colsum (weight-gradient launches only): fused column sums of the stored A; falls back to a separate
+    ofb_colsum launch when the GEMM is not fully streamed."""
     g = GemmArgs()
     g.A, g.B, g.C = ptr(A), ptr(B), ptr(C_out)
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -106,12 +108,17 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kc, b_kc, alpha=1.0, bias=None, 
     g.bias, g.colscale, g.rowscale, g.rs_div = ptr(bias), ptr(colscale), ptr(rowscale), rs_div
     g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
     g.kscale, g.ks_div = ptr(kscale), ks_div
+    fused = a_colsum is not None and bool(lib().ofb_gemm_is_streamed(C.byref(g)))
+    if fused:
+        g.a_colsum = ptr(a_colsum)
     lib().ofb_gemm_workspace_bytes.restype = C.c_int64
     need = lib().ofb_gemm_workspace_bytes(C.byref(g))
     if need > 0:
         ws = _workspace(A.device, need)
         g.workspace, g.workspace_bytes = ptr(ws), ws.numel() * 4
     check(lib().ofb_gemm_f32(C.byref(g), stream()), 'ofb_gemm_f32')
+    if a_colsum is not None and not fused:           # A stored [K][M]: column sums over its K rows
+        colsum(A, lda, K, M, a_colsum, rowscale=kscale, rs_div=ks_div)
 
 
 def splitk_reduce(ws, splits, count, out, accumulate=False):

@@ -40,13 +40,15 @@ def linear_bwd_input(dy2d, W, resid=None, rowscale=None, rs_div=1, act=hip.ACT_N
     return dx
 
 
-def linear_bwd_weight(dy2d, x2d, kscale=None, ks_div=1, out=None):
-    """dW[N,K] = dY[M,N]^T @ X[M,K]: few output tiles, reduction over all tokens -> the GEMM's stream-K tail."""
+def linear_bwd_weight(dy2d, x2d, kscale=None, ks_div=1, out=None, want_bias=False):
+    """dW[N,K] = dY[M,N]^T @ X[M,K]: few output tiles, reduction over all tokens -> the GEMM's stream-K tail.
+    want_bias: also return db[N] = colsum(dY (*kscale)), fused into the same launch."""
     M, N = dy2d.shape
     K = x2d.shape[1]
     dW = out if out is not None else _new(dy2d, N, K)
-    hip.gemm(dy2d, x2d, dW, N, K, M, N, K, K, 0, 0, kscale=kscale, ks_div=ks_div)
-    return dW
+    db = _new(dy2d, N) if want_bias else None
+    hip.gemm(dy2d, x2d, dW, N, K, M, N, K, K, 0, 0, kscale=kscale, ks_div=ks_div, a_colsum=db)
+    return (dW, db) if want_bias else dW
 
 
 def bias_grad(dy2d, rowscale=None, rs_div=1):
@@ -62,12 +64,17 @@ def _gated_linear_bwd(dy2d, x2d, W, b, gvec, resid=None):
     N, K = W.shape
     if gvec is None:
         dx = linear_bwd_input(dy2d, W, resid=resid)
-        return dx, linear_bwd_weight(dy2d, x2d), (bias_grad(dy2d) if b is not None else None), None
+        if b is None:
+            return dx, linear_bwd_weight(dy2d, x2d), None, None
+        dW, db = linear_bwd_weight(dy2d, x2d, want_bias=True)
+        return dx, dW, db, None
     Weff = _new(W, N, K)
     hip.scale_rows(W, gvec, Weff, N, K)
     dx = linear_bwd_input(dy2d, Weff, resid=resid)
-    dWraw = linear_bwd_weight(dy2d, x2d)
-    dbraw = bias_grad(dy2d) if b is not None else None
+    if b is not None:
+        dWraw, dbraw = linear_bwd_weight(dy2d, x2d, want_bias=True)
+    else:
+        dWraw, dbraw = linear_bwd_weight(dy2d, x2d), None
     dW, db, dg = Weff, (_new(W, N) if b is not None else None), _new(W, N)     # reuse Weff storage for dW
     hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K)
     return dx, dW, db, dg
@@ -159,8 +166,10 @@ class AttnBranch(torch.autograd.Function):
         M = B * N
         d2 = _c(dout).view(M, D)
         do = linear_bwd_input(d2, wproj, rowscale=rowscale, rs_div=N)
-        dwp = linear_bwd_weight(d2, o, kscale=rowscale, ks_div=N)
-        dbp = bias_grad(d2, rowscale=rowscale, rs_div=N) if has_pb else None
+        if has_pb:
+            dwp, dbp = linear_bwd_weight(d2, o, kscale=rowscale, ks_div=N, want_bias=True)
+        else:
+            dwp, dbp = linear_bwd_weight(d2, o, kscale=rowscale, ks_div=N), None
         dqkv = torch.empty_like(qkv)
         hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
         dx, dwq, dbq, dg3 = _gated_linear_bwd(dqkv, x2d, wqkv, bqkv, g3, resid=d2 if self_resid else None)
@@ -195,8 +204,10 @@ class MlpBranch(torch.autograd.Function):
         M = B * N
         d2 = _c(dout).view(M, D)
         dhpre = linear_bwd_input(d2, w2, rowscale=rowscale, rs_div=N, act=hip.ACT_DGELU, aux=hpre)
-        dw2 = linear_bwd_weight(d2, h, kscale=rowscale, ks_div=N)
-        db2 = bias_grad(d2, rowscale=rowscale, rs_div=N) if has_b2 else None
+        if has_b2:
+            dw2, db2 = linear_bwd_weight(d2, h, kscale=rowscale, ks_div=N, want_bias=True)
+        else:
+            dw2, db2 = linear_bwd_weight(d2, h, kscale=rowscale, ks_div=N), None
         dx, dw1, db1, dg = _gated_linear_bwd(dhpre, x2d, w1, b1, gv, resid=d2 if self_resid else None)
         dres = None if self_resid else dout
         return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None
@@ -240,8 +251,7 @@ class PatchEmbedTokens(torch.autograd.Function):
         dgm = _new(conv, 2, D)
         hip.colsum(part[1], D, chunks * (L + 1), D, dgm[0])
         hip.colsum(part[2], D, chunks * (L + 1), D, dgm[1])
-        dw = linear_bwd_weight(dconv, patches)
-        db = bias_grad(dconv)
+        dw, db = linear_bwd_weight(dconv, patches, want_bias=True)
         dcls = dpos[0].reshape(cshape)
         return (None, dw.view(wshape), db, None if gshape is None else dgm[0].view(gshape), dpos.view(pshape), dcls,
                 None if mshape is None else dgm[1].view(mshape), None, None)

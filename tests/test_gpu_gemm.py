@@ -63,9 +63,10 @@ def test_gemm_nn_and_tn(M, N, K):
     ks = _mk(((M + 196) // 197,), 10)
     rows = torch.arange(M) // 197
     exp = (dy.double() * ks.double()[rows].unsqueeze(1)).t() @ x.double()
-    dw = torch.empty(N, K, device='cuda')
-    hip.gemm(dyd, xd, dw, N, K, M, N, K, K, 0, 0, kscale=ks.cuda(), ks_div=197)
+    dw, db = torch.empty(N, K, device='cuda'), torch.full((N,), float('nan'), device='cuda')
+    hip.gemm(dyd, xd, dw, N, K, M, N, K, K, 0, 0, kscale=ks.cuda(), ks_div=197, a_colsum=db)
     _check(dw, exp, what=f'tn {N}x{K}x{M}')
+    _check(db, (dy.double() * ks.double()[rows].unsqueeze(1)).sum(0), what='fused bias grad', tol=1e-5)
 
 
 def test_gemm_stream_k_tail_shapes():
