@@ -70,7 +70,7 @@ __device__ __forceinline__ void load_mc(TileRegs& r, const float* __restrict__ X
     const int idx = t + 256 * i, k = k0 + (idx % BK), o = o0 + ((idx / BK) << 2);
     if (!GUARD) {
       f32x4 u = *reinterpret_cast<const f32x4*>(X + (size_t)k * ld + o);
-      if (kscale) u *= kscale[k / ks_div];
+      if (kscale) u *= kscale[ks_div == 1 ? k : k / ks_div];
       r.v[i] = u;
       continue;
     }
@@ -84,7 +84,7 @@ __device__ __forceinline__ void load_mc(TileRegs& r, const float* __restrict__ X
         for (int j = 0; j < 4; ++j)
           if (o + j < O) v[j] = p[j];
       }
-      if (kscale) v *= kscale[k / ks_div];
+      if (kscale) v *= kscale[ks_div == 1 ? k : k / ks_div];
     }
     r.v[i] = v;
   }
@@ -295,7 +295,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
                 const int row = rbase + r4 + 8 * rg;
                 if (g.resid) rv[r4] = g.resid[(size_t)row * g.ldr + col];
                 if (g.act == OFB_ACT_DGELU) av[r4] = g.aux[(size_t)row * g.ldaux + col];
-                if (g.rowscale) rsv[r4] = g.rowscale[row / g.rs_div];
+                if (g.rowscale) rsv[r4] = g.rowscale[g.rs_div == 1 ? row : row / g.rs_div];
               }
 #pragma unroll
               for (int r4 = 0; r4 < 4; ++r4) {
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
                 const bool ok = colok && row < g.M;
                 rv[r4] = (g.resid && ok) ? g.resid[(size_t)row * g.ldr + col] : 0.f;
                 av[r4] = (g.act == OFB_ACT_DGELU && ok) ? g.aux[(size_t)row * g.ldaux + col] : 0.f;
-                rsv[r4] = (g.rowscale && row < g.M) ? g.rowscale[row / g.rs_div] : 1.f;
+                rsv[r4] = (g.rowscale && row < g.M) ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
               }
 #pragma unroll
               for (int r4 = 0; r4 < 4; ++r4) {
@@ -402,7 +402,7 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, 
     if (row >= g.M) continue;
     const float rv = g.resid ? g.resid[(size_t)row * g.ldr + col] : 0.f;
     const float av = (g.act == OFB_ACT_DGELU) ? g.aux[(size_t)row * g.ldaux + col] : 0.f;
-    const float rsv = g.rowscale ? g.rowscale[row / g.rs_div] : 1.f;
+    const float rsv = g.rowscale ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
     g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, sum[j], row, col, bias, cs, rsv, rv, av);
   }
 }

@@ -37,12 +37,14 @@ class DropPath(nn.Module):
         super().__init__()
         self.drop_prob = float(drop_prob)
 
-    def row_scale(self, batch, device, u=None):
+    def row_scale(self, batch, device, u=None, tokens=1):
+        """per-sample keep/keep_prob factor, expanded to one entry per token for the fused branch kernels."""
         if self.drop_prob == 0.0 or not self.training:
             return None
         keep = 1.0 - self.drop_prob
         u = torch.rand(batch, device=device) if u is None else u
-        return torch.floor(keep + u) / keep
+        s = torch.floor(keep + u) / keep
+        return s.repeat_interleave(tokens) if tokens > 1 else s
 
     def forward(self, x):
         s = self.row_scale(x.shape[0], x.device)

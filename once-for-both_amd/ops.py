@@ -137,7 +137,7 @@ def layer_norm_fork(x, gamma, beta, eps):
 
 
 class AttnBranch(torch.autograd.Function):
-    """out = resid + rowscale[b] * proj(attention(g * qkv(x)))   (layers.py:488-517 + residual/DropPath of
+    """out = resid + rowscale[token] * proj(attention(g * qkv(x)))   (layers.py:488-517 + residual/DropPath of
     vision_transformer.py:197,203).  If `resid` is None the branch input is also the residual (the search
     path, where LN output replaces the stream) and its gradient add is fused into the qkv input-grad GEMM."""
 
@@ -154,7 +154,7 @@ class AttnBranch(torch.autograd.Function):
         o, lse = _new(x, M, Hd), _new(x, B * heads, N)
         hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
         r2d = x2d if resid is None else _c(resid).view(M, D)
-        out = linear_fwd(o, wproj, bproj, rowscale=rowscale, rs_div=N, resid=r2d)
+        out = linear_fwd(o, wproj, bproj, rowscale=rowscale, rs_div=1, resid=r2d)
         ctx.save_for_backward(x2d, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale)
         ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None)
         return out.view(B, N, D)
@@ -165,11 +165,11 @@ class AttnBranch(torch.autograd.Function):
         B, N, D, heads, dh, scale, self_resid, has_pb = ctx.meta
         M = B * N
         d2 = _c(dout).view(M, D)
-        do = linear_bwd_input(d2, wproj, rowscale=rowscale, rs_div=N)
+        do = linear_bwd_input(d2, wproj, rowscale=rowscale, rs_div=1)
         if has_pb:
-            dwp, dbp = linear_bwd_weight(d2, o, kscale=rowscale, ks_div=N, want_bias=True)
+            dwp, dbp = linear_bwd_weight(d2, o, kscale=rowscale, ks_div=1, want_bias=True)
         else:
-            dwp, dbp = linear_bwd_weight(d2, o, kscale=rowscale, ks_div=N), None
+            dwp, dbp = linear_bwd_weight(d2, o, kscale=rowscale, ks_div=1), None
         dqkv = torch.empty_like(qkv)
         hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
         dx, dwq, dbq, dg3 = _gated_linear_bwd(dqkv, x2d, wqkv, bqkv, g3, resid=d2 if self_resid else None)
@@ -179,7 +179,8 @@ class AttnBranch(torch.autograd.Function):
 
 
 class MlpBranch(torch.autograd.Function):
-    """out = resid + rowscale[b] * fc2(gelu(g * fc1(x)))   (layers.py:843-865 + residual/DropPath)."""
+    """out = resid + rowscale[token] * fc2(gelu(g * fc1(x)))   (layers.py:843-865 + residual/DropPath).
+    rowscale is the per-sample DropPath factor expanded to one entry per token ([B*N])."""
 
     @staticmethod
     def forward(ctx, x, resid, w1, b1, w2, b2, g, rowscale):
@@ -192,7 +193,7 @@ class MlpBranch(torch.autograd.Function):
         hpre = _new(x, M, hid)
         h = linear_fwd(x2d, w1, b1, colscale=gv, act=hip.ACT_GELU, aux=hpre)
         r2d = x2d if resid is None else _c(resid).view(M, D)
-        out = linear_fwd(h, w2, b2, rowscale=rowscale, rs_div=N, resid=r2d)
+        out = linear_fwd(h, w2, b2, rowscale=rowscale, rs_div=1, resid=r2d)
         ctx.save_for_backward(x2d, hpre, h, w1, b1, w2, gv, rowscale)
         ctx.meta = (B, N, D, resid is None, b2 is not None)
         return out.view(B, N, D)
@@ -203,11 +204,11 @@ class MlpBranch(torch.autograd.Function):
         B, N, D, self_resid, has_b2 = ctx.meta
         M = B * N
         d2 = _c(dout).view(M, D)
-        dhpre = linear_bwd_input(d2, w2, rowscale=rowscale, rs_div=N, act=hip.ACT_DGELU, aux=hpre)
+        dhpre = linear_bwd_input(d2, w2, rowscale=rowscale, rs_div=1, act=hip.ACT_DGELU, aux=hpre)
         if has_b2:
-            dw2, db2 = linear_bwd_weight(d2, h, kscale=rowscale, ks_div=N, want_bias=True)
+            dw2, db2 = linear_bwd_weight(d2, h, kscale=rowscale, ks_div=1, want_bias=True)
         else:
-            dw2, db2 = linear_bwd_weight(d2, h, kscale=rowscale, ks_div=N), None
+            dw2, db2 = linear_bwd_weight(d2, h, kscale=rowscale, ks_div=1), None
         dx, dw1, db1, dg = _gated_linear_bwd(dhpre, x2d, w1, b1, gv, resid=d2 if self_resid else None)
         dres = None if self_resid else dout
         return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None

@@ -79,7 +79,7 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
     def _row_scale(self, x, u=None):
-        return self.drop_path.row_scale(x.shape[0], x.device, u) if isinstance(self.drop_path, DropPath) else None
+        return self.drop_path.row_scale(x.shape[0], x.device, u, tokens=x.shape[1]) if isinstance(self.drop_path, DropPath) else None
 
     def forward(self, x):
         y, xr = ops.layer_norm_fork(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
@@ -122,7 +122,7 @@ class MAEBlock(nn.Module):
         x, weighted_mask_embed, weighted_embed = input
         self.weighted_mask_embed = weighted_mask_embed
         replace = weighted_mask_embed is not None and bool(((weighted_mask_embed < 1) & (weighted_mask_embed > 0)).any())
-        rs = (lambda: self.drop_path.row_scale(x.shape[0], x.device)) if isinstance(self.drop_path, DropPath) else (lambda: None)
+        rs = (lambda: self.drop_path.row_scale(x.shape[0], x.device, tokens=x.shape[1])) if isinstance(self.drop_path, DropPath) else (lambda: None)
         g_a = self.attn.current_gate() if hasattr(self.attn, 'current_gate') else None
         g_m = self.mlp.current_gate() if hasattr(self.mlp, 'current_gate') else None
         return self.run(x, replace, g_a, g_m, rs(), rs()), weighted_mask_embed
@@ -321,12 +321,13 @@ class MIMVisionTransformer(MAEBaseModel):
             forced = self._forced
             u = forced['droppath_u'] if forced and 'droppath_u' in forced else torch.rand(2 * depth, B, device=dev)
         call = 0
+        ntok = x.shape[1]
         for i, blk in enumerate(self.blocks):
             rs = [None, None]
             if u is not None and rates[i] > 0:
                 keep = 1.0 - rates[i]
-                sc = torch.floor(keep + u[call:call + 2]) / keep
-                rs = [sc[0].contiguous(), sc[1].contiguous()]
+                sc = (torch.floor(keep + u[call:call + 2]) / keep).repeat_interleave(ntok, dim=1)   # one factor per token
+                rs = [sc[0], sc[1]]
                 call += 2
             x = blk.run(x, replace, self._module_gate(blk.attn), self._module_gate(blk.mlp), rs[0], rs[1])
         x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
