@@ -12,6 +12,7 @@
 // MFMAs (within one K-iteration) whatever the tile count, and weight gradients (few tiles, long K = all tokens) need
 // no separate split-K path.  Partials are summed in a fixed order: results are run-to-run deterministic.
 #include "ofb_common.h"
+#include <type_traits>
 
 #define BM 128
 #define BN 128
@@ -162,7 +163,7 @@ __device__ __forceinline__ float epilogue_value(float alpha, int act, float* __r
 
 // TAIL = false: the full rounds (tile = v, v + W, ...; fused epilogue).  TAIL = true: the streamed remainder (<= 2 runs of
 // K-iterations per workgroup, raw partial tiles to the workspace).  Same main loop; launched back to back.
-template <bool A_KC, bool B_KC, bool VEC, bool GUARD, bool FULL_EPI, bool TAIL>
+template <bool A_KC, bool B_KC, bool VEC, bool GUARD, bool FULL_EPI, bool TAIL, bool DEFER>
 __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(const ofb_gemm_args g, const Plan p) {
   __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BM * LDP];
   float* As = lds;                    // [2][BM][LDP]
@@ -181,18 +182,18 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   TileRegs ra, rb;
-  auto gload = [&](const Seg& sg, int it) {
+  auto gload = [&](const Seg& sg, int it) __attribute__((always_inline)) {
     const int k0 = it * BK;
     if (A_KC) load_kc<VEC, GUARD>(ra, g.A, g.lda, sg.m0, g.M, k0, g.K, t);
     else load_mc<VEC, GUARD>(ra, g.A, g.lda, sg.m0, g.M, k0, g.K, t, g.kscale, g.ks_div);
     if (B_KC) load_kc<VEC, GUARD>(rb, g.B, g.ldb, sg.n0, g.N, k0, g.K, t);
     else load_mc<VEC, GUARD>(rb, g.B, g.ldb, sg.n0, g.N, k0, g.K, t, nullptr, 1);
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf) __attribute__((always_inline)) {
     if (A_KC) store_kc(ra, As + buf * BM * LDP, t); else store_mc(ra, As + buf * BM * LDP, t);
     if (B_KC) store_kc(rb, Bs + buf * BN * LDP, t); else store_mc(rb, Bs + buf * BN * LDP, t);
   };
-  auto compute = [&](int buf) {
+  auto compute = [&](int buf) __attribute__((always_inline)) {
     // fragment reads: lane (row l31, half h) takes k = 8q + 4h + j (q < BK/8; j = 0..3) with one b128 per q; A and B
     // use the same k <-> (q, h, j) map, so each MFMA step (q, j) multiplies matching k's.
     const float* a_s = As + buf * BM * LDP + (wm0 + l31) * LDP + 4 * h;
@@ -236,6 +237,104 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
   lstore(0);
   __syncthreads();
   int buf = 0;
+
+  if constexpr (DEFER) {
+    // ---- full rounds, full tiles, >= 17 K-iterations: DEFERRED, DISTRIBUTED epilogue -------------------------------
+    // A finished tile's accumulators move to `pacc` and are written out 4 rows x (mi, ni) at a time during the first 16
+    // K-iterations of the NEXT tile (that stretch of the K loop is unrolled so every group index is static): side
+    // inputs are requested before the MFMA block and consumed after it, stores drain while the next MFMA block runs.
+    // The epilogue's HBM traffic is thereby spread under the matrix work instead of arriving as one burst per round
+    // during which every co-resident workgroup idles its MFMA pipe.
+    f32x16 pacc[2][2];
+    bool pend = false;
+    int pm0 = 0, pn0 = 0;
+    float pbias0 = 0.f, pbias1 = 0.f, pcs0 = 1.f, pcs1 = 1.f;
+    f32x4 e_rv = {0.f, 0.f, 0.f, 0.f}, e_av = {0.f, 0.f, 0.f, 0.f}, e_rs = {1.f, 1.f, 1.f, 1.f};
+    auto epi_load = [&](auto G) __attribute__((always_inline)) {          // request the side inputs of group G
+      constexpr int gi = decltype(G)::value, ni = gi >> 3, mi = (gi >> 2) & 1, rg = gi & 3;
+      if (!FULL_EPI) return;
+      const int col = pn0 + wn0 + 32 * ni + l31, rbase = pm0 + wm0 + 32 * mi + 4 * h + 8 * rg;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = rbase + r4;
+        if (g.resid) e_rv[r4] = g.resid[(size_t)row * g.ldr + col];
+        if (g.act == OFB_ACT_DGELU) e_av[r4] = g.aux[(size_t)row * g.ldaux + col];
+        if (g.rowscale) e_rs[r4] = g.rowscale[g.rs_div == 1 ? row : row / g.rs_div];
+      }
+    };
+    auto epi_store = [&](auto G) __attribute__((always_inline)) {         // finish and store group G
+      constexpr int gi = decltype(G)::value, ni = gi >> 3, mi = (gi >> 2) & 1, rg = gi & 3;
+      const int col = pn0 + wn0 + 32 * ni + l31, rbase = pm0 + wm0 + 32 * mi + 4 * h + 8 * rg;
+      const float bias = ni ? pbias1 : pbias0, cs = ni ? pcs1 : pcs0;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int row = rbase + r4;
+        const float a = pacc[mi][ni][4 * rg + r4];
+        if (FULL_EPI) g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, a, row, col, bias, cs, e_rs[r4], e_rv[r4], e_av[r4]);
+        else g.C[(size_t)row * g.ldc + col] = (a * g.alpha + bias) * cs;
+      }
+    };
+    auto kstep = [&](int it, auto G) __attribute__((always_inline)) {     // one K-iteration (not the tile's last) + group G
+      if (pend) epi_load(G);
+      gload(cur, it + 1);
+      compute(buf);
+      __builtin_amdgcn_sched_barrier(0);            // every MFMA of this K-tile stays ahead of the wait / LDS refill
+      lstore(buf ^ 1);
+      if (pend) epi_store(G);
+      __syncthreads();
+      buf ^= 1;
+    };
+#define OFB_IC(n) std::integral_constant<int, n>{}
+    while (true) {
+      kstep(0, OFB_IC(0));   kstep(1, OFB_IC(1));   kstep(2, OFB_IC(2));   kstep(3, OFB_IC(3));
+      kstep(4, OFB_IC(4));   kstep(5, OFB_IC(5));   kstep(6, OFB_IC(6));   kstep(7, OFB_IC(7));
+      kstep(8, OFB_IC(8));   kstep(9, OFB_IC(9));   kstep(10, OFB_IC(10)); kstep(11, OFB_IC(11));
+      kstep(12, OFB_IC(12)); kstep(13, OFB_IC(13)); kstep(14, OFB_IC(14)); kstep(15, OFB_IC(15));
+      for (int it = 16; it + 1 < p.I; ++it) {                              // the rest of the K loop (host guarantees I >= 17)
+        gload(cur, it + 1);
+        compute(buf);
+        __builtin_amdgcn_sched_barrier(0);
+        lstore(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+      }
+      const Seg nxt = get_seg<false>(p, v, sidx + 1);
+      const bool has_next = nxt.ok;
+      if (has_next) gload(nxt, 0);
+      compute(buf);
+      __builtin_amdgcn_sched_barrier(0);
+      // this tile becomes the pending one
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          pacc[mi][ni] = acc[mi][ni];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+      pend = true;
+      pm0 = cur.m0; pn0 = cur.n0;
+      {
+        const int c0 = pn0 + wn0 + l31;
+        pbias0 = g.bias ? g.bias[c0] : 0.f; pbias1 = g.bias ? g.bias[c0 + 32] : 0.f;
+        pcs0 = g.colscale ? g.colscale[c0] : 1.f; pcs1 = g.colscale ? g.colscale[c0 + 32] : 1.f;
+      }
+      if (!has_next) break;
+      lstore(buf ^ 1);
+      __syncthreads();
+      buf ^= 1;
+      ++sidx;
+      cur = nxt;
+    }
+    // the worker's last tile: plain epilogue
+#define OFB_FLUSH(n) epi_load(OFB_IC(n)); epi_store(OFB_IC(n));
+    OFB_FLUSH(0) OFB_FLUSH(1) OFB_FLUSH(2) OFB_FLUSH(3) OFB_FLUSH(4) OFB_FLUSH(5) OFB_FLUSH(6) OFB_FLUSH(7)
+    OFB_FLUSH(8) OFB_FLUSH(9) OFB_FLUSH(10) OFB_FLUSH(11) OFB_FLUSH(12) OFB_FLUSH(13) OFB_FLUSH(14) OFB_FLUSH(15)
+#undef OFB_FLUSH
+#undef OFB_IC
+    return;
+  }
+
   while (true) {
     // all K-iterations of this unit but the last: prefetch the next K-tile of the same unit
     for (int it = cur.it0; it + 1 < cur.it1; ++it) {
@@ -420,10 +519,20 @@ template <bool A_KC, bool B_KC, bool VEC, bool GUARD>
 void launch2(const ofb_gemm_args& g, const Plan& p, bool full, hipStream_t s) {
   const dim3 grid(p.W);
   if (p.full_rounds > 0) {
-    if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, true, false>), grid, dim3(256), 0, s, g, p);
-    else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, false, false>), grid, dim3(256), 0, s, g, p);
+    if constexpr (!GUARD) {
+      if (A_KC && p.I >= 17) {      // deferred, distributed epilogue (needs 16 K-iterations of the next tile to hide under)
+        if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, true, false, true>), grid, dim3(256), 0, s, g, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, false, false, true>), grid, dim3(256), 0, s, g, p);
+      } else {
+        if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, true, false, false>), grid, dim3(256), 0, s, g, p);
+        else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, false, false, false>), grid, dim3(256), 0, s, g, p);
+      }
+    } else {
+      if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, true, false, false>), grid, dim3(256), 0, s, g, p);
+      else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, false, false, false>), grid, dim3(256), 0, s, g, p);
+    }
   }
-  if (p.R > 0) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, false, true>), grid, dim3(256), 0, s, g, p);
+  if (p.R > 0) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, false, true, false>), grid, dim3(256), 0, s, g, p);
 }
 
 template <bool A_KC, bool B_KC>
