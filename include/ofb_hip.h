@@ -111,7 +111,7 @@ int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const 
  * (models/layers.py:510-514; plain Attention.forward :387-391 for the finetune path).
  * qkv: [B*N][3*H*dh] exactly as the qkv Linear writes it (q | k | v, head-major); out: [B*N][H*dh]
  * (the transpose(1,2).reshape of :514 is folded into the store); lse: [B*H][N] row log-sum-exp.
- * Limits: N <= 224, dh <= 64, dh % 4 == 0 (covers DeiT-T/S/B and every pruned d' in {16,24,..,64}).
+ * Limits: N <= 208 (13 tiles of 16 tokens), dh <= 64, dh % 4 == 0 (covers DeiT-T/S/B and every pruned d in {16,24,..,64}).
  * bwd writes dqkv in the same packing (dq | dk | dv).
  * ------------------------------------------------------------------------------------------- */
 int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t H, int32_t dh, float scale,

@@ -18,7 +18,7 @@ def _ref(qkv, B, N, H, dh, scale, dout):
 
 
 # (B, N, H, dh): DeiT-S/T/B head shapes, pruned head dims, short and maximal sequences
-CASES = [(2, 197, 6, 64), (3, 197, 3, 64), (2, 197, 4, 40), (1, 197, 2, 16), (2, 50, 2, 32), (1, 224, 2, 64), (2, 33, 1, 24),
+CASES = [(2, 197, 6, 64), (3, 197, 3, 64), (2, 197, 4, 40), (1, 197, 2, 16), (2, 50, 2, 32), (1, 208, 2, 64), (2, 33, 1, 24),
          (1, 1, 1, 8)]
 
 
@@ -70,6 +70,6 @@ def test_attention_rejects_unsupported():
     from ofb_amd import hip
     t = torch.zeros(300 * 192, device='cuda')
     with pytest.raises(hip.OfbError):
-        hip.attention_fwd(t, t, t, 1, 300, 1, 64, 0.125)     # N > 224
+        hip.attention_fwd(t, t, t, 1, 300, 1, 64, 0.125)     # N > 208
     with pytest.raises(hip.OfbError):
         hip.attention_fwd(t, t, t, 1, 100, 1, 30, 0.125)     # dh % 4 != 0
