@@ -143,9 +143,20 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 
 __global__ void scale_rows_kernel(const float* __restrict__ W, const float* __restrict__ g, float* __restrict__ out, int N,
                                   int K) {
+  // one float4 per thread when rows are 16-B multiples (token matrices), scalar otherwise
   const int64_t total = (int64_t)N * K;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = W[i] * g[i / K];
+  if ((K & 3) == 0) {
+    const int64_t n4 = total >> 2;
+    const int k4 = K >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+      f32x4 v = reinterpret_cast<const f32x4*>(W)[i];
+      v *= g[i / k4];
+      reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+      out[i] = W[i] * g[i / K];
+  }
 }
 
 // Gate folded into a Linear layer, y = g[n] * (x W^T + b)[n]:  given the raw gradients of the UNGATED product
@@ -229,7 +240,8 @@ extern "C" int ofb_colsum(const float* x, int32_t ld, int32_t M, int32_t N, cons
 
 extern "C" int ofb_scale_rows(const float* W, const float* g, float* out, int32_t N, int32_t K, void* stream) {
   if (!W || !g || !out || N <= 0 || K <= 0) return OFB_EINVAL;
-  const int64_t total = (int64_t)N * K;
+  if ((K & 3) == 0 && (!ofb_aligned16(W) || !ofb_aligned16(out))) return OFB_EINVAL;
+  const int64_t total = (K & 3) == 0 ? (int64_t)N * K / 4 : (int64_t)N * K;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(scale_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, W, g, out, N, K);
   return ofb_launch_status();

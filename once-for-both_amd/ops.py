@@ -80,6 +80,15 @@ def _gated_linear_bwd(dy2d, x2d, W, b, gvec, resid=None):
     return dx, dW, db, dg
 
 
+def _droppath_scaled(d2, rowscale):
+    """d2 * rowscale[token]: one HBM pass instead of a scale lookup inside the three GEMMs that consume it."""
+    if rowscale is None:
+        return d2
+    out = torch.empty_like(d2)
+    hip.scale_rows(d2, rowscale, out, d2.shape[0], d2.shape[1])
+    return out
+
+
 class Linear(torch.autograd.Function):
     """y = x W^T + b on 2-D inputs (head: vision_transformer.py:744; decoder 1x1 conv :723)."""
 
@@ -165,11 +174,12 @@ class AttnBranch(torch.autograd.Function):
         B, N, D, heads, dh, scale, self_resid, has_pb = ctx.meta
         M = B * N
         d2 = _c(dout).view(M, D)
-        do = linear_bwd_input(d2, wproj, rowscale=rowscale, rs_div=1)
+        d2s = _droppath_scaled(d2, rowscale)          # gradient of the branch output (DropPath factor applied once)
+        do = linear_bwd_input(d2s, wproj)
         if has_pb:
-            dwp, dbp = linear_bwd_weight(d2, o, kscale=rowscale, ks_div=1, want_bias=True)
+            dwp, dbp = linear_bwd_weight(d2s, o, want_bias=True)
         else:
-            dwp, dbp = linear_bwd_weight(d2, o, kscale=rowscale, ks_div=1), None
+            dwp, dbp = linear_bwd_weight(d2s, o), None
         dqkv = torch.empty_like(qkv)
         hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
         dx, dwq, dbq, dg3 = _gated_linear_bwd(dqkv, x2d, wqkv, bqkv, g3, resid=d2 if self_resid else None)
@@ -204,11 +214,12 @@ class MlpBranch(torch.autograd.Function):
         B, N, D, self_resid, has_b2 = ctx.meta
         M = B * N
         d2 = _c(dout).view(M, D)
-        dhpre = linear_bwd_input(d2, w2, rowscale=rowscale, rs_div=1, act=hip.ACT_DGELU, aux=hpre)
+        d2s = _droppath_scaled(d2, rowscale)
+        dhpre = linear_bwd_input(d2s, w2, act=hip.ACT_DGELU, aux=hpre)
         if has_b2:
-            dw2, db2 = linear_bwd_weight(d2, h, kscale=rowscale, ks_div=1, want_bias=True)
+            dw2, db2 = linear_bwd_weight(d2s, h, want_bias=True)
         else:
-            dw2, db2 = linear_bwd_weight(d2, h, kscale=rowscale, ks_div=1), None
+            dw2, db2 = linear_bwd_weight(d2s, h), None
         dx, dw1, db1, dg = _gated_linear_bwd(dhpre, x2d, w1, b1, gv, resid=d2 if self_resid else None)
         dres = None if self_resid else dout
         return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None

@@ -154,3 +154,41 @@ def test_eval_forward():
     p = O.formula_params(cfg, torch.float64)
     ref = O.search_forward(cfg, p, st, inputs['imgs'].double(), training=False)
     assert rel_err(logits.cpu(), ref['logits']) < 2e-5
+
+
+def test_deit_base_matches_oracle():
+    """BASELINE config 4 shape (DeiT-B: D 768, 12 heads, 6x7 attention cells, 33 embed cells): no golden fixture, so the
+    pinned oracle is the reference here (fp64, same closed-form parameters and inputs)."""
+    cfg = O.Config(**O.DEIT_BASE, num_classes=1000, drop_path_rate=0.1)
+    st = O.SearchState(w_p=0.8, keep_ratio=0.85)
+    B = 2
+    from oracle import fill
+    inputs = dict(imgs=torch.from_numpy(fill.images(B)), labels=torch.from_numpy(fill.labels(B, 1000)),
+                  patch_noise=torch.from_numpy(fill.patch_noise(B)), droppath_u=torch.from_numpy(fill.droppath_noise(24, B)))
+    p = {k: v.requires_grad_(True) for k, v in O.formula_params(cfg, torch.float64).items()}
+    p['alpha_patch'].requires_grad_(False)
+    ref = O.search_step_loss(cfg, p, st, inputs['imgs'].double(), inputs['labels'], inputs['patch_noise'].double(),
+                             inputs['droppath_u'].double(), target_flops=3.6)
+    ref['loss_total'].backward()
+    m = build_product(cfg, st, inputs)
+    from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
+    crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), torch.device('cuda'),
+                         attn_w=0.5, mlp_w=0.5, patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+    imgs, labels = inputs['imgs'].cuda(), inputs['labels'].cuda()
+    logits, (dec, _) = m(imgs)
+    base, arch = crit(imgs, logits, labels, m, 'arch', 3.6, False)
+    total = base + arch + (base / dec).detach() * dec
+    total.backward()
+    torch.cuda.synchronize()
+    assert rel_err(logits.detach().cpu(), ref['logits'].detach()) < 1e-4
+    for k in ['base', 'arch', 'decoder_loss', 'loss_total']:
+        got = dict(base=base, arch=arch, decoder_loss=dec, loss_total=total)[k]
+        _scalar_close(got.detach(), ref[k].detach(), k, 1e-4)
+    worst = 0.0
+    for k, prm in m.named_parameters():
+        if p[k].grad is None or float(p[k].grad.norm()) < 1e-9 or 'qkv.bias' in k:
+            continue
+        e = rel_err(prm.grad.detach().cpu(), p[k].grad)
+        worst = max(worst, e)
+        assert e < TOL, (k, e)
+    print(f'  deit-base worst grad rel err vs fp64 oracle: {worst:.2e}')
