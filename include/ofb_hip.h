@@ -196,11 +196,14 @@ int ofb_norm_targets(const float* imgs, float* out, float* scratch1, float* scra
 /* PMIM masked L1 loss (models/vision_transformer.py:724-729) evaluated in PATCH layout: rec [B*L][C*P*P] is the
  * decoder 1x1-conv output before PixelShuffle (channel c*P*P+i*P+j <-> pixel (c, P*py+i, P*px+j)), targets
  * [B][C][P*gw][P*gw], mask [B*L] in {0,1}.  out2 = {loss, 1/((sum(mask)*P*P+1e-5)*C)}; partial: [B*L] scratch.
- * bwd: drec = upstream[0] * out2[1] * sign(rec - target) * mask. */
-int ofb_pmim_loss_fwd(const float* rec, const float* targets, const float* mask, float* partial, float* out2, int32_t B,
-                      int32_t L, int32_t P, int32_t C, void* stream);
-int ofb_pmim_loss_bwd(const float* rec, const float* targets, const float* mask, const float* out2, const float* upstream,
-                      float* drec, int32_t B, int32_t L, int32_t P, int32_t C, void* stream);
+ * bwd: drec = upstream[0] * out2[1] * sign(rec - target) * mask.
+ * patch_ids (optional): rec holds only n_rows decoded patches, row i = global patch patch_ids[i] (unmasked patches add
+ * exactly 0 to the loss and its gradient, so decoding only the masked ones is exact); else n_rows = B*L. */
+int ofb_pmim_loss_fwd(const float* rec, const float* targets, const float* mask, const int32_t* patch_ids, int32_t n_rows,
+                      float* partial, float* out2, int32_t B, int32_t L, int32_t P, int32_t C, void* stream);
+int ofb_pmim_loss_bwd(const float* rec, const float* targets, const float* mask, const int32_t* patch_ids, int32_t n_rows,
+                      const float* out2, const float* upstream, float* drec, int32_t B, int32_t L, int32_t P, int32_t C,
+                      void* stream);
 
 /* Label-smoothing cross entropy (timm LabelSmoothingCrossEntropy as used by search.py:584 / losses.py:38):
  * loss[0] = mean_b[(1-s)*nll + s*mean_c(-logp)]; grad [B][C] = d loss / d logits; row_loss [B] scratch. */
@@ -208,8 +211,9 @@ int ofb_ls_cross_entropy(const float* logits, const int64_t* labels, float* row_
                          int32_t C, float smoothing, void* stream);
 
 /* Per-sample random patch masking (models/vision_transformer.py:586-612): mask[b][l] = 0 for the len_keep patches
- * with the smallest noise[b][.], 1 for the rest (== gather(mask, argsort(argsort(noise)))). */
-int ofb_patch_mask(const float* noise, float* mask, int32_t B, int32_t L, int32_t len_keep, void* stream);
+ * with the smallest noise[b][.], 1 for the rest (== gather(mask, argsort(argsort(noise)))).  masked_ids (optional,
+ * [B][L-len_keep]): global ids b*L + l of the removed patches, so the decoder can run on those rows only. */
+int ofb_patch_mask(const float* noise, float* mask, int32_t* masked_ids, int32_t B, int32_t L, int32_t len_keep, void* stream);
 
 /* out = x * scalar_dev[0] (chains a device-resident upstream gradient without a host sync) */
 int ofb_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream);

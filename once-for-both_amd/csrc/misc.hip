@@ -131,11 +131,12 @@ __global__ __launch_bounds__(256) void box_v_norm_kernel(const float* __restrict
 // PMIM masked L1 (vision_transformer.py:724-729) in PATCH layout: rec[b*L+l][c*P*P + i*P + j] is pixel
 // (c, P*py+i, P*px+j) after PixelShuffle.  One block per patch; unmasked patches contribute exactly 0.
 // ---------------------------------------------------------------------------------------------------
+// `ids` (optional): rec row i holds global patch ids[i] (only masked patches were decoded); otherwise row i is patch i.
 __global__ __launch_bounds__(256) void pmim_loss_fwd_kernel(const float* __restrict__ rec, const float* __restrict__ tgt,
-                                                            const float* __restrict__ mask, float* __restrict__ partial,
-                                                            int L, int gw, int P, int C, int img) {
+                                                            const float* __restrict__ mask, const int32_t* __restrict__ ids,
+                                                            float* __restrict__ partial, int L, int gw, int P, int C, int img) {
   __shared__ float red[4];
-  const int patch = blockIdx.x, b = patch / L, l = patch % L, py = l / gw, px = l % gw;
+  const int row = blockIdx.x, patch = ids ? ids[row] : row, b = patch / L, l = patch % L, py = l / gw, px = l % gw;
   const float m = mask[patch];
   float s = 0.f;
   if (m != 0.f) {
@@ -143,21 +144,22 @@ __global__ __launch_bounds__(256) void pmim_loss_fwd_kernel(const float* __restr
     for (int o = threadIdx.x; o < C * PP; o += 256) {
       const int c = o / PP, i = (o % PP) / P, j = o % P;
       const float t = tgt[(((size_t)b * C + c) * img + (py * P + i)) * img + px * P + j];
-      s += fabsf(t - rec[(size_t)patch * C * PP + o]) * m;
+      s += fabsf(t - rec[(size_t)row * C * PP + o]) * m;
     }
   }
   s = ofb_wave_sum(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
   __syncthreads();
-  if (threadIdx.x == 0) partial[patch] = red[0] + red[1] + red[2] + red[3];
+  if (threadIdx.x == 0) partial[row] = red[0] + red[1] + red[2] + red[3];
 }
 
 // out[0] = sum(partial) / (sum(mask) + 1e-5) / C ; out[1] = 1 / ((sum(mask)*P*P + 1e-5) * C)  (gradient scale)
 __global__ __launch_bounds__(1024) void pmim_loss_final_kernel(const float* __restrict__ partial, const float* __restrict__ mask,
-                                                               int n, int PP, int C, float* __restrict__ out) {
+                                                               int nrows, int npatch, int PP, int C, float* __restrict__ out) {
   __shared__ float r1[16], r2[16];
   float s = 0.f, ms = 0.f;
-  for (int i = threadIdx.x; i < n; i += 1024) { s += partial[i]; ms += mask[i]; }
+  for (int i = threadIdx.x; i < nrows; i += 1024) s += partial[i];
+  for (int i = threadIdx.x; i < npatch; i += 1024) ms += mask[i];
   s = ofb_wave_sum(s); ms = ofb_wave_sum(ms);
   if ((threadIdx.x & 63) == 0) { r1[threadIdx.x >> 6] = s; r2[threadIdx.x >> 6] = ms; }
   __syncthreads();
@@ -172,10 +174,10 @@ __global__ __launch_bounds__(1024) void pmim_loss_final_kernel(const float* __re
 
 // drec = upstream * scale * sign(rec - tgt) * m
 __global__ __launch_bounds__(256) void pmim_loss_bwd_kernel(const float* __restrict__ rec, const float* __restrict__ tgt,
-                                                            const float* __restrict__ mask, const float* __restrict__ scale2,
-                                                            const float* __restrict__ upstream, float* __restrict__ drec,
-                                                            int L, int gw, int P, int C, int img) {
-  const int patch = blockIdx.x, b = patch / L, l = patch % L, py = l / gw, px = l % gw;
+                                                            const float* __restrict__ mask, const int32_t* __restrict__ ids,
+                                                            const float* __restrict__ scale2, const float* __restrict__ upstream,
+                                                            float* __restrict__ drec, int L, int gw, int P, int C, int img) {
+  const int row = blockIdx.x, patch = ids ? ids[row] : row, b = patch / L, l = patch % L, py = l / gw, px = l % gw;
   const float m = mask[patch];
   const int PP = P * P;
   const float k = scale2[1] * upstream[0] * m;
@@ -184,10 +186,10 @@ __global__ __launch_bounds__(256) void pmim_loss_bwd_kernel(const float* __restr
     if (m != 0.f) {
       const int c = o / PP, i = (o % PP) / P, j = o % P;
       const float t = tgt[(((size_t)b * C + c) * img + (py * P + i)) * img + px * P + j];
-      const float r = rec[(size_t)patch * C * PP + o];
+      const float r = rec[(size_t)row * C * PP + o];
       d = (r > t) ? k : ((r < t) ? -k : 0.f);
     }
-    drec[(size_t)patch * C * PP + o] = d;
+    drec[(size_t)row * C * PP + o] = d;
   }
 }
 
@@ -242,8 +244,8 @@ __global__ __launch_bounds__(256) void mean_kernel(const float* __restrict__ x, 
 
 // mask[b][l] = 1 if patch l is NOT among the len_keep smallest-noise patches of sample b (0 keep / 1 remove):
 // rank by counting == argsort(argsort(noise)) of vision_transformer.py:597-607.
-__global__ __launch_bounds__(256) void patch_mask_kernel(const float* __restrict__ noise, float* __restrict__ mask, int L,
-                                                         int len_keep) {
+__global__ __launch_bounds__(256) void patch_mask_kernel(const float* __restrict__ noise, float* __restrict__ mask,
+                                                         int32_t* __restrict__ masked_ids, int L, int len_keep) {
   extern __shared__ float nz[];
   const int b = blockIdx.x;
   for (int l = threadIdx.x; l < L; l += 256) nz[l] = noise[(size_t)b * L + l];
@@ -253,6 +255,7 @@ __global__ __launch_bounds__(256) void patch_mask_kernel(const float* __restrict
     int r = 0;
     for (int k = 0; k < L; ++k) r += (nz[k] < v) || (nz[k] == v && k < l);
     mask[(size_t)b * L + l] = (r >= len_keep) ? 1.0f : 0.0f;
+    if (masked_ids && r >= len_keep) masked_ids[(size_t)b * (L - len_keep) + (r - len_keep)] = b * L + l;   // global patch id
   }
 }
 
@@ -318,26 +321,30 @@ extern "C" int ofb_norm_targets(const float* imgs, float* out, float* scratch1, 
 }
 
 // rec [B*L][C*P*P] patch layout, targets [B][C][img][img], mask [B*L] in {0,1}; partial [B*L]; out2 = {loss, grad scale}
-extern "C" int ofb_pmim_loss_fwd(const float* rec, const float* targets, const float* mask, float* partial, float* out2,
-                                 int32_t B, int32_t L, int32_t P, int32_t C, void* stream) {
+extern "C" int ofb_pmim_loss_fwd(const float* rec, const float* targets, const float* mask, const int32_t* patch_ids,
+                                 int32_t n_rows, float* partial, float* out2, int32_t B, int32_t L, int32_t P, int32_t C,
+                                 void* stream) {
   if (!rec || !targets || !mask || !partial || !out2 || B <= 0 || L <= 0 || P <= 0 || C <= 0) return OFB_EINVAL;
+  if (patch_ids ? n_rows <= 0 : n_rows != B * L) return OFB_EINVAL;
   int gw = 1;
   while (gw * gw < L) ++gw;
   if (gw * gw != L) return OFB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(pmim_loss_fwd_kernel, dim3(B * L), dim3(256), 0, s, rec, targets, mask, partial, L, gw, P, C, gw * P);
-  hipLaunchKernelGGL(pmim_loss_final_kernel, dim3(1), dim3(1024), 0, s, (const float*)partial, mask, B * L, P * P, C, out2);
+  hipLaunchKernelGGL(pmim_loss_fwd_kernel, dim3(n_rows), dim3(256), 0, s, rec, targets, mask, patch_ids, partial, L, gw, P, C, gw * P);
+  hipLaunchKernelGGL(pmim_loss_final_kernel, dim3(1), dim3(1024), 0, s, (const float*)partial, mask, n_rows, B * L, P * P, C, out2);
   return ofb_launch_status();
 }
 
-extern "C" int ofb_pmim_loss_bwd(const float* rec, const float* targets, const float* mask, const float* out2,
-                                 const float* upstream, float* drec, int32_t B, int32_t L, int32_t P, int32_t C, void* stream) {
+extern "C" int ofb_pmim_loss_bwd(const float* rec, const float* targets, const float* mask, const int32_t* patch_ids,
+                                 int32_t n_rows, const float* out2, const float* upstream, float* drec, int32_t B, int32_t L,
+                                 int32_t P, int32_t C, void* stream) {
   if (!rec || !targets || !mask || !out2 || !upstream || !drec || B <= 0 || L <= 0) return OFB_EINVAL;
+  if (patch_ids ? n_rows <= 0 : n_rows != B * L) return OFB_EINVAL;
   int gw = 1;
   while (gw * gw < L) ++gw;
   if (gw * gw != L) return OFB_EINVAL;
-  hipLaunchKernelGGL(pmim_loss_bwd_kernel, dim3(B * L), dim3(256), 0, (hipStream_t)stream, rec, targets, mask, out2, upstream,
-                     drec, L, gw, P, C, gw * P);
+  hipLaunchKernelGGL(pmim_loss_bwd_kernel, dim3(n_rows), dim3(256), 0, (hipStream_t)stream, rec, targets, mask, patch_ids, out2,
+                     upstream, drec, L, gw, P, C, gw * P);
   return ofb_launch_status();
 }
 
@@ -350,10 +357,12 @@ extern "C" int ofb_ls_cross_entropy(const float* logits, const int64_t* labels, 
   return ofb_launch_status();
 }
 
-extern "C" int ofb_patch_mask(const float* noise, float* mask, int32_t B, int32_t L, int32_t len_keep, void* stream) {
-  if (!noise || !mask || B <= 0 || L <= 0 || len_keep < 0) return OFB_EINVAL;
+extern "C" int ofb_patch_mask(const float* noise, float* mask, int32_t* masked_ids, int32_t B, int32_t L, int32_t len_keep,
+                              void* stream) {
+  if (!noise || !mask || B <= 0 || L <= 0 || len_keep < 0 || len_keep > L) return OFB_EINVAL;
   if (L > 8192) return OFB_ELIMIT;
-  hipLaunchKernelGGL(patch_mask_kernel, dim3(B), dim3(256), L * sizeof(float), (hipStream_t)stream, noise, mask, L, len_keep);
+  hipLaunchKernelGGL(patch_mask_kernel, dim3(B), dim3(256), L * sizeof(float), (hipStream_t)stream, noise, mask, masked_ids, L,
+                     len_keep);
   return ofb_launch_status();
 }
 

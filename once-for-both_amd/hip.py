@@ -258,14 +258,14 @@ def norm_targets(imgs, out, s1, s2, planes, H, W, k=47):
           'ofb_norm_targets')
 
 
-def pmim_loss_fwd(rec, targets, mask, partial, out2, B, L, P, Cc):
-    check(lib().ofb_pmim_loss_fwd(ptr(rec), ptr(targets), ptr(mask), ptr(partial), ptr(out2), _i(B), _i(L), _i(P), _i(Cc),
-                                  stream()), 'ofb_pmim_loss_fwd')
+def pmim_loss_fwd(rec, targets, mask, ids, n_rows, partial, out2, B, L, P, Cc):
+    check(lib().ofb_pmim_loss_fwd(ptr(rec), ptr(targets), ptr(mask), ptr(ids), _i(n_rows), ptr(partial), ptr(out2), _i(B), _i(L),
+                                  _i(P), _i(Cc), stream()), 'ofb_pmim_loss_fwd')
 
 
-def pmim_loss_bwd(rec, targets, mask, out2, upstream, drec, B, L, P, Cc):
-    check(lib().ofb_pmim_loss_bwd(ptr(rec), ptr(targets), ptr(mask), ptr(out2), ptr(upstream), ptr(drec), _i(B), _i(L),
-                                  _i(P), _i(Cc), stream()), 'ofb_pmim_loss_bwd')
+def pmim_loss_bwd(rec, targets, mask, ids, n_rows, out2, upstream, drec, B, L, P, Cc):
+    check(lib().ofb_pmim_loss_bwd(ptr(rec), ptr(targets), ptr(mask), ptr(ids), _i(n_rows), ptr(out2), ptr(upstream), ptr(drec),
+                                  _i(B), _i(L), _i(P), _i(Cc), stream()), 'ofb_pmim_loss_bwd')
 
 
 def ls_cross_entropy(logits, labels, row_loss, loss, grad, B, Cn, smoothing):
@@ -282,8 +282,8 @@ def adamw_step(table_dev, n_tensors, max_numel, lr, beta1, beta2, eps, wd, step)
                                _f(wd), _i(step), stream()), 'ofb_adamw_step')
 
 
-def patch_mask(noise, mask, B, L, len_keep):
-    check(lib().ofb_patch_mask(ptr(noise), ptr(mask), _i(B), _i(L), _i(len_keep), stream()), 'ofb_patch_mask')
+def patch_mask(noise, mask, B, L, len_keep, masked_ids=None):
+    check(lib().ofb_patch_mask(ptr(noise), ptr(mask), ptr(masked_ids), _i(B), _i(L), _i(len_keep), stream()), 'ofb_patch_mask')
 
 
 def diag_mfma_peak(out, blocks, iters):

@@ -279,24 +279,26 @@ def norm_targets(imgs, ksize=47):
 
 
 class PmimLoss(torch.autograd.Function):
-    """sum(|t - x_rec| * M) / (sum(M) + 1e-5) / C evaluated in patch layout (vision_transformer.py:724-729)."""
+    """sum(|t - x_rec| * M) / (sum(M) + 1e-5) / C evaluated in patch layout (vision_transformer.py:724-729).
+    patch_ids (int32, optional): rec holds only those patches (the masked ones); exact, since M = 0 elsewhere."""
 
     @staticmethod
-    def forward(ctx, rec, targets, mask, B, L, P, Cc):
+    def forward(ctx, rec, targets, mask, patch_ids, B, L, P, Cc):
         rec, mask = _c(rec), _c(mask.reshape(-1))
-        partial, out2 = _new(rec, B * L), _new(rec, 2)
-        hip.pmim_loss_fwd(rec, targets, mask, partial, out2, B, L, P, Cc)
-        ctx.save_for_backward(rec, targets, mask, out2)
-        ctx.meta = (B, L, P, Cc)
+        n_rows = rec.shape[0]
+        partial, out2 = _new(rec, n_rows), _new(rec, 2)
+        hip.pmim_loss_fwd(rec, targets, mask, patch_ids, n_rows, partial, out2, B, L, P, Cc)
+        ctx.save_for_backward(rec, targets, mask, out2, patch_ids)
+        ctx.meta = (B, L, P, Cc, n_rows)
         return out2[0]
 
     @staticmethod
     def backward(ctx, up):
-        rec, targets, mask, out2 = ctx.saved_tensors
-        B, L, P, Cc = ctx.meta
+        rec, targets, mask, out2, patch_ids = ctx.saved_tensors
+        B, L, P, Cc, n_rows = ctx.meta
         drec = torch.empty_like(rec)
-        hip.pmim_loss_bwd(rec, targets, mask, out2, _c(up).reshape(1), drec, B, L, P, Cc)
-        return drec, None, None, None, None, None, None
+        hip.pmim_loss_bwd(rec, targets, mask, patch_ids, n_rows, out2, _c(up).reshape(1), drec, B, L, P, Cc)
+        return drec, None, None, None, None, None, None, None
 
 
 class LabelSmoothingCE(torch.autograd.Function):

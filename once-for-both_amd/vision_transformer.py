@@ -239,6 +239,7 @@ class MIMVisionTransformer(MAEBaseModel):
         self._gate_flags = (1, 1, 1)
         self._forced = None         # parity tests: dict(patch_noise=(B,L), droppath_u=(2*depth,B))
         self._gate_out = None
+        self._side_stream = None
 
     # ---- small reference API -------------------------------------------------------------------
     def adjust_masking_ratio(self, epoch, warmup_epochs, total_epochs, min_ratio=0.75, max_ratio=0.95, method='linear'):
@@ -299,7 +300,8 @@ class MIMVisionTransformer(MAEBaseModel):
         forced = self._forced
         noise = forced['patch_noise'] if forced and 'patch_noise' in forced else torch.rand(B, L, device=device)
         mask = torch.empty(B, L, device=device)
-        hip.patch_mask(noise.contiguous(), mask, B, L, len_keep)
+        self._masked_ids = torch.empty(B * (L - len_keep), device=device, dtype=torch.int32)
+        hip.patch_mask(noise.contiguous(), mask, B, L, len_keep, self._masked_ids)
         return mask
 
     def forward_features(self, x):
@@ -333,16 +335,40 @@ class MIMVisionTransformer(MAEBaseModel):
         x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x, mask, None, None
 
+    def _targets_async(self, imgs):
+        """norm_targets(imgs, 47) depends only on the input batch: run its two HBM-bound kernels on a side stream so they
+        overlap the MFMA-bound trunk (the persistent GEMM workgroups leave half of every CU's wave slots free)."""
+        main = torch.cuda.current_stream()
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=imgs.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            targets = norm_targets(imgs, 47)
+        imgs.record_stream(side)
+        return targets, side
+
     def forward(self, imgs):
+        pending = self._targets_async(imgs) if (self.mae and self.training and imgs.is_cuda and
+                                                int(self.num_patches * self.patch_ratio_list[0]) != self.num_patches) else None
         latent, mask, _, _ = self.forward_features(imgs)
         B, T, D = latent.shape
         if self.mae and mask is not None:
             L, P, Cc = T - 1, self.patch_size, self.in_chans
-            z = latent[:, 1:, :].reshape(B * L, D)
+            # only masked patches reach the loss (M = 0 elsewhere, vision_transformer.py:724-729): decode just those rows.
+            # token row of global patch id p = b*L + l is  b*(L+1) + 1 + l = p + p // L + 1
+            ids = self._masked_ids
+            tok_rows = ids + torch.div(ids, L, rounding_mode='floor') + 1
+            z = latent.reshape(B * T, D).index_select(0, tok_rows)
             dec = self.decoder[0]
             rec = ops.Linear.apply(z, dec.weight.view(dec.weight.shape[0], -1), dec.bias)      # 1x1 conv, patch layout
-            targets = norm_targets(imgs, 47)
-            decoder_loss = ops.PmimLoss.apply(rec, targets, mask, B, L, P, Cc)
+            if pending is not None:
+                targets, side = pending
+                torch.cuda.current_stream().wait_stream(side)
+                targets.record_stream(torch.cuda.current_stream())
+            else:
+                targets = norm_targets(imgs, 47)
+            decoder_loss = ops.PmimLoss.apply(rec, targets, mask, ids, B, L, P, Cc)
         else:
             decoder_loss = 0.
         x = ops.Linear.apply(latent[:, 0].contiguous(), self.head.weight, self.head.bias)

@@ -32,8 +32,11 @@ def test_patch_mask_and_ce():
     for keep in (0.95, 0.75, 0.5):
         lk = int(196 * keep)
         mask = torch.empty(5, 196, device='cuda')
-        hip.patch_mask(n.cuda(), mask, 5, 196, lk)
-        assert torch.equal(mask.cpu(), O.keep_mask_from_noise(n, lk))
+        ids = torch.empty(5 * (196 - lk), device='cuda', dtype=torch.int32)
+        hip.patch_mask(n.cuda(), mask, 5, 196, lk, ids)
+        ref = O.keep_mask_from_noise(n, lk)
+        assert torch.equal(mask.cpu(), ref)
+        assert sorted(ids.cpu().tolist()) == torch.nonzero(ref.reshape(-1)).reshape(-1).tolist()
     g = torch.Generator().manual_seed(4)
     logits = (torch.randn(37, 1000, generator=g) * 3).requires_grad_(True)
     labels = torch.randint(0, 1000, (37,), generator=g)
