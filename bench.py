@@ -138,7 +138,7 @@ def main():
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
-    loss_val = float(out[3])
+    loss_val = float(out[3].detach())
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

@@ -87,12 +87,12 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
         if model_ema is not None:
             model_ema.update(model)
         if it % print_freq == 0 or it == n_iter - 1:          # the only host syncs of the loop
-            lv = float(total)
+            lv = float(total.detach())
             if not math.isfinite(lv):
                 print('Loss is {}, stopping training'.format(lv))
                 sys.exit(1)
-            stats = dict(loss_total=lv, loss_param=float(base), loss_arch=float(arch) if arch is not None else 0.0,
-                         loss_decoder=float(dec) if not isinstance(dec, float) else 0.0,
+            stats = dict(loss_total=lv, loss_param=float(base.detach()), loss_arch=float(arch.detach()) if arch is not None else 0.0,
+                         loss_decoder=float(dec.detach()) if not isinstance(dec, float) else 0.0,
                          lr_param=optimizer_param.param_groups[0]['lr'])
             print(f'Epoch: [{epoch}] [{it}/{n_iter}] ' + ' '.join(f'{k}: {v:.5f}' for k, v in stats.items())
                   + f' time: {(time.time() - t0) / (it + 1):.4f}')
@@ -135,7 +135,7 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
         if model_ema is not None:
             model_ema.update(model)
         if it % print_freq == 0 or it == n_iter - 1:
-            lv = float(loss)
+            lv = float(loss.detach())
             if not math.isfinite(lv):
                 print('Loss is {}, stopping training'.format(lv))
                 sys.exit(1)

@@ -206,6 +206,14 @@ class MAEPatchEmbed(PatchEmbed, _Searchable):
             g = None
         return self.norm(self.conv_tokens(x, g).contiguous())
 
+    def fuse(self):
+        """fold the frozen gate into the conv weights (reference layers.py:202-206); one-off, host-driven."""
+        self.fused = True
+        self.score.requires_grad = False
+        sc = self.score.data.reshape(-1)
+        self.proj.weight = nn.Parameter(self.proj.weight.data * sc.view(-1, 1, 1, 1))
+        self.proj.bias = nn.Parameter(self.proj.bias.data * sc)
+
     @staticmethod
     def from_patchembed(patchmodule, embed_search=True):
         return MAEPatchEmbed(patchmodule, embed_search)
@@ -302,6 +310,15 @@ class MAESparseAttention(Attention, _Searchable):
         self.weighted_mask_embed = mask_embed
         return self._branch(x, torch.zeros_like(x), self.current_gate(), None, self.active_heads())
 
+    def fuse(self):
+        """fold the frozen gate into qkv (rows, score tiled x3; reference layers.py:539-543)."""
+        self.fused = True
+        self.score.requires_grad = False
+        sc = self.score.data.reshape(-1).repeat(3)
+        self.qkv.weight = nn.Parameter(self.qkv.weight.data * sc.unsqueeze(-1))
+        if self.qkv.bias is not None:
+            self.qkv.bias = nn.Parameter(self.qkv.bias.data * sc)
+
     @staticmethod
     def from_attn(attn_module, head_search=False, channel_search=False, attn_search=True):
         return MAESparseAttention(attn_module, head_search, channel_search, attn_search)
@@ -378,6 +395,14 @@ class MAESparseMlp(Mlp, _Searchable):
     def forward(self, x, mask_embed=None, weighted_embed=None):
         self.weighted_mask_embed = mask_embed
         return self._branch(x, torch.zeros_like(x), self.current_gate(), None)
+
+    def fuse(self):
+        """fold the frozen gate into fc1 (reference layers.py:867-871)."""
+        self.fused = True
+        self.score.requires_grad = False
+        sc = self.score.data.reshape(-1)
+        self.fc1.weight = nn.Parameter(self.fc1.weight.data * sc.unsqueeze(-1))
+        self.fc1.bias = nn.Parameter(self.fc1.bias.data * sc)
 
     @staticmethod
     def from_mlp(mlp_module, mlp_search=True):

@@ -425,7 +425,16 @@ class MIMVisionTransformer(MAEBaseModel):
         raise NotImplementedError('compress() is SURVEY 8(f)-1, scheduled after the hot path')
 
     def fuse(self):
-        raise NotImplementedError('fuse() is SURVEY 8(f)-2, scheduled after the hot path')
+        """reference vision_transformer.py:747-757: fold every frozen gate into the weights / tokens it scales."""
+        assert self.finish_search == True
+        self.fused = True
+        we = self.patch_embed.score.data.clone().unsqueeze(-2)            # (1, 1, D)
+        if self.mask_token is not None:
+            self.mask_token = nn.Parameter(self.mask_token.data * we)
+        self.cls_token = nn.Parameter(self.cls_token.data * we)
+        self.pos_embed = nn.Parameter(self.pos_embed.data * we)
+        for m in self.searchable_modules:
+            m.fuse()
 
 
 VisionTransformerSearched = MIMVisionTransformer      # north_star alias

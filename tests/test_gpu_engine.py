@@ -1,0 +1,70 @@
+"""BASELINE config 1 plumbing: DeiT-Tiny OFB search, 2-class synthetic subset, bs 8, driven by the epoch engine
+(reference engine.search_one_epoch protocol: progressive masking ratio, w_p warm-up, 3 optimizers, lr schedulers),
+plus the finetune engine on a plain ViT."""
+import types
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class _Sched:
+    def __init__(self):
+        self.calls = []
+
+    def step_update(self, it):
+        self.calls.append(it)
+
+
+def _loader(n_iter, bs, ncls, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [(torch.randn(bs, 3, 224, 224, generator=g), torch.randint(0, ncls, (bs,), generator=g)) for _ in range(n_iter)]
+
+
+def test_search_one_epoch_deit_tiny():
+    import ofb_amd
+    from ofb_amd import engine
+    from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
+    torch.manual_seed(0)
+    dev = torch.device('cuda')
+    m = ofb_amd.create_model('deit_tiny_patch16_224_mim', method='search', num_classes=2, drop_path_rate=0.1, patch_search=False,
+                             mask_ratio=1.0).to(dev)
+    m.correct_require_grad(0.5, 0.5, 0, 0.5)
+    opt_p, opt_a, opt_d = engine.build_optimizers(m, 2.5e-4 * 8 / 256)
+    crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, 0.5, 0.5, 0.0, 0.5, 5.0)
+    args = types.SimpleNamespace(accum_iter=2, warmup_epochs=20, epochs=100)
+    before = {k: v.detach().clone() for k, v in m.named_parameters()}
+    scheds = [_Sched(), _Sched(), _Sched()]
+    stats, finish, pruned, *_ = engine.search_one_epoch(m, crit, 1.0, _loader(6, 8, 2), opt_p, opt_d, opt_a, scheds[0], scheds[1],
+                                                        scheds[2], dev, epoch=3, args=args, print_freq=3)
+    torch.cuda.synchronize()
+    assert not finish and not pruned
+    assert all(torch.isfinite(torch.tensor(v)) for v in stats.values()), stats
+    assert scheds[0].calls == [3 * 6 + 1, 3 * 6 + 3, 3 * 6 + 5]                    # one scheduler step per accumulation boundary
+    # schedules followed the reference formulas at t = epoch + it/len (engine.py:102-117)
+    t_last = 3 + 4 / 6
+    assert abs(m.blocks[0].attn.w_p - (0.99 - 0.89 * t_last / 20)) < 1e-9
+    assert abs(m.patch_ratio_list[0] - (0.95 - 0.2 * t_last / 20)) < 1e-9
+    changed = [k for k, v in m.named_parameters() if v.requires_grad and not torch.equal(v.detach(), before[k])]
+    assert len(changed) == sum(1 for _, v in m.named_parameters() if v.requires_grad)       # every trainable tensor stepped
+    assert torch.equal(m.alpha_patch.detach(), before['alpha_patch'])
+
+
+def test_train_one_epoch_finetune_vit():
+    import ofb_amd
+    from ofb_amd import engine
+    from ofb_amd.optim import AdamW
+    from ofb_amd.losses import DistillationLoss, LabelSmoothingCrossEntropy
+    torch.manual_seed(0)
+    dev = torch.device('cuda')
+    m = ofb_amd.VisionTransformer(embed_dim=192, depth=3, num_heads=3, num_classes=5, drop_path_rate=0.1).to(dev)
+    torch.nn.init.normal_(m.head.weight, std=0.02)
+    opt = AdamW(m.parameters(), None, lr=1e-3, weight_decay=0.05)
+    crit = DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0)
+    args = types.SimpleNamespace(accum_iter=1)
+    data = _loader(1, 8, 5) * 8                                            # the same batch 8 times: the loss must go down
+    sched = _Sched()
+    first = engine.train_one_epoch(m, crit, data[:1], opt, sched, dev, 0, args=args, set_training_mode=False)
+    last = engine.train_one_epoch(m, crit, data, opt, sched, dev, 1, args=args, set_training_mode=False)
+    assert last['loss'] < first['loss'], (first, last)

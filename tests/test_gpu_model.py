@@ -192,3 +192,57 @@ def test_deit_base_matches_oracle():
         worst = max(worst, e)
         assert e < TOL, (k, e)
     print(f'  deit-base worst grad rel err vs fp64 oracle: {worst:.2e}')
+
+
+@pytest.mark.parametrize('mode', ['finished', 'fused'])
+def test_post_search_branches(mode):
+    """MAESparseAttention / MAESparseMlp / MAEPatchEmbed after finish_search (gate = frozen score, layers.py:518-528,
+    859-860, 196-197; plain pre-LN block since the embed staircase is 0/1) and after fuse (no gate, :529-536)."""
+    z, cfg, st, inputs, lr = load_case('micro_a')
+    m = build_product(cfg, st, inputs).eval()
+    p = O.formula_params(cfg, torch.float64)
+    for mod in m.searchable_modules:
+        mod.finish_search = True
+        mod.fused = (mode == 'fused')
+    m.finish_search = True
+    with torch.no_grad():
+        logits, (dec, _) = m(inputs['imgs'].cuda())
+    assert dec == 0.
+    # oracle: an ordinary (un-replaced-stream) ViT whose Linear outputs are scaled by `score` (or not at all when fused)
+    D, H = cfg.embed_dim, cfg.num_heads
+    one = lambda name: (p[name + '.score'] if mode == 'finished' else torch.ones_like(p[name + '.score']))
+    g_e = one('patch_embed')
+    B = inputs['imgs'].shape[0]
+    imgs = inputs['imgs'].double()
+    gh = cfg.img_size // cfg.patch_size
+    patches = imgs.reshape(B, 3, gh, 16, gh, 16).permute(0, 2, 4, 1, 3, 5).reshape(B, gh * gh, -1)
+    x = (patches @ p['patch_embed.proj.weight'].reshape(D, -1).t() + p['patch_embed.proj.bias']) * g_e + p['pos_embed'][:, 1:] * g_e
+    x = torch.cat([((p['cls_token'] + p['pos_embed'][:, :1]) * g_e).expand(B, -1, -1), x], 1)
+    for i in range(cfg.depth):
+        b = f'blocks.{i}.'
+        h1 = O.layer_norm(x, p[b + 'norm1.weight'], p[b + 'norm1.bias'], cfg.ln_eps)
+        x = x + O.gated_attention(h1, p[b + 'attn.qkv.weight'], p[b + 'attn.qkv.bias'], p[b + 'attn.proj.weight'],
+                                  p[b + 'attn.proj.bias'], one(b + 'attn'), H, (D // H) ** -0.5)
+        h2 = O.layer_norm(x, p[b + 'norm2.weight'], p[b + 'norm2.bias'], cfg.ln_eps)
+        x = x + O.gated_mlp(h2, p[b + 'mlp.fc1.weight'], p[b + 'mlp.fc1.bias'], p[b + 'mlp.fc2.weight'], p[b + 'mlp.fc2.bias'],
+                            one(b + 'mlp'))
+    x = O.layer_norm(x, p['norm.weight'], p['norm.bias'], cfg.ln_eps)
+    ref = x[:, 0] @ p['head.weight'].t() + p['head.bias']
+    e = rel_err(logits.cpu(), ref)
+    print(f'  {mode}: logits rel err {e:.2e}')
+    assert e < 2e-5
+
+
+def test_fuse_preserves_outputs():
+    """fuse() (reference vision_transformer.py:747-757) must not change the function the finished model computes."""
+    z, cfg, st, inputs, lr = load_case('micro_a')
+    m = build_product(cfg, st, inputs).eval()
+    for mod in m.searchable_modules:
+        mod.finish_search = True
+    m.finish_search = True
+    with torch.no_grad():
+        before, _ = m(inputs['imgs'].cuda())
+        m.fuse()
+        after, _ = m(inputs['imgs'].cuda())
+    assert m.fused and all(mod.fused for mod in m.searchable_modules)
+    assert rel_err(after.cpu(), before.cpu()) < 1e-5
