@@ -468,7 +468,10 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
 }
 
 // Sums the partial tiles of each streamed tail tile in workgroup order and applies the epilogue.
-// grid (R, 4): block (r, part) handles rows [32*part, 32*part+32) of tail tile r.
+// grid (R, 16): block (r, part) handles rows [8*part, 8*part+8) of tail tile r (weight gradients have only a few dozen
+// tail tiles, each with ~30 contributors: 16 blocks per tile keep every CU busy).
+#define FIX_PARTS 16
+#define FIX_ROWS (BM / FIX_PARTS)
 __global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, const Plan p) {
   const int r = blockIdx.x, part = blockIdx.y, t = threadIdx.x;
   const int tile = p.full_rounds * p.W + r;
@@ -476,14 +479,15 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, 
   const int lo = r * p.I, hi = lo + p.I;         // this tile's run of flattened K-iterations
   const int v0 = lo / p.q, v1 = (hi - 1) / p.q;
   const int c = t & 127, col = n0 + c;
-  float sum[16];
+  constexpr int NJ = FIX_ROWS / 2;
+  float sum[NJ];
 #pragma unroll
-  for (int j = 0; j < 16; ++j) sum[j] = 0.f;
+  for (int j = 0; j < NJ; ++j) sum[j] = 0.f;
   for (int v = v0; v <= v1; ++v) {
     const int slot = (v * p.q < lo) ? 2 * v + 1 : 2 * v;   // second segment if the run started in the previous tile
-    const float* ws = g.workspace + (size_t)slot * (BM * BN) + (size_t)(32 * part + (t >> 7)) * BN + c;
+    const float* ws = g.workspace + (size_t)slot * (BM * BN) + (size_t)(FIX_ROWS * part + (t >> 7)) * BN + c;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) sum[j] += ws[(size_t)(2 * j) * BN];
+    for (int j = 0; j < NJ; ++j) sum[j] += ws[(size_t)(2 * j) * BN];
   }
   if (g.a_colsum && n0 == 0 && part == 0 && t < BM && m0 + t < g.M) {
     float bs = 0.f;
@@ -496,8 +500,8 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, 
   if (col >= g.N) return;
   const float bias = g.bias ? g.bias[col] : 0.f, cs = g.colscale ? g.colscale[col] : 1.f;
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int row = m0 + 32 * part + (t >> 7) + 2 * j;
+  for (int j = 0; j < NJ; ++j) {
+    const int row = m0 + FIX_ROWS * part + (t >> 7) + 2 * j;
     if (row >= g.M) continue;
     const float rv = g.resid ? g.resid[(size_t)row * g.ldr + col] : 0.f;
     const float av = (g.act == OFB_ACT_DGELU) ? g.aux[(size_t)row * g.ldaux + col] : 0.f;
@@ -604,7 +608,7 @@ extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream) {
   else if (g.a_kc) rc = launch<true, false>(g, p, vec, s);
   else rc = launch<false, false>(g, p, vec, s);
   if (rc == 0 && p.R) {
-    hipLaunchKernelGGL(gemm_fixup_kernel, dim3(p.R, 4), dim3(256), 0, s, g, p);
+    hipLaunchKernelGGL(gemm_fixup_kernel, dim3(p.R, FIX_PARTS), dim3(256), 0, s, g, p);
     rc = ofb_launch_status();
   }
   ofb_prof_post(0, s);

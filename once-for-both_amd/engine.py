@@ -143,6 +143,25 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
     return stats
 
 
+@torch.no_grad()
+def evaluate(data_loader, model, device):
+    """reference engine.py:222-257 / evaluate_finetune :260-290: top-1 / top-5 accuracy and CE loss in eval mode.
+    Works for the search model (returns (logits, aux)) and the finetune model (returns logits)."""
+    model.eval()
+    n, loss_sum, c1, c5 = 0, 0.0, 0.0, 0.0
+    for images, target in data_loader:
+        images, target = images.to(device, non_blocking=True), target.to(device, non_blocking=True)
+        out = model(images)
+        logits = out[0] if isinstance(out, tuple) else out
+        logp = torch.log_softmax(logits.float(), -1)                      # metric bookkeeping, not on the training path
+        loss_sum += float(-logp.gather(1, target.view(-1, 1)).sum())
+        top = logits.topk(min(5, logits.shape[1]), 1).indices
+        c1 += float((top[:, 0] == target).sum())
+        c5 += float((top == target.view(-1, 1)).any(1).sum())
+        n += target.numel()
+    return {'loss': loss_sum / max(n, 1), 'acc1': 100.0 * c1 / max(n, 1), 'acc5': 100.0 * c5 / max(n, 1)}
+
+
 def param_groups(model, weight_decay=1e-3):
     """search.py:486-508 grouping -> dict of lists (params / decoder / archs optimizers)."""
     skip = model.no_weight_decay() if hasattr(model, 'no_weight_decay') else []

@@ -68,3 +68,5 @@ def test_train_one_epoch_finetune_vit():
     first = engine.train_one_epoch(m, crit, data[:1], opt, sched, dev, 0, args=args, set_training_mode=False)
     last = engine.train_one_epoch(m, crit, data, opt, sched, dev, 1, args=args, set_training_mode=False)
     assert last['loss'] < first['loss'], (first, last)
+    ev = engine.evaluate(data[:2], m, dev)
+    assert 0.0 <= ev['acc1'] <= ev['acc5'] <= 100.0 and ev['loss'] > 0
