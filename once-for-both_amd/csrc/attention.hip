@@ -104,7 +104,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   for (int kt = 0; kt < ATT_NT; ++kt)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const float pv = expf(S[kt][r] - m);
+      const float pv = __expf(S[kt][r] - m);
       S[kt][r] = pv;
       l += pv;
     }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qrow = qt * ATT_T + 4 * g + r;
-      const float pv = (key < N) ? expf(S[r] - lse_s[qrow]) : 0.f;
+      const float pv = (key < N) ? __expf(S[r] - lse_s[qrow]) : 0.f;
       P[r] = pv;
       dS[r] = pv * (dP[r] - del_s[qrow]);
     }
