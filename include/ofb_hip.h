@@ -160,17 +160,23 @@ typedef struct ofb_gate_grad {
 } ofb_gate_grad;
 
 typedef struct ofb_flops_cfg {
-  int32_t num_patches, embed_dim, num_heads, head_dim, hidden, patch_area, num_classes, depth;
+  int32_t num_patches, embed_dim, num_heads, head_dim, hidden, patch_area, num_classes, depth;   /* ORIGINAL architecture */
   float target;              /* target GMACs */
-  const int32_t* active_heads;   /* [depth] device array or null (= num_heads) */
+  int32_t ln_dim;            /* current embedding width (norm1.normalized_shape[0]); 0 = embed_dim */
+  const int32_t* active_heads;   /* [depth] device array (head_num after compress) or null (= num_heads) */
+  /* modules finished by compress() have a constant staircase sum: slot s of {embed, attn_0, mlp_0, ...} reads
+   * wsum[live_slot[s]] when live_slot[s] >= 0, else wconst[s].  Both null: wsum already has all 1+2*depth slots. */
+  const int32_t* live_slot;  /* [1+2*depth] device array or null */
+  const float* wconst;       /* [1+2*depth] device array or null */
+  int32_t n_live;            /* entries of wsum / dwsum (1+2*depth when live_slot is null) */
 } ofb_flops_cfg;
 
 /* spars_out[3] = {attn, mlp, embed} sums, spars_per_module[n_modules]; max_elems = max H*C over modules. */
 int ofb_gates_fwd(const ofb_gate_desc* descs_dev, int32_t n_modules, int32_t max_elems, int32_t entropy, int32_t var,
                   int32_t norm, float* spars_out, float* spars_per_module, void* stream);
 int ofb_gates_bwd(const ofb_gate_desc* descs_dev, const ofb_gate_grad* grads_dev, int32_t n_modules, void* stream);
-/* wsum[1+2*depth] = {embed, attn_0, mlp_0, ...}; out3 = {((searched-target)/total)^2, total, searched};
- * dwsum = d out3[0] / d wsum. */
+/* wsum[n_live] = staircase sums of the live modules in {embed, attn_0, mlp_0, ...} order; out3 =
+ * {((searched-target)/total)^2, total, searched}; dwsum[n_live] = d out3[0] / d wsum. */
 int ofb_flops_loss(const float* wsum, const ofb_flops_cfg* cfg, float* out3, float* dwsum, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -217,6 +223,13 @@ int ofb_patch_mask(const float* noise, float* mask, int32_t* masked_ids, int32_t
 
 /* out = x * scalar_dev[0] (chains a device-resident upstream gradient without a host sync) */
 int ofb_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream);
+
+/* dst[o][i][k] = src[o][idx[i]][k] for a tensor viewed as [outer][n_src][inner]: the physical cut compress() applies to
+ * weights and to AdamW moments (models/layers.py:272-293 `weight.data.clone()[keep_index, ...]`, optim.py:129-139).
+ * idx: int32 device array [n_idx], every entry in [0, n_src) (entries outside are rejected on the device: the
+ * row is zero-filled and the call reports OFB_EINVAL through `bad`, a 1-int device flag, when given). */
+int ofb_index_select(const float* src, const int32_t* idx, float* dst, int64_t outer, int64_t n_src, int64_t n_idx, int64_t inner,
+                     int32_t* bad, void* stream);
 
 /* Multi-tensor AdamW, one launch per parameter group (optim.py:56-120): decoupled decay, bias-corrected Adam. */
 typedef struct ofb_adamw_tensor { float* p; const float* g; float* m; float* v; int64_t n; } ofb_adamw_tensor;

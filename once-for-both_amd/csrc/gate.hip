@@ -182,19 +182,22 @@ __global__ void spars_finalize_kernel(const ofb_gate_desc* __restrict__ descs, i
   out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
 }
 
-// FLOPs (MAC) model of vision_transformer.py:759-783 with e = wsum[0], (sd_l, hid_l) = wsum[1+2l], wsum[2+2l].
+// FLOPs (MAC) model of vision_transformer.py:759-783 with e = W(0), (sd_l, hid_l) = W(1+2l), W(2+2l), where W(s) is the
+// live staircase sum wsum[live_slot[s]] or, for a module compress() has finished, the constant wconst[s].
 __global__ void flops_loss_kernel(const float* __restrict__ wsum, ofb_flops_cfg c, float* __restrict__ out,
                                   float* __restrict__ dwsum) {
   if (threadIdx.x != 0) return;
   const double N = c.num_patches, n = c.num_patches, D = c.embed_dim, H = c.num_heads, dh = c.head_dim, hid = c.hidden,
-               P2 = c.patch_area, ncls = c.num_classes;
-  const double e = wsum[0];
+               P2 = c.patch_area, ncls = c.num_classes, Dln = c.ln_dim > 0 ? c.ln_dim : c.embed_dim;
+  auto slot = [&](int s) { return c.live_slot ? c.live_slot[s] : s; };
+  auto W = [&](int s) { const int j = slot(s); return (double)(j >= 0 ? wsum[j] : c.wconst[s]); };
+  const double e = W(0);
   double total = N * D * 3.0 * P2, searched = N * e * 3.0 * P2, de = N * 3.0 * P2;
   for (int l = 0; l < c.depth; ++l) {
-    const double sd = wsum[1 + 2 * l], hh = wsum[2 + 2 * l];
+    const double sd = W(1 + 2 * l), hh = W(2 + 2 * l);
     const double aH = c.active_heads ? (double)c.active_heads[l] : H;
     total += 2.0 * D * N;
-    searched += 2.0 * D * n;
+    searched += 2.0 * Dln * n;
     total += N * (H * dh * 3.0 * H * dh) + 3.0 * N * H * dh + H * N * dh * N + H * N * N + 5.0 * H * N * N + H * N * N * dh +
              N * (H * dh * H * dh) + N * H * dh;
     searched += n * (e * 3.0 * sd) + 3.0 * n * sd + n * n * sd + aH * n * n + 5.0 * aH * n * n + n * n * sd + n * (sd * e) + n * e;
@@ -204,8 +207,9 @@ __global__ void flops_loss_kernel(const float* __restrict__ wsum, ofb_flops_cfg 
     searched += (e * hh + hh * e + e + hh) * n;
     const double dhh = (2.0 * e + 1.0) * n;
     de += (2.0 * hh + 1.0) * n;
-    dwsum[1 + 2 * l] = (float)dsd;   // provisional: scaled below
-    dwsum[2 + 2 * l] = (float)dhh;
+    const int ja = slot(1 + 2 * l), jm = slot(2 + 2 * l);
+    if (ja >= 0) dwsum[ja] = (float)dsd;   // provisional: scaled below
+    if (jm >= 0) dwsum[jm] = (float)dhh;
   }
   total += D * ncls;
   searched += e * ncls;
@@ -217,8 +221,10 @@ __global__ void flops_loss_kernel(const float* __restrict__ wsum, ofb_flops_cfg 
   out[0] = (float)(diff * diff);
   out[1] = (float)total;
   out[2] = (float)searched;
-  dwsum[0] = (float)(k * de);
-  for (int l = 0; l < 2 * c.depth; ++l) dwsum[1 + l] = (float)(k * (double)dwsum[1 + l]);
+  const int je = slot(0);
+  for (int j = 0; j < c.n_live; ++j)
+    if (j != je) dwsum[j] = (float)(k * (double)dwsum[j]);
+  if (je >= 0) dwsum[je] = (float)(k * de);
 }
 
 }  // namespace
@@ -239,7 +245,10 @@ extern "C" int ofb_gates_bwd(const ofb_gate_desc* descs_dev, const ofb_gate_grad
 }
 
 extern "C" int ofb_flops_loss(const float* wsum, const ofb_flops_cfg* cfg, float* out3, float* dwsum, void* stream) {
-  if (!wsum || !cfg || !out3 || !dwsum || cfg->depth <= 0) return OFB_EINVAL;
+  if (!cfg || !out3 || cfg->depth <= 0 || cfg->n_live < 0 || cfg->n_live > 1 + 2 * cfg->depth) return OFB_EINVAL;
+  if (cfg->n_live > 0 && (!wsum || !dwsum)) return OFB_EINVAL;
+  if ((cfg->live_slot == nullptr) != (cfg->wconst == nullptr)) return OFB_EINVAL;
+  if (!cfg->live_slot && cfg->n_live != 1 + 2 * cfg->depth) return OFB_EINVAL;
   hipLaunchKernelGGL(flops_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, wsum, *cfg, out3, dwsum);
   return ofb_launch_status();
 }

@@ -265,6 +265,22 @@ __global__ void scale_by_scalar_kernel(const float* __restrict__ x, const float*
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = x[i] * k;
 }
 
+// index_select along the middle axis of an [outer][n_src][inner] view (compress(): weight / moment slicing)
+__global__ __launch_bounds__(256) void index_select_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                           float* __restrict__ dst, int64_t n_src, int64_t n_idx, int64_t inner,
+                                                           int64_t total, int32_t* __restrict__ bad) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t k = e % inner, oi = e / inner, i = oi % n_idx, o = oi / n_idx;
+    const int32_t j = idx[i];
+    if (j < 0 || j >= n_src) {
+      if (bad) *bad = 1;
+      dst[e] = 0.f;
+    } else {
+      dst[e] = src[(o * n_src + j) * inner + k];
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // multi-tensor AdamW (optim.py:56-120): p *= 1 - lr*wd; m,v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 // ---------------------------------------------------------------------------------------------------
@@ -370,6 +386,16 @@ extern "C" int ofb_scale_by_scalar(const float* x, const float* scalar_dev, floa
   if (!x || !scalar_dev || !out || n <= 0) return OFB_EINVAL;
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipLaunchKernelGGL(scale_by_scalar_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, scalar_dev, out, n);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_index_select(const float* src, const int32_t* idx, float* dst, int64_t outer, int64_t n_src, int64_t n_idx,
+                                int64_t inner, int32_t* bad, void* stream) {
+  if (!src || !idx || !dst || outer <= 0 || n_src <= 0 || n_idx <= 0 || inner <= 0) return OFB_EINVAL;
+  const int64_t total = outer * n_idx * inner;
+  const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(index_select_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, idx, dst, n_src, n_idx, inner,
+                     total, bad);
   return ofb_launch_status();
 }
 

@@ -98,16 +98,13 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
                   + f' time: {(time.time() - t0) / (it + 1):.4f}')
         every = max(1, n_iter // 3 // accum_iter)
         if not finish_search and boundary and ((it + 1) // accum_iter) % every == 0 and hasattr(net, 'compress'):
-            try:
-                finish_search, execute_prune, optimizer_param, optimizer_decoder, optimizer_arch = net.compress(
-                    0.2, optimizer_param, optimizer_decoder, optimizer_arch)
-                execute_pruned |= execute_prune
-                if reducer is not None and execute_prune:
-                    reducer.rebuild([p for p in net.parameters()])
-                if finish_search:
-                    optimizer_arch, lr_scheduler_arch = None, None
-            except NotImplementedError:
-                pass
+            finish_search, execute_prune, optimizer_param, optimizer_decoder, optimizer_arch = net.compress(
+                0.2, optimizer_param, optimizer_decoder, optimizer_arch)
+            execute_pruned |= execute_prune
+            if reducer is not None and execute_prune:            # compress() replaced Parameters: re-bucket the exchange
+                reducer.rebuild([p for p in net.parameters()])
+            if finish_search:
+                optimizer_arch, lr_scheduler_arch = None, None
     return stats, finish_search, execute_pruned, optimizer_param, optimizer_decoder, optimizer_arch
 
 

@@ -43,7 +43,7 @@ SYMBOLS = [
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets',
-    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
+    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
 ]
 
 
@@ -208,7 +208,8 @@ class GateGrad(C.Structure):
 class FlopsCfg(C.Structure):
     _fields_ = [('num_patches', C.c_int32), ('embed_dim', C.c_int32), ('num_heads', C.c_int32), ('head_dim', C.c_int32),
                 ('hidden', C.c_int32), ('patch_area', C.c_int32), ('num_classes', C.c_int32), ('depth', C.c_int32),
-                ('target', C.c_float), ('active_heads', C.c_void_p)]
+                ('target', C.c_float), ('ln_dim', C.c_int32), ('active_heads', C.c_void_p), ('live_slot', C.c_void_p),
+                ('wconst', C.c_void_p), ('n_live', C.c_int32)]
 
 
 class AdamwTensor(C.Structure):
@@ -275,6 +276,35 @@ def ls_cross_entropy(logits, labels, row_loss, loss, grad, B, Cn, smoothing):
 
 def scale_by_scalar(x, scalar_dev, out, n):
     check(lib().ofb_scale_by_scalar(ptr(x), ptr(scalar_dev), ptr(out), C.c_int64(n), stream()), 'ofb_scale_by_scalar')
+
+
+def index_select(t, index, dim):
+    """t.index_select(dim, index) on the device through ofb_index_select (compress() surgery).  `index`: integer tensor or
+    list; returns a new contiguous tensor.  Out-of-range indices raise OfbError."""
+    if not t.is_cuda:
+        raise OfbError('ofb_index_select needs a device tensor (no CPU fallback)')
+    t = t if t.is_contiguous() else t.contiguous()
+    dim = dim % t.dim()
+    idx = torch.as_tensor(index).reshape(-1)
+    on_host = not idx.is_cuda
+    if on_host and idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= t.shape[dim]):
+        raise OfbError('ofb_index_select: index out of range')
+    idx = idx.to(device=t.device, dtype=torch.int32)
+    shape = list(t.shape)
+    outer = 1
+    for s in shape[:dim]:
+        outer *= s
+    inner = 1
+    for s in shape[dim + 1:]:
+        inner *= s
+    n_src, n_idx = shape[dim], idx.numel()
+    out = torch.empty(shape[:dim] + [n_idx] + shape[dim + 1:], device=t.device, dtype=torch.float32)
+    bad = None if on_host else torch.zeros(1, device=t.device, dtype=torch.int32)     # host-built indices were checked above
+    check(lib().ofb_index_select(ptr(t), ptr(idx), ptr(out), C.c_int64(outer), C.c_int64(n_src), C.c_int64(n_idx), C.c_int64(inner),
+                                 ptr(bad), stream()), 'ofb_index_select')
+    if bad is not None and int(bad.item()):
+        raise OfbError('ofb_index_select: index out of range')
+    return out
 
 
 def adamw_step(table_dev, n_tensors, max_numel, lr, beta1, beta2, eps, wd, step):

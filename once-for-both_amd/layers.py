@@ -10,7 +10,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import hip, ops
 
 
 def to_2tuple(x):
@@ -155,6 +155,87 @@ class _Searchable:
             self._single_gate()
         return self._wr_view(), self._prob_view()
 
+    # ---- compress(): host decisions (reference layers.py:218-338 / 559-696 / 883-992) ----------------------
+    def _averaged_alpha(self):
+        a = self.alpha.data
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+            a = reduce_tensor(a)
+        return a
+
+    def _prune_cells(self, thresh, optimizer_archs, prefix, alpha_reduced=None):
+        """Cell-level part of compress().  Cells whose probability among the live cells is <= thresh / n_live die: their
+        switch goes off, their alpha is zeroed and alpha's optimizer state restarts.  Returns None when the module's
+        shapes stay as they are, else (finished, i_max, j_max): the module must be cut to option (i_max, j_max) of
+        its search space - the single surviving cell (finished) or the largest surviving head / channel option."""
+        sw = self.switch_cell.detach().to('cpu', torch.bool)
+        if int(sw.sum()) == 1:
+            self.finish_search, self.execute_prune = True, False
+            self.alpha.requires_grad = False
+            return None
+        a_dev = self._averaged_alpha() if alpha_reduced is None else alpha_reduced
+        a = a_dev.detach().to('cpu', torch.float32)
+        thr = thresh / int(sw.sum())
+        prob = plan_cell_pruning(a, sw, thr)
+        if prob is None:
+            self.execute_prune = False
+            return None
+        self.execute_prune = True
+        sw = prob > thr
+        old_alpha = self.alpha
+        self.alpha = nn.Parameter(torch.where(sw, a, torch.zeros_like(a)).to(old_alpha.device), requires_grad=old_alpha.requires_grad)
+        self.switch_cell = sw
+        if optimizer_archs is not None and old_alpha.requires_grad:
+            optimizer_archs.update(old_alpha, self.alpha, f'{prefix}.alpha', 0, torch.arange(self.alpha.shape[-1]), dim=-1,
+                                   initialize=True)
+        self._wr = self._g = None
+        on = torch.nonzero(sw)
+        if int(sw.sum()) == 1:
+            self.finish_search = True
+            if optimizer_archs is not None and self.alpha.requires_grad:
+                self.alpha.requires_grad = False
+                optimizer_archs.update(self.alpha, self.alpha, f'{prefix}.alpha', 0, None, dim=-1)
+            self.alpha.requires_grad = False
+            return True, int(on[0, 0]), int(on[0, 1])
+        if int(sw[:, -1].sum()) == 0 or int(sw[-1, :].sum()) == 0:
+            i_max, j_max = int(on[:, 0].max()), int(on[:, 1].max())
+            old_alpha = self.alpha
+            self.alpha = nn.Parameter(old_alpha.data[:i_max + 1, :j_max + 1].clone(), requires_grad=old_alpha.requires_grad)
+            self.switch_cell = sw[:i_max + 1, :j_max + 1].clone()
+            if optimizer_archs is not None and old_alpha.requires_grad:
+                optimizer_archs.update(old_alpha, self.alpha, f'{prefix}.alpha', 0,
+                                       [torch.arange(i_max + 1), torch.arange(j_max + 1)], dim=[0, -1])
+            return False, i_max, j_max
+        return None
+
+    def _swap(self, owner, attr, new_data, optimizer, name, group_idx, keep_idx, dim, initialize=False):
+        """replace parameter `owner.attr` by `new_data` (same requires_grad) and let the optimizer follow."""
+        old = getattr(owner, attr)
+        new = nn.Parameter(new_data, requires_grad=old.requires_grad)
+        setattr(owner, attr, new)
+        if optimizer is not None and old.requires_grad:
+            optimizer.update(old, new, name, group_idx, keep_idx, dim, initialize=initialize)
+        return new
+
+
+def plan_cell_pruning(alpha, switch, thr):
+    """Pure host rule of compress() (reference layers.py:230-239): softmax over the live cells of `alpha`; returns the
+    probabilities (0 for dead cells) when at least one live cell is <= thr, else None (nothing to prune)."""
+    masked = torch.where(switch, alpha, torch.full_like(alpha, float('-inf')))
+    prob = torch.softmax(masked.reshape(-1), 0).reshape_as(alpha)
+    return prob if float(prob[switch].min()) <= thr else None
+
+
+def rank_cut(score, n_chan, n_head=None):
+    """Which channels (and heads) survive a cut, best first (reference layers.py:268-269, 613-619): per head the
+    `n_chan` highest scores; heads ranked by their summed sigmoid(score).  Host tensors; returns (head_index or None,
+    chan_index [heads_kept][n_chan])."""
+    score = score.detach().to('cpu', torch.float32)
+    chan = torch.argsort(score, dim=1, descending=True)[:, :n_chan]
+    if n_head is None:
+        return None, chan
+    heads = torch.argsort(score.sigmoid().sum(-1), dim=0, descending=True)[:n_head] if score.shape[0] != 1 else torch.arange(n_head)
+    return heads, chan[heads]
+
 
 class MAEPatchEmbed(PatchEmbed, _Searchable):
     """reference models/layers.py:131-365 (search state + embed gate)."""
@@ -184,8 +265,9 @@ class MAEPatchEmbed(PatchEmbed, _Searchable):
         return [int(r * self.embed_dim) for r in self.embed_ratio_list]
 
     def gate_plan(self):
-        return dict(H=1, C=self.score.shape[-1], A0=1, A1=len(self.embed_ratio_list), kind=2, head_thr=[1],
-                    chan_thr=self._chan_thr(), norm_coef=1e-4, w_p=float(self.w_p),
+        A1 = self.alpha.shape[-1]                      # compress() drops trailing options
+        return dict(H=1, C=self.score.shape[-1], A0=1, A1=A1, kind=2, head_thr=[1],
+                    chan_thr=self._chan_thr()[:A1], norm_coef=1e-4, w_p=float(self.w_p),
                     on=[int(v) for v in self.switch_cell.reshape(-1).tolist()])
 
     def _shape_wm(self, wm):
@@ -205,6 +287,33 @@ class MAEPatchEmbed(PatchEmbed, _Searchable):
         else:
             g = None
         return self.norm(self.conv_tokens(x, g).contiguous())
+
+    def compress(self, thresh, optimizer_params, optimizer_decoder, optimizer_archs, prefix='', alpha_reduced=None):
+        """reference layers.py:218-338.  Returns (keep_index | None, optimizer_params, optimizer_decoder, optimizer_archs);
+        keep_index (host int64 tensor) lists the surviving embedding channels, best score first."""
+        cut = self._prune_cells(thresh, optimizer_archs, prefix, alpha_reduced)
+        if cut is None:
+            return None, optimizer_params, optimizer_decoder, optimizer_archs
+        finished, _, j = cut
+        width = self._chan_thr()[j]
+        _, chan = rank_cut(self.score, width)
+        keep = chan.reshape(-1)
+        dev = self.proj.weight.device
+        sc = self.score.detach().to('cpu', torch.float32)[:, keep]
+        if finished:                                   # the gate freezes into a trainable per-channel scale (:272)
+            sc = self.w_p * sc.sigmoid() + (1 - self.w_p) * torch.ones_like(sc)
+        else:
+            self.mask = self.mask[:j + 1, :width]
+        self.weighted_mask = torch.ones(1, width, device=dev)          # recomputed by the next forward while live
+        self.proj.out_channels = width
+        self._swap(self, 'score', sc.to(dev), optimizer_params, f'{prefix}.score', 0, keep, -1, initialize=finished)
+        self._swap(self.proj, 'weight', hip.index_select(self.proj.weight.data, keep, 0), optimizer_params, f'{prefix}.proj.weight', 1, keep, 0)
+        self._swap(self.proj, 'bias', hip.index_select(self.proj.bias.data, keep, 0), optimizer_params, f'{prefix}.proj.bias', 0, keep, -1)
+        if self.norm_layer:
+            self.norm.normalized_shape[0] = width
+            self._swap(self.norm, 'weight', hip.index_select(self.norm.weight.data, keep, 0), optimizer_params, f'{prefix}.norm.weight', 0, keep, -1)
+            self._swap(self.norm, 'bias', hip.index_select(self.norm.bias.data, keep, 0), optimizer_params, f'{prefix}.norm.bias', 0, keep, -1)
+        return keep, optimizer_params, optimizer_decoder, optimizer_archs
 
     def fuse(self):
         """fold the frozen gate into the conv weights (reference layers.py:202-206); one-off, host-driven."""
@@ -285,8 +394,9 @@ class MAESparseAttention(Attention, _Searchable):
 
     def gate_plan(self):
         H, d = self.score.shape
-        return dict(H=H, C=d, A0=len(self.head_num_list), A1=len(self.qkv_channel_ratio_list), kind=0,
-                    head_thr=list(self.head_num_list), chan_thr=self._chan_thr(), norm_coef=4e-4, w_p=float(self.w_p),
+        A0, A1 = self.alpha.shape                      # compress() drops trailing head / channel options
+        return dict(H=H, C=d, A0=A0, A1=A1, kind=0,
+                    head_thr=list(self.head_num_list)[:A0], chan_thr=self._chan_thr()[:A1], norm_coef=4e-4, w_p=float(self.w_p),
                     on=[int(v) for v in self.switch_cell.reshape(-1).tolist()])
 
     def _shape_wm(self, wm):
@@ -309,6 +419,46 @@ class MAESparseAttention(Attention, _Searchable):
     def forward(self, x, mask_embed=None, weighted_embed=None):
         self.weighted_mask_embed = mask_embed
         return self._branch(x, torch.zeros_like(x), self.current_gate(), None, self.active_heads())
+
+    def compress(self, thresh, optimizer_params, optimizer_decoder, optimizer_archs, prefix='', alpha_reduced=None):
+        """reference layers.py:559-696: cut heads (ranked by summed sigmoid(score)) and per-head q/k/v channels (ranked by
+        score) down to the surviving option; proj loses the matching input columns."""
+        cut = self._prune_cells(thresh, optimizer_archs, prefix, alpha_reduced)
+        if cut is None:
+            return optimizer_params, optimizer_decoder, optimizer_archs
+        finished, i, j = cut
+        H_cur, d_cur = self.score.shape
+        n_head, n_chan = self.head_num_list[i], self._chan_thr()[j]
+        heads, chan = rank_cut(self.score, n_chan, n_head)
+        dev = self.qkv.weight.device
+        sc = torch.gather(self.score.detach().to('cpu', torch.float32)[heads], 1, chan)
+        if finished:
+            sc = self.w_p * sc.sigmoid() + (1 - self.w_p) * torch.ones_like(sc)
+        else:
+            self.mask = self.mask[:i + 1, :n_head, :j + 1, :n_chan]
+        self.weighted_mask = torch.ones(n_head, 1, n_chan, device=dev)
+        self.head_num = n_head
+        self.scale = self.qk_scale or n_chan ** -0.5
+        rows = (heads.view(-1, 1) * d_cur + chan).reshape(-1)                   # positions inside one of q / k / v
+        qkv_rows = torch.cat([rows + t * H_cur * d_cur for t in range(3)])
+        self.qkv.out_features, self.proj.in_features = 3 * n_head * n_chan, n_head * n_chan
+        self._swap(self, 'score', sc.to(dev), optimizer_params, f'{prefix}.score', 0, [heads, chan], [0, -1], initialize=finished)
+        self._swap(self.qkv, 'weight', hip.index_select(self.qkv.weight.data, qkv_rows, 0), optimizer_params, f'{prefix}.qkv.weight', 1, qkv_rows, 0)
+        if self.qkv.bias is not None:
+            self._swap(self.qkv, 'bias', hip.index_select(self.qkv.bias.data, qkv_rows, 0), optimizer_params, f'{prefix}.qkv.bias', 0, qkv_rows, -1)
+        self._swap(self.proj, 'weight', hip.index_select(self.proj.weight.data, rows, 1), optimizer_params, f'{prefix}.proj.weight', 1, rows, -1)
+        return optimizer_params, optimizer_decoder, optimizer_archs
+
+    def compress_patchembed(self, info, optimizer_params, optimizer_decoder, optimizer_archs, prefix=''):
+        """the embedding width shrank (reference layers.py:698-728): qkv loses input columns, proj output rows.
+        info: kept-channel index tensor, or a keep ratio / count (first channels)."""
+        keep = _embed_keep(info, self.in_features)
+        self.qkv.in_features = self.proj.out_features = keep.numel()
+        self._swap(self.qkv, 'weight', hip.index_select(self.qkv.weight.data, keep, 1), optimizer_params, f'{prefix}.qkv.weight', 1, keep, -1)
+        self._swap(self.proj, 'weight', hip.index_select(self.proj.weight.data, keep, 0), optimizer_params, f'{prefix}.proj.weight', 1, keep, 0)
+        if self.proj.bias is not None:
+            self._swap(self.proj, 'bias', hip.index_select(self.proj.bias.data, keep, 0), optimizer_params, f'{prefix}.proj.bias', 0, keep, -1)
+        return optimizer_params, optimizer_decoder, optimizer_archs
 
     def fuse(self):
         """fold the frozen gate into qkv (rows, score tiled x3; reference layers.py:539-543)."""
@@ -374,8 +524,9 @@ class MAESparseMlp(Mlp, _Searchable):
         return [int(r * self.hidden_features) for r in self.hidden_ratio_list]
 
     def gate_plan(self):
-        return dict(H=1, C=self.score.shape[-1], A0=1, A1=len(self.hidden_ratio_list), kind=1, head_thr=[1],
-                    chan_thr=self._chan_thr(), norm_coef=1e-4, w_p=float(self.w_p),
+        A1 = self.alpha.shape[-1]
+        return dict(H=1, C=self.score.shape[-1], A0=1, A1=A1, kind=1, head_thr=[1],
+                    chan_thr=self._chan_thr()[:A1], norm_coef=1e-4, w_p=float(self.w_p),
                     on=[int(v) for v in self.switch_cell.reshape(-1).tolist()])
 
     def _shape_wm(self, wm):
@@ -396,6 +547,39 @@ class MAESparseMlp(Mlp, _Searchable):
         self.weighted_mask_embed = mask_embed
         return self._branch(x, torch.zeros_like(x), self.current_gate(), None)
 
+    def compress(self, thresh, optimizer_params, optimizer_decoder, optimizer_archs, prefix='', alpha_reduced=None):
+        """reference layers.py:883-992: keep the hidden channels with the highest scores; fc2 loses the matching columns."""
+        cut = self._prune_cells(thresh, optimizer_archs, prefix, alpha_reduced)
+        if cut is None:
+            return optimizer_params, optimizer_decoder, optimizer_archs
+        finished, _, j = cut
+        width = self._chan_thr()[j]
+        _, chan = rank_cut(self.score, width)
+        keep = chan.reshape(-1)
+        dev = self.fc1.weight.device
+        sc = self.score.detach().to('cpu', torch.float32)[:, keep]
+        if finished:
+            sc = self.w_p * sc.sigmoid() + (1 - self.w_p) * torch.ones_like(sc)
+        else:
+            self.mask = self.mask[:j + 1, :width]
+        self.weighted_mask = torch.ones(1, width, device=dev)
+        self.fc1.out_features = self.fc2.in_features = width
+        self._swap(self, 'score', sc.to(dev), optimizer_params, f'{prefix}.score', 0, keep, -1, initialize=finished)
+        self._swap(self.fc1, 'weight', hip.index_select(self.fc1.weight.data, keep, 0), optimizer_params, f'{prefix}.fc1.weight', 1, keep, 0)
+        self._swap(self.fc1, 'bias', hip.index_select(self.fc1.bias.data, keep, 0), optimizer_params, f'{prefix}.fc1.bias', 0, keep, -1)
+        self._swap(self.fc2, 'weight', hip.index_select(self.fc2.weight.data, keep, 1), optimizer_params, f'{prefix}.fc2.weight', 1, keep, -1)
+        return optimizer_params, optimizer_decoder, optimizer_archs
+
+    def compress_patchembed(self, info, optimizer_params, optimizer_decoder, optimizer_archs, prefix=''):
+        """the embedding width shrank (reference layers.py:994-1025): fc1 loses input columns, fc2 output rows."""
+        keep = _embed_keep(info, self.in_features)
+        self.fc1.in_features = self.fc2.out_features = keep.numel()
+        self._swap(self.fc1, 'weight', hip.index_select(self.fc1.weight.data, keep, 1), optimizer_params, f'{prefix}.fc1.weight', 1, keep, -1)
+        self._swap(self.fc2, 'weight', hip.index_select(self.fc2.weight.data, keep, 0), optimizer_params, f'{prefix}.fc2.weight', 1, keep, 0)
+        if self.fc2.bias is not None:
+            self._swap(self.fc2, 'bias', hip.index_select(self.fc2.bias.data, keep, 0), optimizer_params, f'{prefix}.fc2.bias', 0, keep, -1)
+        return optimizer_params, optimizer_decoder, optimizer_archs
+
     def fuse(self):
         """fold the frozen gate into fc1 (reference layers.py:867-871)."""
         self.fused = True
@@ -407,6 +591,13 @@ class MAESparseMlp(Mlp, _Searchable):
     @staticmethod
     def from_mlp(mlp_module, mlp_search=True):
         return MAESparseMlp(mlp_module, mlp_search)
+
+
+def _embed_keep(info, in_features):
+    """compress_patchembed's `info`: an index tensor, or a keep ratio (float) / count (int) meaning the first channels."""
+    if isinstance(info, torch.Tensor):
+        return info.detach().to('cpu', torch.int64).reshape(-1)
+    return torch.arange(int(in_features * info) if isinstance(info, float) else int(info))
 
 
 class ModuleInjection:

@@ -51,4 +51,49 @@ class AdamW(Optimizer):
         return loss
 
     def update(self, ori_w, cur_w, w_name, group_idx, keep_idx, dim, initialize=False):
-        raise NotImplementedError('optimizer-state surgery belongs to compress() (SURVEY 8f-1)')
+        """compress() hook (reference optim.py:122-182): parameter `w_name` of group `group_idx` was replaced by `cur_w`.
+
+        * cur_w frozen (requires_grad False): the slot and its state leave the optimizer.
+        * initialize=True: the moments restart from zero at step 0 (re-seeded alpha / finished score).
+        * otherwise the moments are cut exactly like the weight was: `keep_idx` is a 1-D index (index_select along `dim`)
+          or an index tensor of the state's rank (gather along `dim`); lists of both apply the cuts in sequence.
+        A parameter that never received a step has no moments to carry; its slot is simply re-pointed."""
+        names = self.param_names[group_idx]
+        slot = names.index(w_name)
+        plist = self.param_groups[group_idx]['params']
+        old = self.state.pop(ori_w, None)
+        if not cur_w.requires_grad:
+            del names[slot]
+            del plist[slot]
+            return
+        plist[slot] = cur_w
+        if old is None or len(old) == 0:
+            return
+        if initialize:
+            self.state[cur_w] = {'step': 0, 'exp_avg': torch.zeros_like(cur_w, memory_format=torch.preserve_format),
+                                 'exp_avg_sq': torch.zeros_like(cur_w, memory_format=torch.preserve_format)}
+            return
+        cuts = list(zip(keep_idx, dim)) if isinstance(keep_idx, (list, tuple)) else [(keep_idx, dim)]
+        m, v = old['exp_avg'], old['exp_avg_sq']
+        for idx, d in cuts:
+            m, v = take(m, idx, d), take(v, idx, d)
+        if tuple(m.shape) != tuple(cur_w.shape):
+            raise hip.OfbError(f'AdamW.update({w_name}): cut moments {tuple(m.shape)} do not match the parameter {tuple(cur_w.shape)}')
+        self.state[cur_w] = {'step': old['step'], 'exp_avg': m, 'exp_avg_sq': v}
+
+
+def take(t, index, dim):
+    """the slicing vocabulary of compress(): 1-D `index` -> t.index_select(dim, index); same-rank `index` (2-D) ->
+    torch.gather(t, dim, index).  Runs on the device through ofb_index_select."""
+    index = torch.as_tensor(index)
+    if index.dim() == 1:
+        return hip.index_select(t, index, dim)
+    if index.dim() != 2 or t.dim() != 2:
+        raise hip.OfbError('gather-style cuts are defined for 2-D state only')
+    rows, cols = t.shape
+    index = index.to(torch.int64)
+    if dim % 2 == 1:                                   # out[r][c] = t[r][index[r][c]]
+        flat = torch.arange(index.shape[0], device=index.device).view(-1, 1) * cols + index
+    else:                                              # out[r][c] = t[index[r][c]][c]
+        flat = index * cols + torch.arange(index.shape[1], device=index.device).view(1, -1)
+    return hip.index_select(t.reshape(-1), flat.reshape(-1), 0).view(index.shape)

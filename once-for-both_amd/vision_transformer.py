@@ -236,6 +236,8 @@ class MIMVisionTransformer(MAEBaseModel):
         self.apply(_init_vit_weights)
         w = self.patch_embed.proj.weight.data
         nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        self._hidden0 = int(embed_dim * mlp_ratio)           # original MLP width (the FLOPs model's `total`)
+        self._flops_maps = None
         self._gate_flags = (1, 1, 1)
         self._forced = None         # parity tests: dict(patch_noise=(B,L), droppath_u=(2*depth,B))
         self._gate_out = None
@@ -375,39 +377,70 @@ class MIMVisionTransformer(MAEBaseModel):
         return x, (decoder_loss, None)
 
     # ---- losses (reference base_model.py:31-86) -------------------------------------------------
+    def _flops_slots(self):
+        """the FLOPs model's module slots {embed, attn_0, mlp_0, ...}: which are live (index into the gate kernel's wsum)
+        and the constant staircase sum of the ones compress() has finished (all ones over the kept channels).  Device
+        arrays are cached until the next compress()."""
+        if self._flops_maps is None:
+            mods = [self.patch_embed] + [m for b in self.blocks for m in (b.attn, b.mlp)]
+            live_pos = {id(m): i for i, m in enumerate(self._live_modules())}
+            slot, const, heads = [], [], []
+            for m in mods:
+                searchable = hasattr(m, 'finish_search')
+                j = live_pos.get(id(m), -1) if searchable else -1
+                slot.append(j)
+                const.append(0.0 if j >= 0 else float(m.score.numel() if searchable else self._plain_width(m)))
+            for b in self.blocks:
+                heads.append(b.attn.active_heads() if hasattr(b.attn, 'active_heads') else b.attn.num_heads)
+            dev = self.pos_embed.device
+            self._flops_maps = dict(slot=torch.tensor(slot, dtype=torch.int32, device=dev), const=torch.tensor(const, device=dev),
+                                    heads=torch.tensor(heads, dtype=torch.int32, device=dev), n_live=len(live_pos))
+        return self._flops_maps
+
+    @staticmethod
+    def _plain_width(m):
+        """width a never-searched module contributes (its full q/k/v, hidden or embedding width)."""
+        if hasattr(m, 'qkv'):
+            return m.qkv.out_features // 3
+        return m.fc1.out_features if hasattr(m, 'fc1') else m.proj.out_channels
+
     def _flops_cfg(self, target):
         cfg = hip.FlopsCfg()
         a0 = self.blocks[0].attn
         cfg.num_patches, cfg.embed_dim, cfg.num_heads, cfg.head_dim = self.num_patches, self.embed_dim, a0.num_heads, a0.head_dim
-        cfg.hidden, cfg.patch_area = self.blocks[0].mlp.hidden_features, self.patch_size ** 2
+        cfg.hidden, cfg.patch_area = self._hidden0, self.patch_size ** 2
         cfg.num_classes, cfg.depth, cfg.target = self.num_classes, len(self.blocks), float(target)
-        cfg.active_heads = None
+        maps = self._flops_slots()
+        cfg.ln_dim = self.norm.normalized_shape[0]
+        cfg.active_heads, cfg.live_slot, cfg.wconst = maps['heads'].data_ptr(), maps['slot'].data_ptr(), maps['const'].data_ptr()
+        cfg.n_live = maps['n_live']
         return cfg
 
-    def _wsum_all(self):
-        go = self._gate_out
-        if go is None or len(go['live']) != len(self.searchable_modules):
-            raise NotImplementedError('FLOPs model with finished modules arrives with compress() (SURVEY 8f-1)')
-        return go['wsum']
-
-    def get_flops(self):
+    def _flops_eval(self, target):
+        """(loss, out3) of the FLOPs model; differentiable w.r.t. the live staircase sums."""
         if self._gate_out is None:
             self._compute_gates()
-        _, out3 = ops.FlopsLoss.apply(self._wsum_all(), self._flops_cfg(0.0))
+        cfg = self._flops_cfg(target)
+        if cfg.n_live == 0:                                   # search finished: every slot is a constant
+            out3 = torch.empty(3, device=self.pos_embed.device)
+            hip.flops_loss(None, cfg, out3, None)
+            return out3[0].clone(), out3
+        return ops.FlopsLoss.apply(self._gate_out['wsum'], cfg)
+
+    def get_flops(self):
+        _, out3 = self._flops_eval(0.0)
         total = self._total_flops()
         return total / 1e9, out3[2]
 
     def _total_flops(self):
         N, D, H, d = self.num_patches, self.embed_dim, self.blocks[0].attn.num_heads, self.blocks[0].attn.head_dim
-        hid, P2 = self.blocks[0].mlp.hidden_features, self.patch_size ** 2
+        hid, P2 = self._hidden0, self.patch_size ** 2
         per_block = 2 * D * N + N * (H * d * 3 * H * d) + 3 * N * H * d + H * N * d * N + H * N * N + 5 * H * N * N \
             + H * N * N * d + N * (H * d * H * d) + N * H * d + (2 * D * hid + D + hid) * N
         return N * D * 3 * P2 + len(self.blocks) * per_block + D * self.num_classes
 
     def get_flops_loss(self, target_flops):
-        if self._gate_out is None:
-            self._compute_gates()
-        loss, _ = ops.FlopsLoss.apply(self._wsum_all(), self._flops_cfg(target_flops))
+        loss, _ = self._flops_eval(target_flops)
         return loss
 
     def get_sparsity_loss(self, device, entropy=True, var=True, norm=True):
@@ -421,8 +454,77 @@ class MIMVisionTransformer(MAEBaseModel):
         sp = self._gate_out['spars']
         return sp[0], sp[1], zero, sp[2]
 
+    def _cut_embedding(self, keep, optimizer_params, optimizer_decoder):
+        """every consumer of the embedding width outside the searchable modules follows a cut of the patch embedding
+        (reference vision_transformer.py:838-907): tokens, all LayerNorms, classifier input, PMIM decoder input."""
+        def swap(owner, attr, dim, opt, name, group, opt_dim):
+            old = getattr(owner, attr)
+            new = nn.Parameter(hip.index_select(old.data, keep, dim), requires_grad=old.requires_grad)
+            setattr(owner, attr, new)
+            if opt is not None and old.requires_grad:
+                opt.update(old, new, name, group, keep, opt_dim)
+
+        width = keep.numel()
+        for attr in (['mask_token'] if self.mask_token is not None else []) + ['cls_token', 'pos_embed']:
+            swap(self, attr, -1, optimizer_params, attr, 0, -1)
+        norms = [(self.norm, 'norm')]
+        for i, blk in enumerate(self.blocks):
+            norms += [(blk.norm1, f'blocks.{i}.norm1'), (blk.norm2, f'blocks.{i}.norm2')]
+        for ln, name in norms:
+            ln.normalized_shape[0] = width
+            swap(ln, 'weight', 0, optimizer_params, f'{name}.weight', 0, -1)
+            swap(ln, 'bias', 0, optimizer_params, f'{name}.bias', 0, -1)
+        if isinstance(self.head, nn.Linear):
+            self.head.in_features = width
+            swap(self.head, 'weight', 1, optimizer_params, 'head.weight', 1, -1)
+        if self.mae:
+            self.decoder[0].in_channels = width
+            swap(self.decoder[0], 'weight', 1, optimizer_decoder, 'decoder.0.weight', 1, 1)
+
     def compress(self, thresh=0.2, optimizer_params=None, optimizer_decoder=None, optimizer_archs=None):
-        raise NotImplementedError('compress() is SURVEY 8(f)-1, scheduled after the hot path')
+        """reference vision_transformer.py:785-950: prune search cells whose probability fell to <= thresh / n_live, cut
+        the weights of modules whose largest options died (or that are down to one cell) and keep the three optimizers
+        consistent.  Returns (finish_search, execute_prune, optimizer_params, optimizer_decoder, optimizer_archs).
+
+        Rank-averaged alphas (collective C3) come from ONE fused all-reduce over every live module instead of one per
+        module; decisions are taken on the host from that single copy, so all ranks cut identically."""
+        from .dp import average_scalars
+        assert int(self.switch_cell_patch.sum()) == 1            # single patch cell (patch_search is off on this path)
+        finish_patch, execute_patch = True, False
+        self.alpha_patch.requires_grad = False
+        if not self.searchable_modules:
+            self.searchable_modules = [m for m in self.modules() if hasattr(m, 'alpha')]
+        names = {id(m): n for n, m in self.named_modules()}
+        live = [m for m in self.searchable_modules if int(m.switch_cell.sum()) != 1]
+        averaged = dict(zip((id(m) for m in live), average_scalars([m.alpha.data for m in live]))) if live else {}
+
+        finish_embed = execute_embed = False
+        keep = None
+        for m in self.searchable_modules:
+            if hasattr(m, 'embed_ratio_list'):
+                keep, optimizer_params, optimizer_decoder, optimizer_archs = m.compress(
+                    thresh, optimizer_params, optimizer_decoder, optimizer_archs, 'patch_embed', averaged.get(id(m)))
+                finish_embed, execute_embed = m.finish_search, m.execute_prune
+                if keep is not None:
+                    self._cut_embedding(keep, optimizer_params, optimizer_decoder)
+                break
+        self.finish_search = finish_patch and finish_embed
+        self.execute_prune = execute_patch or execute_embed
+        for m in self.searchable_modules:
+            if hasattr(m, 'embed_ratio_list'):
+                continue
+            name = names[id(m)]
+            if (not m.finish_search) or m.execute_prune:
+                optimizer_params, optimizer_decoder, optimizer_archs = m.compress(
+                    thresh, optimizer_params, optimizer_decoder, optimizer_archs, name, averaged.get(id(m)))
+            if keep is not None:
+                optimizer_params, optimizer_decoder, optimizer_archs = m.compress_patchembed(
+                    keep, optimizer_params, optimizer_decoder, optimizer_archs, name)
+            self.finish_search &= m.finish_search
+            self.execute_prune |= m.execute_prune
+        self._gate_out = None                                    # shapes / cells changed: gates and FLOPs maps are stale
+        self._flops_maps = None
+        return self.finish_search, self.execute_prune, optimizer_params, optimizer_decoder, optimizer_archs
 
     def fuse(self):
         """reference vision_transformer.py:747-757: fold every frozen gate into the weights / tokens it scales."""

@@ -130,6 +130,11 @@ class SearchState:
     w_p: float = 0.99                              # update_w, layers.py:169-171
     keep_ratio: float = 0.95                       # adjust_masking_ratio, vision_transformer.py:521
     switch: Dict[str, torch.Tensor] = field(default_factory=dict)   # name -> bool (A0,A1); default all on
+    finished: Dict[str, bool] = field(default_factory=dict)         # module.finish_search (set by compress)
+    execute: Dict[str, bool] = field(default_factory=dict)          # module.execute_prune of the last compress
+    heads: Dict[str, int] = field(default_factory=dict)             # attention head_num after a compress
+    frozen: set = field(default_factory=set)                        # parameter names whose requires_grad went False
+    fused: bool = False
 
     def cell_mask(self, name, alpha):
         sw = self.switch.get(name)
@@ -186,7 +191,8 @@ def gated_attention(x, wqkv, bqkv, wproj, bproj, g, heads, scale):
     """layers.py:488-517.  g (H,d) scales q,k,v channels; scale is the frozen 64^-0.5-style constant (D-2)."""
     B, N, _ = x.shape
     qkv = (x @ wqkv.t() + bqkv).reshape(B, N, 3, heads, -1).permute(2, 0, 3, 1, 4)
-    q, k, v = qkv[0] * g.unsqueeze(1), qkv[1] * g.unsqueeze(1), qkv[2] * g.unsqueeze(1)
+    g = torch.ones((), dtype=x.dtype) if g is None else g.unsqueeze(1)          # fused module: gate already in the weights
+    q, k, v = qkv[0] * g, qkv[1] * g, qkv[2] * g
     attn = torch.softmax((q @ k.transpose(-2, -1)) * scale, dim=-1)
     ctx = (attn @ v).transpose(1, 2).reshape(B, N, -1)
     return ctx @ wproj.t() + bproj
@@ -194,7 +200,8 @@ def gated_attention(x, wqkv, bqkv, wproj, bproj, g, heads, scale):
 
 def gated_mlp(x, w1, b1, w2, b2, g):
     """layers.py:843-865: gate applied to fc1 output before GELU(erf)."""
-    return gelu_erf((x @ w1.t() + b1) * g) @ w2.t() + b2
+    h = x @ w1.t() + b1
+    return gelu_erf(h if g is None else h * g) @ w2.t() + b2
 
 
 def box_sums_47(img64, k=47):
@@ -232,20 +239,29 @@ def label_smoothing_ce(logits, labels, smoothing=0.1):
 # ----------------------------------------------------------------------------------------
 # whole search-model forward (vision_transformer.py:614-745) + losses
 # ----------------------------------------------------------------------------------------
+def search_space(cfg: Config, name: str):
+    """(head thresholds, channel thresholds) of a searchable module in ORIGINAL units; compress() only ever
+    drops trailing options, so a module whose alpha shrank to (a0, a1) uses the first a0 / a1 entries."""
+    if name == 'patch_embed':
+        return [1], cfg.embed_channels()
+    if name.endswith('.attn'):
+        return cfg.attn_heads(), cfg.attn_channels()
+    return [1], cfg.mlp_channels()
+
+
 def gates_for(cfg: Config, p: Dict[str, torch.Tensor], st: SearchState):
-    """All 25 (g, wr, wm, prob) tuples keyed by searchable-module name."""
+    """(g, wr, wm, prob) per searchable module.  A finished module's `score` IS its gate (layers.py:192-195,
+    516-528, 859-862) and its staircase is all ones over the kept channels; a fused one has no gate (g = None)."""
     out = {}
-    D, H, d, hid = cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden
-    a = p['patch_embed.alpha']
-    out['patch_embed'] = bimask_gate(a, st.cell_mask('patch_embed', a), p['patch_embed.score'], [1],
-                                     cfg.embed_channels(), st.w_p)
-    for i in range(cfg.depth):
-        n = f'blocks.{i}.attn'
+    for n in module_names(cfg):
+        sc = p[n + '.score']
+        if st.finished.get(n, False):
+            ones = torch.ones_like(sc)
+            out[n] = (None if st.fused else sc, ones, ones, None)
+            continue
         a = p[n + '.alpha']
-        out[n] = bimask_gate(a, st.cell_mask(n, a), p[n + '.score'], cfg.attn_heads(), cfg.attn_channels(), st.w_p)
-        n = f'blocks.{i}.mlp'
-        a = p[n + '.alpha']
-        out[n] = bimask_gate(a, st.cell_mask(n, a), p[n + '.score'], [1], cfg.mlp_channels(), st.w_p)
+        ht, ct = search_space(cfg, n)
+        out[n] = bimask_gate(a, st.cell_mask(n, a), sc, ht[:a.shape[0]], ct[:a.shape[1]], st.w_p)
     return out
 
 
@@ -253,11 +269,14 @@ def search_forward(cfg: Config, p: Dict[str, torch.Tensor], st: SearchState, img
                    droppath_u=None, training=True, scale=None):
     """Returns dict(logits, decoder_loss, mask, latent, x_rec, gates).  droppath_u: (2*depth, B) uniforms,
     consumed in call order attn0, mlp0, attn1, ...; keep = floor(keep_prob + u) (timm DropPath)."""
-    D, H, Pz, L = cfg.embed_dim, cfg.num_heads, cfg.patch_size, cfg.num_patches
+    Pz, L = cfg.patch_size, cfg.num_patches
+    D = p['patch_embed.proj.weight'].shape[0]                                   # shrinks when compress() cuts the embedding
     B = imgs.shape[0]
-    scale = (D // H) ** -0.5 if scale is None else scale
+    scale = cfg.head_dim ** -0.5 if scale is None else scale                    # qk_scale is pinned at construction (layers.py:418)
     gates = gates_for(cfg, p, st)
     g_e, wr_e = gates['patch_embed'][0], gates['patch_embed'][1]                # (1,D)
+    if g_e is None:
+        g_e = torch.ones((), dtype=imgs.dtype)                                  # fused: gate folded into weights and tokens
 
     # patch embed conv16/16 as a GEMM over patchified pixels (layers.py:177) + gate (:191)
     gh = cfg.img_size // Pz
@@ -291,6 +310,7 @@ def search_forward(cfg: Config, p: Dict[str, torch.Tensor], st: SearchState, img
     replace_stream = bool(((wr_e > 0) & (wr_e < 1)).any())
     for i in range(cfg.depth):
         b = f'blocks.{i}.'
+        H = st.heads.get(b + 'attn', cfg.num_heads)
         h1 = layer_norm(x, p[b + 'norm1.weight'], p[b + 'norm1.bias'], cfg.ln_eps)
         a = gated_attention(h1, p[b + 'attn.qkv.weight'], p[b + 'attn.qkv.bias'], p[b + 'attn.proj.weight'],
                             p[b + 'attn.proj.bias'], gates[b + 'attn'][0], H, scale)
@@ -341,22 +361,26 @@ def sparsity_losses(cfg: Config, p, st: SearchState, gates, entropy=True, var=Tr
     return acc['attn'], acc['mlp'], z.clone(), acc['embed']
 
 
-def flops_G(cfg: Config, gates):
-    """(total, searched) MACs/1e9 (vision_transformer.py:759-783, :207-220; layers.py:345-360,747-766,1032-1044)."""
+def flops_G(cfg: Config, gates, st: SearchState = None):
+    """(total, searched) MACs/1e9 (vision_transformer.py:759-783, :207-220; layers.py:345-360,747-766,1032-1044).
+    After compress() the LayerNorm term uses the cut embedding width (norm1.normalized_shape[0]) and the softmax /
+    q@k terms the surviving head count (head_num); `total` keeps the original architecture."""
     N = cfg.num_patches
     n = N                                   # active_patches: model has no weighted_mask attr -> num_patch
     D, H, d, hid, P2 = cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden, cfg.patch_size ** 2
     e = gates['patch_embed'][2].sum()
+    D_act = gates['patch_embed'][2].shape[-1]
     total = N * D * 3 * P2
     searched = N * e * 3 * P2
     for i in range(cfg.depth):
         sd = gates[f'blocks.{i}.attn'][2].sum()
         hh = gates[f'blocks.{i}.mlp'][2].sum()
+        aH = st.heads.get(f'blocks.{i}.attn', H) if st is not None else H
         total += 2 * D * N
-        searched = searched + 2 * D * n                                           # norm1.normalized_shape[0] = D
+        searched = searched + 2 * D_act * n                                       # norm1.normalized_shape[0]
         total += N * (H * d * 3 * H * d) + 3 * N * H * d + H * N * d * N + H * N * N + 5 * H * N * N + H * N * N * d \
             + N * (H * d * H * d) + N * H * d
-        searched = searched + n * (e * 3 * sd) + 3 * n * sd + n * n * sd + H * n * n + 5 * H * n * n + n * n * sd \
+        searched = searched + n * (e * 3 * sd) + 3 * n * sd + n * n * sd + aH * n * n + 5 * aH * n * n + n * n * sd \
             + n * (sd * e) + n * e
         total += (2 * D * hid + D + hid) * N
         searched = searched + (e * hh + hh * e + e + hh) * n
@@ -366,14 +390,17 @@ def flops_G(cfg: Config, gates):
 
 
 def search_step_loss(cfg: Config, p, st: SearchState, imgs, labels, patch_noise, droppath_u=None, target_flops=1.0,
-                     w=(0.5, 0.5, 0.0, 0.5, 5.0)):
-    """engine.py:131-144 + losses.py:80-106.  Returns dict with loss_total and every component."""
+                     w=(0.5, 0.5, 0.0, 0.5, 5.0), finish_search=False):
+    """engine.py:131-144 + losses.py:80-106.  Returns dict with loss_total and every component.
+    finish_search=True: the criterion returns the base loss only (losses.py:104-106)."""
     out = search_forward(cfg, p, st, imgs, patch_noise, droppath_u, training=True)
     base = label_smoothing_ce(out['logits'], labels)
     l_attn, l_mlp, l_patch, l_emb = sparsity_losses(cfg, p, st, out['gates'])
-    tot_f, sea_f = flops_G(cfg, out['gates'])
+    tot_f, sea_f = flops_G(cfg, out['gates'], st)
     l_flops = ((sea_f - target_flops) / tot_f) ** 2
     arch = w[0] * l_attn + w[1] * l_mlp + w[2] * l_patch + w[3] * l_emb + w[4] * l_flops
+    if finish_search:
+        arch = arch.detach() * 0
     total = base + arch
     dec = out['decoder_loss']
     if not isinstance(dec, float):
@@ -422,3 +449,199 @@ def vit_forward(p, imgs, depth, heads: List[int], scale, eps=1e-6, patch=16):
                           p[b + 'mlp.fc2.bias'], torch.ones(1, hid, dtype=x.dtype))
     x = layer_norm(x, p['norm.weight'], p['norm.bias'], eps)
     return x[:, 0] @ p['head.weight'].t() + p['head.bias']
+
+
+# ----------------------------------------------------------------------------------------
+# compress(): alpha-threshold pruning + physical slicing + optimizer-state surgery
+# (vision_transformer.py:785-950, layers.py:218-338 / 559-728 / 883-1025, optim.py:122-182)
+# ----------------------------------------------------------------------------------------
+class OptimState:
+    """Per-parameter AdamW state of the three reference optimizers, keyed by parameter NAME.
+    groups: {'p0': [...], 'p1': [...], 'd0': [...], 'd1': [...], 'a0': [...]} = param_names of optimizer_params
+    (no-decay / decay), optimizer_decoder (no-decay / decay) and optimizer_archs."""
+    HYPER = {'p0': (0.9, 0.0), 'p1': (0.9, 1e-3), 'd0': (0.9, 0.0), 'd1': (0.9, 1e-3), 'a0': (0.5, 1e-3)}
+    GROUP_OF = {'nodecay': 'p0', 'decay': 'p1', 'decoder_nodecay': 'd0', 'decoder_decay': 'd1', 'arch': 'a0'}
+
+    def __init__(self, p: Dict[str, torch.Tensor], frozen=()):
+        self.groups = {g: [] for g in self.HYPER}
+        self.state = {}
+        for k, v in p.items():
+            if k in frozen:
+                continue
+            self.groups[self.GROUP_OF[optimizer_group(k, tuple(v.shape))]].append(k)
+
+    def group_of(self, name):
+        return next(g for g, names in self.groups.items() if name in names)
+
+    def step(self, p, grads, lr):
+        """one AdamW step on every listed parameter that received a gradient (optim.py:71-73 skips grad None)."""
+        for g, names in self.groups.items():
+            b1, wd = self.HYPER[g]
+            for k in names:
+                if grads.get(k) is None:
+                    continue
+                st = self.state.setdefault(k, dict(step=0, m=torch.zeros_like(p[k]), v=torch.zeros_like(p[k])))
+                st['step'] += 1
+                p[k], st['m'], st['v'] = adamw_step(p[k], grads[k], st['m'], st['v'], st['step'], lr, b1, 0.999, 1e-8, wd)
+
+    # optim.py:122-182 -------------------------------------------------------------------
+    def take(self, name, index, dim):
+        """keep `index` along `dim` of both moments (index: 1-D -> index_select, same-rank -> gather)."""
+        st = self.state[name]
+        for key in ('m', 'v'):
+            t = st[key]
+            st[key] = t.index_select(dim % t.dim(), index) if index.dim() == 1 else torch.gather(t, dim % t.dim(), index)
+
+    def reinit(self, name, like):
+        assert name in self.state                       # the reference pops the old entry (KeyError if never stepped)
+        self.state[name] = dict(step=0, m=torch.zeros_like(like), v=torch.zeros_like(like))
+
+    def drop(self, name):
+        self.groups[self.group_of(name)].remove(name)
+        self.state.pop(name)
+
+
+def _slice_param(p, opt, name, index, dim):
+    """replace p[name] by its `index` slice along `dim` and cut the optimizer moments the same way."""
+    t = p[name]
+    p[name] = t.index_select(dim % t.dim(), index)
+    if opt is not None and name in opt.state:
+        opt.take(name, index, dim)
+
+
+def compress_module(cfg: Config, p, st: SearchState, opt: OptimState, name: str, thresh: float):
+    """One searchable module's compress().  Returns (keep_index or None) - the embedding module's kept output channels.
+
+    1. cells whose softmax probability among the live cells is <= thresh / n_live are switched off and their alpha
+       zeroed; the alpha optimizer state restarts (layers.py:230-247).
+    2. one live cell left -> the module is finished: channels/heads are cut to that cell's size by score rank, `score`
+       becomes the frozen-shape gate w_p*sigmoid(score)+(1-w_p) (a trainable parameter with fresh optimizer state),
+       alpha leaves the arch optimizer (:258-293).
+    3. else if the largest option(s) died -> alpha / mask / switch lose their trailing rows/columns and the weights are
+       cut to the largest surviving option, optimizer moments following (:294-334)."""
+    alpha = p[name + '.alpha']
+    on = st.cell_mask(name, alpha)
+    if int(on.sum()) == 1:
+        st.finished[name], st.execute[name] = True, False
+        st.frozen.add(name + '.alpha')
+        return None
+    thr = thresh / int(on.sum())
+    pr = masked_softmax(alpha.detach(), on)
+    if float(pr[on].min()) > thr:
+        st.execute[name] = False
+        return None
+    st.execute[name] = True
+    on = pr > thr
+    alpha = torch.where(on, alpha.detach(), torch.zeros_like(alpha))
+    p[name + '.alpha'], st.switch[name] = alpha, on
+    if opt is not None:
+        opt.reinit(name + '.alpha', alpha)
+    heads_thr, chan_thr = search_space(cfg, name)
+    score = p[name + '.score'].detach()
+    is_attn = name.endswith('.attn')
+    idx = torch.nonzero(on)
+    finished = int(on.sum()) == 1
+    if finished:
+        i_max, j_max = int(idx[0, 0]), int(idx[0, 1])
+    elif is_attn and (int(on[:, -1].sum()) == 0 or int(on[-1, :].sum()) == 0):
+        i_max, j_max = int(idx[:, 0].max()), int(idx[:, 1].max())
+    elif (not is_attn) and int(on[0, -1]) == 0:
+        i_max, j_max = 0, int(idx[-1, 1])
+    else:
+        return None                                                            # cells died inside the staircase only
+    if finished:
+        st.finished[name] = True
+        st.frozen.add(name + '.alpha')
+        if opt is not None:
+            opt.drop(name + '.alpha')
+    else:
+        ar0, ar1 = torch.arange(i_max + 1), torch.arange(j_max + 1)
+        _slice_param(p, opt, name + '.alpha', ar0, 0)
+        _slice_param(p, opt, name + '.alpha', ar1, 1)
+        st.switch[name] = on[:i_max + 1, :j_max + 1]
+    n_chan = chan_thr[j_max]
+    chan_index = torch.argsort(score, dim=1, descending=True)[:, :n_chan]      # per current head: kept channels, best first
+    if is_attn:
+        H_cur, d_cur = score.shape
+        n_head = heads_thr[i_max]
+        head_index = torch.argsort(torch.sigmoid(score).sum(-1), dim=0, descending=True)[:n_head]
+        chan_index = chan_index[head_index]                                     # (n_head, n_chan)
+        st.heads[name] = n_head
+        new_score = torch.gather(score[head_index], 1, chan_index)
+        rows = (head_index.view(-1, 1) * d_cur + chan_index).reshape(-1)        # positions inside one of q / k / v
+        qkv_rows = torch.cat([rows + t * H_cur * d_cur for t in range(3)])
+        if finished:
+            new_score = st.w_p * torch.sigmoid(new_score) + (1 - st.w_p) * torch.ones_like(new_score)
+        p[name + '.score'] = new_score
+        if opt is not None:
+            if finished:
+                opt.reinit(name + '.score', new_score)
+            else:
+                opt.take(name + '.score', head_index, 0)
+                opt.take(name + '.score', chan_index, 1)
+        _slice_param(p, opt, name + '.qkv.weight', qkv_rows, 0)
+        _slice_param(p, opt, name + '.qkv.bias', qkv_rows, 0)
+        _slice_param(p, opt, name + '.proj.weight', rows, 1)
+        return None
+    keep = chan_index.reshape(-1)
+    new_score = score[:, keep]
+    if finished:
+        new_score = st.w_p * torch.sigmoid(new_score) + (1 - st.w_p) * torch.ones_like(new_score)
+    p[name + '.score'] = new_score
+    if opt is not None:
+        if finished:
+            opt.reinit(name + '.score', new_score)
+        else:
+            opt.take(name + '.score', keep, 1)
+    if name == 'patch_embed':
+        _slice_param(p, opt, 'patch_embed.proj.weight', keep, 0)
+        _slice_param(p, opt, 'patch_embed.proj.bias', keep, 0)
+        return keep
+    _slice_param(p, opt, name + '.fc1.weight', keep, 0)
+    _slice_param(p, opt, name + '.fc1.bias', keep, 0)
+    _slice_param(p, opt, name + '.fc2.weight', keep, 1)
+    return None
+
+
+def compress_model(cfg: Config, p, st: SearchState, opt: OptimState = None, thresh=0.2):
+    """MIMVisionTransformer.compress (vision_transformer.py:785-950) for the one-patch-cell configuration.
+    Returns (finish_search, execute_prune)."""
+    keep = compress_module(cfg, p, st, opt, 'patch_embed', thresh)
+    finish, execute = st.finished.get('patch_embed', False), st.execute.get('patch_embed', False)
+    if keep is not None:                                                        # every consumer of the embedding width
+        for k in ['mask_token', 'cls_token', 'pos_embed', 'norm.weight', 'norm.bias']:
+            _slice_param(p, opt, k, keep, -1)
+        for i in range(cfg.depth):
+            for k in ['norm1.weight', 'norm1.bias', 'norm2.weight', 'norm2.bias']:
+                _slice_param(p, opt, f'blocks.{i}.{k}', keep, 0)
+        _slice_param(p, opt, 'head.weight', keep, 1)
+        _slice_param(p, opt, 'decoder.0.weight', keep, 1)
+    for name in module_names(cfg)[1:]:
+        if (not st.finished.get(name, False)) or st.execute.get(name, False):
+            compress_module(cfg, p, st, opt, name, thresh)
+        if keep is not None:                                                    # compress_patchembed, layers.py:698-712 / 994-1008
+            a, b = ('qkv', 'proj') if name.endswith('.attn') else ('fc1', 'fc2')
+            _slice_param(p, opt, f'{name}.{a}.weight', keep, 1)
+            _slice_param(p, opt, f'{name}.{b}.weight', keep, 0)
+            _slice_param(p, opt, f'{name}.{b}.bias', keep, 0)
+        finish &= st.finished.get(name, False)
+        execute |= st.execute.get(name, False)
+    return finish, execute
+
+
+def fuse_params(cfg: Config, p, st: SearchState):
+    """MIMVisionTransformer.fuse (vision_transformer.py:747-757) + module fuse()s: fold every frozen gate into the
+    weights / tokens it scales."""
+    we = p['patch_embed.score'].reshape(-1)
+    for k in ['mask_token', 'cls_token', 'pos_embed']:
+        p[k] = p[k] * we
+    p['patch_embed.proj.weight'] = p['patch_embed.proj.weight'] * we.view(-1, 1, 1, 1)
+    p['patch_embed.proj.bias'] = p['patch_embed.proj.bias'] * we
+    for i in range(cfg.depth):
+        sc = p[f'blocks.{i}.attn.score'].reshape(-1).repeat(3)
+        p[f'blocks.{i}.attn.qkv.weight'] = p[f'blocks.{i}.attn.qkv.weight'] * sc.unsqueeze(-1)
+        p[f'blocks.{i}.attn.qkv.bias'] = p[f'blocks.{i}.attn.qkv.bias'] * sc
+        sc = p[f'blocks.{i}.mlp.score'].reshape(-1)
+        p[f'blocks.{i}.mlp.fc1.weight'] = p[f'blocks.{i}.mlp.fc1.weight'] * sc.unsqueeze(-1)
+        p[f'blocks.{i}.mlp.fc1.bias'] = p[f'blocks.{i}.mlp.fc1.bias'] * sc
+    st.fused = True

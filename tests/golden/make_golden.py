@@ -161,6 +161,189 @@ def run_case(tag, cfg_kw, batch, w_p, keep_ratio, drop_path, switches, lr=1e-3, 
           f'flops={out["flops_searched"]:.5f}/{out["flops_total"]:.5f} -> {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# compress() life cycle: step -> crafted alphas -> compress -> step -> crafted alphas -> compress (finishes)
+# -> step (finish_search) -> eval -> fuse -> eval.  Everything the reference mutates is recorded per stage.
+# ----------------------------------------------------------------------------------------------------------------
+MINI = dict(embed_dim=128, depth=3, num_heads=4, num_classes=10)
+
+
+def craft_alphas(stage):
+    """closed-form alpha overrides (inputs of the case; stored in the fixture as craft<stage>.<name>)."""
+    lo = -6.0
+
+    def kept(r, c, seed):
+        # non-uniform values for surviving cells (exactly uniform probabilities put tan(pi/2 - 0) into the sparsity loss)
+        i, j = np.meshgrid(np.arange(r), np.arange(c), indexing='ij')
+        return (0.3 * np.sin(1.7 * (i * c + j) + seed)).astype(np.float32)
+
+    if stage == 1:
+        e = kept(1, 17, 0.1); e[0, 14:] = lo                                   # embed: last 3 options die -> D 128 -> 116
+        a0 = np.full((2, 7), lo, np.float32); a0[0, 4] = 0.5                   # attn0: one cell survives -> finished (2 heads x 24)
+        a1 = kept(2, 7, 0.2); a1[:, 6] = lo                                    # attn1: last column dies -> 4 heads x 28
+        a2 = kept(2, 7, 0.3); a2[1, :] = lo                                    # attn2: last row dies -> 2 heads x 32
+        m0 = np.full((1, 7), lo, np.float32); m0[0, 3] = 0.25                  # mlp0: finished, hidden 320
+        m1 = kept(1, 7, 0.4); m1[0, 5:] = lo                                   # mlp1: last two die -> hidden 384
+        m2 = kept(1, 7, 0.5); m2[0, 2] = lo                                    # mlp2: a middle cell dies, no shape change
+        return {'patch_embed': e, 'blocks.0.attn': a0, 'blocks.1.attn': a1, 'blocks.2.attn': a2,
+                'blocks.0.mlp': m0, 'blocks.1.mlp': m1, 'blocks.2.mlp': m2}
+    e = np.full((1, 14), lo, np.float32); e[0, 9] = 0.0                        # embed finishes at option 9 -> D 100
+    a1 = np.full((2, 6), lo, np.float32); a1[1, 2] = 0.0                       # attn1: 4 heads x 16
+    a2 = np.full((1, 7), lo, np.float32); a2[0, 5] = 0.0                       # attn2: 2 heads x 28
+    m1 = np.full((1, 5), lo, np.float32); m1[0, 0] = 0.0                       # mlp1: hidden 128
+    m2 = np.full((1, 7), lo, np.float32); m2[0, 6] = 0.0                       # mlp2: keeps all 512 (cell 2 already off)
+    return {'patch_embed': e, 'blocks.1.attn': a1, 'blocks.2.attn': a2, 'blocks.1.mlp': m1, 'blocks.2.mlp': m2}
+
+
+def run_compress_case(tag='mini_c', batch=2, w_p=0.7, keep_ratio=0.9, drop_path=0.1, lr=1e-3, thresh=0.2):
+    cfg = O.Config(**MINI, drop_path_rate=drop_path)
+    model = build_reference(cfg, drop_path)
+    names = O.module_names(cfg)
+    by_name = dict(zip(names, model.searchable_modules))
+    for mod in model.searchable_modules:
+        mod.w_p = w_p
+    model.patch_ratio_list = [keep_ratio]
+    imgs = torch.from_numpy(fill.images(batch))
+    labels = torch.from_numpy(fill.labels(batch, cfg.num_classes))
+    pnoise = torch.from_numpy(fill.patch_noise(batch, cfg.num_patches))
+    dnoise = torch.from_numpy(fill.droppath_noise(2 * cfg.depth, batch))
+    calls = {'dp': 0}
+
+    def fake_rand(*shape, **kw):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        if tuple(shape) == (batch, cfg.num_patches):
+            return pnoise.clone()
+        if tuple(shape) == (batch, 1, 1):
+            r = dnoise[calls['dp']].view(batch, 1, 1).clone()
+            calls['dp'] += 1
+            return r
+        raise RuntimeError(f'unexpected rand shape {shape}')
+
+    groups = {'nodecay': [], 'decay': [], 'decoder_nodecay': [], 'decoder_decay': [], 'arch': []}
+    gnames = {k: [] for k in groups}
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            grp = O.optimizer_group(k, tuple(p.shape))
+            groups[grp].append(p)
+            gnames[grp].append(k)
+    opt_p = ROPT.AdamW([{'params': groups['nodecay'], 'weight_decay': 0.}, {'params': groups['decay'], 'weight_decay': 1e-3}],
+                       {0: gnames['nodecay'], 1: gnames['decay']}, lr=lr, eps=1e-8, betas=(0.9, 0.999))
+    opt_d = ROPT.AdamW([{'params': groups['decoder_nodecay'], 'weight_decay': 0.}, {'params': groups['decoder_decay'], 'weight_decay': 1e-3}],
+                       {0: gnames['decoder_nodecay'], 1: gnames['decoder_decay']}, lr=lr, eps=1e-8, betas=(0.9, 0.999))
+    opt_a = ROPT.AdamW(groups['arch'], {0: gnames['arch']}, lr=lr, eps=1e-8, betas=(0.5, 0.999), weight_decay=1e-3)
+    opts = {'p': opt_p, 'd': opt_d, 'a': opt_a}
+    crit = RLOSS.OFBSearchLOSS(RLOSS.DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0),
+                                torch.device('cpu'), attn_w=0.5, mlp_w=0.5, patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+    wrapped = _Wrap(model)
+    out = dict(meta=np.array([batch, w_p, keep_ratio, drop_path, lr, thresh], np.float64))
+    real_rand, real_sync = torch.rand, torch.cuda.synchronize
+    torch.cuda.synchronize = lambda *a, **k: None            # the reference synchronises the (absent) device inside compress()
+
+    def step(pre, finish):
+        """one search step incl. the three optimizer updates; records losses / grads / updated params under `pre`."""
+        model.train()
+        for p in model.parameters():
+            p.grad = None
+        calls['dp'] = 0
+        torch.rand = fake_rand
+        DropPath.rand = staticmethod(fake_rand)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                logits, (dec_loss, _) = wrapped(imgs)
+                loss = crit(imgs, logits, labels, wrapped, 'arch', 1.0, finish)
+                f_tot, f_sea = model.get_flops()
+            if isinstance(loss, tuple):
+                base, arch = loss
+                total = base + arch
+            else:
+                base, arch, total = loss, torch.zeros(()), loss
+            total = total + (base / dec_loss).data.clone() * dec_loss
+            total.backward()
+        finally:
+            torch.rand = real_rand
+            DropPath.rand = staticmethod(real_rand)
+        out.update({f'{pre}.logits': logits.detach().numpy(), f'{pre}.decoder_loss': dec_loss.item(), f'{pre}.base': base.item(),
+                    f'{pre}.arch': float(arch.detach()), f'{pre}.loss_total': total.item(), f'{pre}.flops_total': float(f_tot),
+                    f'{pre}.flops_searched': float(f_sea)})
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            out[f'{pre}.gnorm.{k}'] = np.float64(p.grad.double().norm().item())
+            if 'alpha' in k or 'score' in k:
+                out[f'{pre}.grad.{k}'] = p.grad.numpy().copy()
+            else:
+                out[f'{pre}.gsamp.{k}'] = sample(p.grad)
+        for o in opts.values():
+            if o is not None:
+                o.step()
+        for k, p in model.named_parameters():
+            out[f'{pre}.{"after" if ("alpha" in k or "score" in k) else "asamp"}.{k}'] = \
+                p.detach().numpy().copy() if ('alpha' in k or 'score' in k) else sample(p)
+
+    def snapshot(pre):
+        """model + optimizer state right after a compress() call."""
+        for name, mod in by_name.items():
+            out[f'{pre}.switch.{name}'] = mod.switch_cell.numpy().copy()
+            out[f'{pre}.flags.{name}'] = np.array([mod.finish_search, mod.execute_prune, getattr(mod, 'head_num', -1)], np.int64)
+        pid = {}
+        for k, p in model.named_parameters():
+            pid[id(p)] = k
+            out[f'{pre}.shape.{k}'] = np.array(p.shape, np.int64)
+            out[f'{pre}.rg.{k}'] = np.array(p.requires_grad)
+            if 'alpha' in k or 'score' in k:
+                out[f'{pre}.val.{k}'] = p.detach().numpy().copy()
+            else:
+                out[f'{pre}.vsamp.{k}'] = sample(p)
+        for on, o in opts.items():
+            if o is None:
+                continue
+            for gi, grp in enumerate(o.param_groups):
+                got = [pid[id(p)] for p in grp['params']]
+                assert got == list(o.param_names[gi]), (on, gi)
+                out[f'{pre}.optnames.{on}.{gi}'] = np.array(got)
+                for p in grp['params']:
+                    st = o.state.get(p)
+                    if st:
+                        k = pid[id(p)]
+                        out[f'{pre}.optstep.{k}'] = np.int64(st['step'])
+                        assert st['exp_avg'].shape == p.shape and st['exp_avg_sq'].shape == p.shape, k
+                        small = 'alpha' in k or 'score' in k
+                        out[f'{pre}.m.{k}'] = st['exp_avg'].numpy().copy() if small else sample(st['exp_avg'])
+                        out[f'{pre}.v.{k}'] = st['exp_avg_sq'].numpy().copy() if small else sample(st['exp_avg_sq'])
+
+    try:
+        step('s0', False)
+        for stage in (1, 2):
+            for name, a in craft_alphas(stage).items():
+                mod = by_name[name]
+                assert tuple(mod.alpha.shape) == a.shape, (name, mod.alpha.shape, a.shape)
+                mod.alpha.data.copy_(torch.from_numpy(a))
+                out[f'craft{stage}.{name}'] = a
+            with contextlib.redirect_stdout(io.StringIO()):
+                fin, ex, opts['p'], opts['d'], opts['a'] = model.compress(thresh, opts['p'], opts['d'], opts['a'])
+            out[f'c{stage}.model_flags'] = np.array([fin, ex], np.int64)
+            snapshot(f'c{stage}')
+            if fin:
+                opts['a'] = None                                         # engine.py:207-209
+            step(f's{stage}', bool(fin))
+        assert fin, 'stage 2 must finish the search'
+        model.eval()
+        with torch.no_grad(), contextlib.redirect_stdout(io.StringIO()):
+            out['eval.logits_prefuse'] = wrapped(imgs)[0].numpy()
+            model.fuse()
+            out['eval.logits_fused'] = wrapped(imgs)[0].numpy()
+        for k, p in model.named_parameters():
+            out[f'fused.vsamp.{k}'] = sample(p)
+    finally:
+        torch.cuda.synchronize = real_sync
+    path = os.path.join(HERE, f'{tag}.npz')
+    np.savez_compressed(path, **out)
+    shapes = {k[len('c2.shape.'):]: tuple(v) for k, v in out.items() if k.startswith('c2.shape.') and 'weight' in k and 'norm' not in k}
+    print(f'{tag}: ' + ' '.join(f's{i}: total={out[f"s{i}.loss_total"]:.5f} flops={out[f"s{i}.flops_searched"]:.5f}' for i in range(3)))
+    print('   final shapes:', shapes)
+    print(f'   -> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def kernel_goldens():
     """Piece-level vectors straight from reference functions."""
     imgs = torch.from_numpy(fill.images(1, tag='nt'))
@@ -175,6 +358,9 @@ def kernel_goldens():
 if __name__ == '__main__':
     torch.manual_seed(0)
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == 'compress':
+        run_compress_case()
+        sys.exit(0)
     micro = O.MICRO
     sw_b = {
         'patch_embed': np.array([[0, 0] + [1] * 15], bool),
@@ -187,3 +373,4 @@ if __name__ == '__main__':
     sw_s = {'blocks.3.attn': np.array([[1, 1, 1, 1, 1, 1, 0], [1, 1, 0, 1, 1, 1, 1], [0, 1, 1, 1, 1, 1, 1]], bool)}
     run_case('small_a', dict(O.DEIT_SMALL, num_classes=1000), batch=2, w_p=0.7, keep_ratio=0.9, drop_path=0.1, switches=sw_s)
     kernel_goldens()
+    run_compress_case()

@@ -1,0 +1,114 @@
+"""compress() life cycle on the HIP-backed model against the reference's own run (tests/golden/mini_c.npz):
+step -> crafted alphas -> compress -> step -> crafted alphas -> compress (finishes) -> step -> eval -> fuse -> eval.
+Checks, per stage, the cell switches, flags, every parameter shape / value, the three optimizers' parameter lists and
+AdamW moments, then losses / FLOPs / gradients / updated parameters of the following search step."""
+import types
+
+import pytest
+import torch
+
+from oracle import ofb_oracle as O
+from tests.compress_util import Lifecycle, check_snapshot, check_step
+from tests.test_gpu_model import build_product
+
+pytestmark = pytest.mark.gpu
+
+
+def _state_view(m, cfg):
+    st = types.SimpleNamespace(switch={}, finished={}, execute={}, heads={})
+    for mod, name in zip(m.searchable_modules, O.module_names(cfg)):
+        st.switch[name] = mod.switch_cell
+        st.finished[name], st.execute[name] = mod.finish_search, mod.execute_prune
+        if hasattr(mod, 'head_num'):
+            st.heads[name] = mod.head_num
+    return st
+
+
+def _opt_view(m, opts):
+    name_of = {id(p): k for k, p in m.named_parameters()}
+    names, state = {}, {}
+    for tag, o in opts.items():
+        for gi in (0, 1):
+            if o is not None and gi < len(o.param_groups):
+                got = [name_of[id(p)] for p in o.param_groups[gi]['params']]
+                assert got == list(o.param_names[gi]), (tag, gi)
+                names[f'{tag}.{gi}'] = got
+                for p in o.param_groups[gi]['params']:
+                    s = o.state.get(p)
+                    if s:
+                        assert s['exp_avg'].shape == p.shape and s['exp_avg'].is_contiguous()
+                        state[name_of[id(p)]] = (s['step'], s['exp_avg'], s['exp_avg_sq'])
+            elif gi == 0 or tag != 'a':
+                names[f'{tag}.{gi}'] = []
+    return dict(names=names, state=state)
+
+
+def test_compress_lifecycle_matches_reference():
+    from ofb_amd.engine import build_optimizers
+    from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
+    lc = Lifecycle(torch.float32)
+    z, cfg = lc.z, lc.cfg
+    inputs = dict(patch_noise=lc.pnoise, droppath_u=lc.dnoise)
+    m = build_product(cfg, lc.st, inputs)
+    opt_p, opt_a, opt_d = build_optimizers(m, lr=lc.lr, weight_decay=1e-3)
+    opts = {'p': opt_p, 'd': opt_d, 'a': opt_a}
+    crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), torch.device('cuda'),
+                         attn_w=0.5, mlp_w=0.5, patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+    imgs, labels = lc.imgs.cuda(), lc.labels.cuda()
+
+    def step(finish):
+        m.train()
+        for p in m.parameters():
+            p.grad = None
+        logits, (dec, _) = m(imgs)
+        loss = crit(imgs, logits, labels, m, 'arch', 1.0, finish)
+        base, arch = loss if isinstance(loss, tuple) else (loss, torch.zeros((), device='cuda'))
+        total = base + arch + (base / dec).detach() * dec
+        total.backward()
+        tot, sea = m.get_flops()
+        grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in m.named_parameters()}
+        for o in opts.values():
+            if o is not None:
+                o.step()
+        torch.cuda.synchronize()
+        out = dict(logits=logits, decoder_loss=dec.detach(), base=base.detach(), arch=arch.detach(), loss_total=total.detach(),
+                   flops_total=tot, flops_searched=sea)
+        return out, grads
+
+    out, grads = step(False)
+    print('s0 worst grad rel err', check_step(z, 's0', out, grads, dict(m.named_parameters()), tol=1e-4, grad_tol=3e-3))
+    for stage in (1, 2):
+        for name, a in lc.crafted(stage).items():
+            mod = dict(zip(O.module_names(cfg), m.searchable_modules))[name]
+            assert tuple(mod.alpha.shape) == tuple(a.shape), name
+            mod.alpha.data.copy_(a)
+        fin, ex, opts['p'], opts['d'], opts['a'] = m.compress(lc.thresh, opts['p'], opts['d'], opts['a'])
+        assert [int(fin), int(ex)] == z[f'c{stage}.model_flags'].tolist()
+        check_snapshot(z, f'c{stage}', cfg, dict(m.named_parameters()), _state_view(m, cfg), _opt_view(m, opts))
+        if fin:
+            opts['a'] = None
+        out, grads = step(bool(fin))
+        print(f's{stage} worst grad rel err', check_step(z, f's{stage}', out, grads, dict(m.named_parameters()), tol=1e-3, grad_tol=3e-3))
+    assert fin and m.finish_search
+    m.eval()
+    with torch.no_grad():
+        lg = m(imgs)[0]
+        assert float((lg.cpu() - torch.from_numpy(z['eval.logits_prefuse'])).abs().max()) < 2e-3
+        m.fuse()
+        lg2 = m(imgs)[0]
+        assert float((lg2.cpu() - torch.from_numpy(z['eval.logits_fused'])).abs().max()) < 2e-3
+        assert float((lg2 - lg).abs().max()) < 1e-4
+
+
+def test_index_select_kernel():
+    from ofb_amd import hip
+    torch.manual_seed(0)
+    t = torch.randn(5, 37, 12, device='cuda')
+    for dim, n in ((0, 3), (1, 20), (2, 7), (-1, 12)):
+        idx = torch.randperm(t.shape[dim])[:n]
+        got = hip.index_select(t, idx, dim)
+        assert got.is_contiguous() and torch.equal(got, t.index_select(dim % 3, idx.cuda()))
+    with pytest.raises(hip.OfbError):
+        hip.index_select(t, torch.tensor([0, 37]), 1)
+    with pytest.raises(hip.OfbError):
+        hip.index_select(t, torch.tensor([0, 37], device='cuda'), 1)

@@ -91,3 +91,45 @@ def test_unsupported_options_are_explicit():
         ofb_amd.create_model('deit_small_patch16_224_mim', method='search', patch_search=True)
     with pytest.raises(NotImplementedError):
         ofb_amd.create_model('deit_small_patch16_224_mim', pretrained=True, method='search', patch_search=False)
+
+
+# ---- compress(): host-side decisions (no device needed) -------------------------------------------------
+def test_cell_pruning_rule_matches_oracle():
+    from ofb_amd.layers import plan_cell_pruning, rank_cut
+    from oracle import ofb_oracle as O
+    torch.manual_seed(3)
+    alpha = torch.randn(3, 7)
+    alpha[1, 2], alpha[2, 6] = -7.0, -9.0
+    sw = torch.ones(3, 7, dtype=torch.bool)
+    sw[0, 0] = False
+    thr = 0.2 / int(sw.sum())
+    prob = plan_cell_pruning(alpha, sw, thr)
+    ref = O.masked_softmax(alpha, sw)
+    assert prob is not None and torch.allclose(prob, ref) and float(prob[0, 0]) == 0.0
+    assert (prob > thr).sum() == int(sw.sum()) - 2
+    assert plan_cell_pruning(torch.zeros(1, 7), torch.ones(1, 7, dtype=torch.bool), 0.2 / 7) is None     # uniform: nothing dies
+    score = torch.randn(6, 64)
+    heads, chan = rank_cut(score, 24, 4)
+    assert heads.tolist() == torch.argsort(score.sigmoid().sum(-1), descending=True)[:4].tolist()
+    assert chan.shape == (4, 24)
+    for r, h in enumerate(heads.tolist()):
+        assert chan[r].tolist() == torch.argsort(score[h], descending=True)[:24].tolist()
+    assert rank_cut(score[:1], 10)[0] is None
+
+
+def test_adamw_update_slot_bookkeeping():
+    """optimizer surgery that needs no device work: re-seeded state and frozen parameters leaving their group."""
+    from ofb_amd.optim import AdamW
+    a, b = torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4))
+    opt = AdamW([a, b], {0: ['a', 'b']}, lr=1e-3)
+    opt.state[a] = {'step': 5, 'exp_avg': torch.ones(2, 3), 'exp_avg_sq': torch.ones(2, 3)}
+    opt.state[b] = {'step': 5, 'exp_avg': torch.ones(4), 'exp_avg_sq': torch.ones(4)}
+    a2 = torch.nn.Parameter(torch.zeros(2, 2))
+    opt.update(a, a2, 'a', 0, torch.arange(2), dim=-1, initialize=True)
+    assert opt.param_groups[0]['params'][0] is a2 and a not in opt.state
+    assert opt.state[a2]['step'] == 0 and opt.state[a2]['exp_avg'].shape == (2, 2) and float(opt.state[a2]['exp_avg'].abs().sum()) == 0
+    b.requires_grad = False
+    opt.update(b, b, 'b', 0, None, dim=-1)
+    assert opt.param_names[0] == ['a'] and len(opt.param_groups[0]['params']) == 1 and b not in opt.state
+    with pytest.raises(ValueError):
+        opt.update(b, b, 'b', 0, None, dim=-1)               # no longer listed (same error as list.index in the reference)
