@@ -236,6 +236,13 @@ typedef struct ofb_adamw_tensor { float* p; const float* g; float* m; float* v; 
 int ofb_adamw_step(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int32_t step, void* stream);
 
+/* Multi-tensor weight EMA (utils.py:430-441 `ema_v.copy_(ema_v * decay + (1 - decay) * model_v)`), one launch for the
+ * whole state_dict; products and the sum are rounded separately (no FMA contraction) so the result is bit-identical to
+ * the reference's three elementwise ops.  one_minus_decay = (float)(1.0 - (double)decay), as Python computes it. */
+typedef struct ofb_ema_tensor { float* ema; const float* src; int64_t n; } ofb_ema_tensor;
+int ofb_ema_update(const ofb_ema_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float decay, float one_minus_decay,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -389,6 +389,22 @@ extern "C" int ofb_scale_by_scalar(const float* x, const float* scalar_dev, floa
   return ofb_launch_status();
 }
 
+__global__ __launch_bounds__(256) void ema_kernel(const ofb_ema_tensor* __restrict__ tab, float decay, float omd) {
+  const ofb_ema_tensor tt = tab[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tt.n; i += (int64_t)gridDim.x * 256)
+    tt.ema[i] = __fadd_rn(__fmul_rn(tt.ema[i], decay), __fmul_rn(omd, tt.src[i]));
+}
+
+extern "C" int ofb_ema_update(const ofb_ema_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float decay,
+                              float one_minus_decay, void* stream) {
+  if (!table_dev || n_tensors <= 0 || max_numel <= 0) return OFB_EINVAL;
+  int bx = (int)((max_numel + 256 * 8 - 1) / (256 * 8));
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(ema_kernel, dim3(bx, n_tensors), dim3(256), 0, (hipStream_t)stream, table_dev, decay, one_minus_decay);
+  return ofb_launch_status();
+}
+
 extern "C" int ofb_index_select(const float* src, const int32_t* idx, float* dst, int64_t outer, int64_t n_src, int64_t n_idx,
                                 int64_t inner, int32_t* bad, void* stream) {
   if (!src || !idx || !dst || outer <= 0 || n_src <= 0 || n_idx <= 0 || inner <= 0) return OFB_EINVAL;

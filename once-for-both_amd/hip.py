@@ -43,7 +43,7 @@ SYMBOLS = [
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets',
-    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
+    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
 ]
 
 
@@ -212,6 +212,10 @@ class FlopsCfg(C.Structure):
                 ('wconst', C.c_void_p), ('n_live', C.c_int32)]
 
 
+class EmaTensor(C.Structure):
+    _fields_ = [('ema', C.c_void_p), ('src', C.c_void_p), ('n', C.c_int64)]
+
+
 class AdamwTensor(C.Structure):
     _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64)]
 
@@ -276,6 +280,11 @@ def ls_cross_entropy(logits, labels, row_loss, loss, grad, B, Cn, smoothing):
 
 def scale_by_scalar(x, scalar_dev, out, n):
     check(lib().ofb_scale_by_scalar(ptr(x), ptr(scalar_dev), ptr(out), C.c_int64(n), stream()), 'ofb_scale_by_scalar')
+
+
+def ema_update(table_dev, n_tensors, max_numel, decay):
+    check(lib().ofb_ema_update(ptr(table_dev), _i(n_tensors), C.c_int64(max_numel), C.c_float(decay), C.c_float(1.0 - decay), stream()),
+          'ofb_ema_update')
 
 
 def index_select(t, index, dim):

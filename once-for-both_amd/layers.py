@@ -51,6 +51,14 @@ class DropPath(nn.Module):
         return x if s is None else x * s.view(-1, *([1] * (x.dim() - 1)))
 
 
+def drop_path_scale(dp, batch, device, u=None, tokens=1):
+    """row_scale for any stochastic-depth module that carries `drop_prob` (ours, or timm's DropPath inside a checkpoint
+    unpickled where timm is installed); None for nn.Identity."""
+    if not hasattr(dp, 'drop_prob'):
+        return None
+    return DropPath.row_scale(dp, batch, device, u, tokens)
+
+
 class LayerNorm(nn.Module):
     """reference models/layers.py:17-102: F.layer_norm over the last dim; `normalized_shape` is a mutable list so
     compress() can shrink it."""
@@ -126,6 +134,15 @@ class _Searchable:
         self.execute_prune = False
         self.fused = False
         self.w_p = 0.99
+
+    def __getstate__(self):
+        """checkpoint / deepcopy view: per-forward gate tensors (autograd outputs) are caches, not state."""
+        d = self.__dict__.copy()
+        d['_g'] = d['_wr'] = None
+        for k in ('weighted_mask', 'weighted_mask_embed'):
+            if isinstance(d.get(k), torch.Tensor):
+                d[k] = d[k].detach()
+        return d
 
     def update_w(self, cur_epoch, warmup_epochs, max=0.99, min=0.1):
         if cur_epoch <= warmup_epochs:                      # reference layers.py:169-171
@@ -363,13 +380,11 @@ class MAESparseAttention(Attention, _Searchable):
                          attn_module.attn_drop.p, attn_module.proj_drop.p)
         self._init_search_state()
         H, d = self.num_heads, self.head_dim
-        self._score_shape = (H, d)
         if attn_search:
             heads = list(range(2, H + 1, 2))
             ratios = [i / d for i in range(d // 4, d + 1, max(d // 8, 1))]
             if head_search:
                 self.head_num_list = heads
-                self._heads, self._chans, self._score_shape = heads, [d], (H, 1)
                 raise NotImplementedError('head-only search space: not on the default OFB path')
             elif channel_search:
                 self.qkv_channel_ratio_list = ratios

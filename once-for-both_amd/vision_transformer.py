@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from . import hip, ops
-from .layers import (Attention, DropPath, LayerNorm, MAEPatchEmbed, MAESparseAttention, MAESparseMlp, Mlp, ModuleInjection,
+from .layers import (Attention, DropPath, drop_path_scale, LayerNorm, MAEPatchEmbed, MAESparseAttention, MAESparseMlp, Mlp, ModuleInjection,
                      PatchEmbed, reduce_tensor, trunc_normal_)
 
 
@@ -79,7 +79,7 @@ class Block(nn.Module):
         self.mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
 
     def _row_scale(self, x, u=None):
-        return self.drop_path.row_scale(x.shape[0], x.device, u, tokens=x.shape[1]) if isinstance(self.drop_path, DropPath) else None
+        return drop_path_scale(self.drop_path, x.shape[0], x.device, u, tokens=x.shape[1])
 
     def forward(self, x):
         y, xr = ops.layer_norm_fork(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
@@ -122,7 +122,7 @@ class MAEBlock(nn.Module):
         x, weighted_mask_embed, weighted_embed = input
         self.weighted_mask_embed = weighted_mask_embed
         replace = weighted_mask_embed is not None and bool(((weighted_mask_embed < 1) & (weighted_mask_embed > 0)).any())
-        rs = (lambda: self.drop_path.row_scale(x.shape[0], x.device, tokens=x.shape[1])) if isinstance(self.drop_path, DropPath) else (lambda: None)
+        rs = lambda: drop_path_scale(self.drop_path, x.shape[0], x.device, tokens=x.shape[1])
         g_a = self.attn.current_gate() if hasattr(self.attn, 'current_gate') else None
         g_m = self.mlp.current_gate() if hasattr(self.mlp, 'current_gate') else None
         return self.run(x, replace, g_a, g_m, rs(), rs()), weighted_mask_embed
@@ -243,6 +243,25 @@ class MIMVisionTransformer(MAEBaseModel):
         self._gate_out = None
         self._side_stream = None
 
+    # ---- checkpoints: whole-object pickles (search.py:671-740) and deepcopy (ModelEma) --------------
+    _TRANSIENT = ('_gate_out', '_side_stream', '_flops_maps', '_forced', '_masked_ids')
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        for k in self._TRANSIENT:
+            d[k] = None
+        return d
+
+    def __setstate__(self, state):
+        """also accepts the attribute set of a model pickled by the reference (utils.install_reference_aliases)."""
+        super().__setstate__(state)
+        for k in self._TRANSIENT:
+            self.__dict__.setdefault(k, None)
+        self.__dict__.setdefault('_gate_flags', (1, 1, 1))
+        if '_hidden0' not in self.__dict__:
+            mlp = self.blocks[0].mlp
+            self._hidden0 = getattr(mlp, 'hidden_features', mlp.fc1.out_features)
+
     # ---- small reference API -------------------------------------------------------------------
     def adjust_masking_ratio(self, epoch, warmup_epochs, total_epochs, min_ratio=0.75, max_ratio=0.95, method='linear'):
         if epoch <= warmup_epochs:
@@ -319,7 +338,7 @@ class MIMVisionTransformer(MAEBaseModel):
         # (:193); that is equivalent to "more than one embed cell is still on", which is host state.
         replace = (not pe.finish_search) and int(pe.switch_cell.sum()) > 1 if hasattr(pe, 'switch_cell') else False
         depth = len(self.blocks)
-        rates = [b.drop_path.drop_prob if isinstance(b.drop_path, DropPath) else 0.0 for b in self.blocks]
+        rates = [float(getattr(b.drop_path, 'drop_prob', 0.0)) for b in self.blocks]
         u = None
         if self.training and any(r > 0 for r in rates):
             forced = self._forced

@@ -334,6 +334,13 @@ def run_compress_case(tag='mini_c', batch=2, w_p=0.7, keep_ratio=0.9, drop_path=
             out['eval.logits_fused'] = wrapped(imgs)[0].numpy()
         for k, p in model.named_parameters():
             out[f'fused.vsamp.{k}'] = sample(p)
+        # whole-object checkpoint exactly as search.py:775-781 writes `model_fused.pth` (class paths models.layers.* /
+        # models.vision_transformer.* inside): the compatibility fixture for ofb_amd.utils.install_reference_aliases
+        import gzip
+        buf = io.BytesIO()
+        torch.save(model, buf)
+        with gzip.open(os.path.join(HERE, 'mini_c_model_fused.pth.gz'), 'wb', compresslevel=9) as f:
+            f.write(buf.getvalue())
     finally:
         torch.cuda.synchronize = real_sync
     path = os.path.join(HERE, f'{tag}.npz')

@@ -112,3 +112,83 @@ def test_index_select_kernel():
         hip.index_select(t, torch.tensor([0, 37]), 1)
     with pytest.raises(hip.OfbError):
         hip.index_select(t, torch.tensor([0, 37], device='cuda'), 1)
+
+
+def _load_reference_fused_checkpoint():
+    import gzip
+    import io
+    import os
+    from ofb_amd import utils
+    from tests.golden_util import GOLDEN_DIR
+    utils.install_reference_aliases()
+    with gzip.open(os.path.join(GOLDEN_DIR, 'mini_c_model_fused.pth.gz'), 'rb') as f:
+        return torch.load(io.BytesIO(f.read()), map_location='cpu', weights_only=False)
+
+
+def test_reference_whole_object_checkpoint_runs_on_hip():
+    """a `model_fused.pth` written by the reference (class paths models.*) unpickles into this package's classes and its
+    eval forward on the HIP kernels reproduces the reference's logits."""
+    import ofb_amd
+    lc = Lifecycle(torch.float32)
+    m = _load_reference_fused_checkpoint()
+    assert isinstance(m, ofb_amd.MIMVisionTransformer) and m.finish_search and m.fused
+    m.cuda().eval()
+    with torch.no_grad():
+        lg = m(lc.imgs.cuda())[0]
+    assert float((lg.cpu() - torch.from_numpy(lc.z['eval.logits_fused'])).abs().max()) < 2e-3
+    tot, sea = m.get_flops()
+    assert abs(float(sea) - float(lc.z['s2.flops_searched'])) < 1e-6 and abs(tot - float(lc.z['s2.flops_total'])) < 1e-6
+
+
+def test_intersect_loads_searched_model_into_finetune_vit():
+    """finetune.py:182-249: the plain ViT adopts the cut shapes / head counts of the searched model; with the gates
+    already folded (fused) both models are the same function."""
+    import ofb_amd
+    from ofb_amd import utils
+    lc = Lifecycle(torch.float32)
+    src = _load_reference_fused_checkpoint().cuda().eval()
+    ft = ofb_amd.VisionTransformer(embed_dim=128, depth=3, num_heads=4, num_classes=10, drop_path_rate=0.1).cuda()
+    utils.intersect(ft, src)
+    assert [b.attn.num_heads for b in ft.blocks] == [2, 4, 2]
+    assert ft.blocks[1].mlp.fc1.out_features == 128 and ft.norm.normalized_shape[0] == 100 and ft.head.in_features == 100
+    ft.eval()
+    with torch.no_grad():
+        lg = ft(lc.imgs.cuda())
+    assert float((lg.cpu() - torch.from_numpy(lc.z['eval.logits_fused'])).abs().max()) < 2e-3
+    ft2 = ofb_amd.VisionTransformer(embed_dim=128, depth=3, num_heads=4, num_classes=7).cuda()
+    utils.intersect(ft2, src, exclude=['head'])
+    assert tuple(ft2.head.weight.shape) == (7, 100)
+    assert tuple(ft2(lc.imgs.cuda()).shape) == (2, 7)
+
+
+def test_model_ema_fused_update_and_reshape():
+    from ofb_amd.utils import ModelEma
+    from tests.golden_util import load_case
+    z, cfg, st, inputs, lr = load_case('micro_a')
+    m = build_product(cfg, st, inputs)
+    ema = ModelEma(m, decay=0.99)
+    assert not any(p.requires_grad for p in ema.ema.parameters())
+    before = {k: v.clone() for k, v in ema.ema.state_dict().items()}
+    torch.manual_seed(1)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn_like(p) * 0.01)
+    ema.update(m)
+    ema.update(m)                                                     # cached table path
+    msd = m.state_dict()
+    for k, v in ema.ema.state_dict().items():
+        e1 = before[k] * 0.99 + (1. - 0.99) * msd[k]
+        e2 = e1 * 0.99 + (1. - 0.99) * msd[k]
+        assert torch.equal(v, e2), k                                  # bit-identical to the reference's expression
+    # a compress() changes shapes: the EMA copy adopts the new tensors (utils.py:442-447)
+    mods = dict(zip(O.module_names(cfg), m.searchable_modules))
+    a = torch.full((1, 7), -6.0)
+    a[0, 2] = 0.0
+    mods['blocks.0.mlp'].alpha.data.copy_(a)
+    m.compress(0.2)
+    ema.update(m)
+    esd = ema.ema.state_dict()
+    assert tuple(esd['blocks.0.mlp.fc1.weight'].shape) == tuple(m.blocks[0].mlp.fc1.weight.shape) == (128, 64)
+    assert torch.equal(esd['blocks.0.mlp.fc1.weight'], m.blocks[0].mlp.fc1.weight.data)
+    assert ema.ema.blocks[0].mlp.fc1.out_features == 128
+    ema.update(m)

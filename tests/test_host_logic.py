@@ -133,3 +133,17 @@ def test_adamw_update_slot_bookkeeping():
     assert opt.param_names[0] == ['a'] and len(opt.param_groups[0]['params']) == 1 and b not in opt.state
     with pytest.raises(ValueError):
         opt.update(b, b, 'b', 0, None, dim=-1)               # no longer listed (same error as list.index in the reference)
+
+
+def test_model_deepcopy_and_pickle_roundtrip_cpu():
+    """ModelEma deep-copies the model and search.py pickles it whole: transient caches must not block either."""
+    import copy, io
+    m = build('deit_tiny_patch16_224_mim', num_classes=2)
+    m._gate_out = {'wsum': torch.ones(3, requires_grad=True) * 2}      # a non-leaf autograd output, as left by a forward
+    m2 = copy.deepcopy(m)
+    assert m2._gate_out is None and m2._hidden0 == m._hidden0
+    buf = io.BytesIO()
+    torch.save(m, buf)
+    buf.seek(0)
+    m3 = torch.load(buf, weights_only=False)
+    assert sorted(m3.state_dict()) == sorted(m.state_dict()) and m3._gate_flags == (1, 1, 1)
