@@ -1,9 +1,17 @@
-// f32 GEMM on v_mfma_f32_32x32x2_f32 (exact f32 fma chains) with fused epilogues.
-// Block tile 128x128x16, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs).
-// Both operands are staged [mn][k] in LDS (row pitch 20 floats) through registers with a one-tile global
-// prefetch; K-contiguous operands are written with ds_write_b128, MN-contiguous ones are transposed on the
-// way in, so the three storage combinations the Linear layers need (x@W^T, dY@W, dY^T@X) share one inner
-// loop of 8 ds_read_b128 + 32 MFMA per wave and K-tile.
+// f32 GEMM with fused epilogues.  Block tile 128x128x16, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles (64 accumulator
+// VGPRs).  Two matrix engines share everything but the LDS image and the inner product (OFB_GEMM_BF16X6):
+//
+//  1 (default)  f32 operands are split EXACTLY into three bf16 values (x = hi + mid + lo, round-to-nearest residual chain)
+//               while they are staged to LDS, and every K-step issues the six leading product terms (mid*mid, hi*lo, lo*hi,
+//               hi*mid, mid*hi, hi*hi; the dropped ones are <= 2^-24 relative) on v_mfma_f32_32x32x16_bf16 with f32
+//               accumulation.  Measured error equals that of an f32 fma chain (1.3e-7 of sum|a*b| at K = 384..1536); the
+//               bf16 matrix pipe has 16x the f32-MFMA rate, so six terms still run ~1.6x faster than the f32 MFMA form.
+//               LDS image per operand tile: 3 planes x 2 k-halves x [128 rows][8 bf16] (fragment = one ds_read_b128).
+//  0            v_mfma_f32_32x32x2_f32 on f32 tiles staged [mn][k] (row pitch 20 floats): bit-exact f32 fma chains.
+//
+// Operands go global -> registers -> LDS with a one-tile prefetch; K-contiguous operands are written row-wise,
+// MN-contiguous ones are transposed on the way in, so the three storage combinations the Linear layers need
+// (x@W^T, dY@W, dY^T@X) share one inner loop.
 //
 // Scheduling (hybrid stream-K): W = CUs x 3 persistent workgroups.  Output tiles that fill whole rounds of W are
 // computed data-parallel with the epilogue fused; the R = tiles mod W remaining tiles are cut along K into W equal
@@ -23,6 +31,18 @@
 #define NLD (BM * BK / 4 / 256)   // float4 loads per thread and operand tile
 #ifndef GEMM_WAVES_PER_SIMD
 #define GEMM_WAVES_PER_SIMD 2
+#endif
+#ifndef OFB_GEMM_BF16X6
+#define OFB_GEMM_BF16X6 1
+#endif
+#if OFB_GEMM_BF16X6
+static_assert(BK == 16, "the bf16x6 engine stages one 32x32x16 MFMA K-step per tile");
+#define SPL_BLK (BM * 16 + 16)       // bytes of one [128 rows][8 bf16] block (+16: the two k-halves land on different banks)
+#define SPL_PLANE (2 * SPL_BLK)      // k-halves
+#define SPL_OPER (3 * SPL_PLANE)     // hi / mid / lo planes
+#define LDS_OPER_FLOATS (SPL_OPER / 4)
+#else
+#define LDS_OPER_FLOATS (BM * LDP)
 #endif
 
 namespace {
@@ -54,6 +74,38 @@ __device__ __forceinline__ void load_kc(TileRegs& r, const float* __restrict__ X
     r.v[i] = v;
   }
 }
+#if OFB_GEMM_BF16X6
+typedef __bf16 ofb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ofb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float ofb_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {      // v_cvt_pk_bf16_f32: a -> low half, b -> high half (RNE)
+  ofb_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ofb_bf16x2));
+}
+// x = hi + mid + lo with each part a bf16 (24 significant bits in total: exact for finite f32 in the normal range);
+// two values at a time so every step is one packed instruction.
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = pack_bf16(a, b);
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+  mid = pack_bf16(ra, rb);
+  lo = pack_bf16(ra - __uint_as_float(mid << 16), rb - __uint_as_float(mid & 0xffff0000u));
+}
+// K-contiguous tile: thread item (row = idx/4, k = 4*(idx%4) .. +3) -> 4 bf16 (8 B) per plane at [k>>3][row][k&7]
+__device__ __forceinline__ void store_kc(const TileRegs& r, float* __restrict__ S, int t) {
+  char* base = reinterpret_cast<char*>(S);
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) {
+    const int idx = t + 256 * i, row = idx >> 2, kq = idx & 3;
+    unsigned h0, m0, l0, h1, m1, l1;
+    split_pair(r.v[i][0], r.v[i][1], h0, m0, l0);
+    split_pair(r.v[i][2], r.v[i][3], h1, m1, l1);
+    char* p = base + (kq >> 1) * SPL_BLK + row * 16 + (kq & 1) * 8;
+    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(p + SPL_PLANE) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(p + 2 * SPL_PLANE) = make_uint2(l0, l1);
+  }
+}
+#else
 __device__ __forceinline__ void store_kc(const TileRegs& r, float* __restrict__ S, int t) {
 #pragma unroll
   for (int i = 0; i < NLD; ++i) {
@@ -61,6 +113,54 @@ __device__ __forceinline__ void store_kc(const TileRegs& r, float* __restrict__ 
     *reinterpret_cast<f32x4*>(&S[(idx / (BK / 4)) * LDP + ((idx % (BK / 4)) << 2)]) = r.v[i];
   }
 }
+#endif
+#if OFB_GEMM_BF16X6
+// MN-contiguous storage X[k*ld + o]: thread t takes rows o = 4*(t/8) .. +3 at the k PAIR (2*(t%8), 2*(t%8)+1): v[0] = even k,
+// v[1] = odd k, so that each output row's two values pack into one bf16x2 LDS word per plane (the transpose costs
+// 12 ds_write_b32 per thread and tile instead of 24 ds_write_b16).
+template <bool VEC, bool GUARD>
+__device__ __forceinline__ void load_mc(TileRegs& r, const float* __restrict__ X, int ld, int o0, int O, int k0, int kend,
+                                        int t, const float* __restrict__ kscale, int ks_div) {
+  static_assert(NLD == 2, "pair loader assumes 2 float4 per thread");
+  const int o = o0 + ((t >> 3) << 2);
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int k = k0 + 2 * (t & 7) + i;
+    if (!GUARD) {
+      f32x4 u = *reinterpret_cast<const f32x4*>(X + (size_t)k * ld + o);
+      if (kscale) u *= kscale[ks_div == 1 ? k : k / ks_div];
+      r.v[i] = u;
+      continue;
+    }
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (k < kend) {
+      const float* p = X + (size_t)k * ld + o;
+      if (VEC) {
+        if (o < O) v = *reinterpret_cast<const f32x4*>(p);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (o + j < O) v[j] = p[j];
+      }
+      if (kscale) v *= kscale[ks_div == 1 ? k : k / ks_div];
+    }
+    r.v[i] = v;
+  }
+}
+__device__ __forceinline__ void store_mc(const TileRegs& r, float* __restrict__ S, int t) {
+  const int kp = t & 7, row0 = (t >> 3) << 2;
+  char* base = reinterpret_cast<char*>(S) + (kp >> 2) * SPL_BLK + (kp & 3) * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    unsigned h, m, l;
+    split_pair(r.v[0][j], r.v[1][j], h, m, l);
+    char* p = base + (row0 + j) * 16;
+    *reinterpret_cast<unsigned*>(p) = h;
+    *reinterpret_cast<unsigned*>(p + SPL_PLANE) = m;
+    *reinterpret_cast<unsigned*>(p + 2 * SPL_PLANE) = l;
+  }
+}
+#else
 // MN-contiguous storage X[k*ld + o]: kk = idx&15, oq = idx>>4 (consecutive lanes take consecutive k rows so that the
 // transposing b32 writes S[(4oq+j)][kk] hit 32 distinct banks).
 template <bool VEC, bool GUARD>
@@ -98,6 +198,7 @@ __device__ __forceinline__ void store_mc(const TileRegs& r, float* __restrict__ 
     for (int j = 0; j < 4; ++j) S[(o + j) * LDP + kk] = r.v[i][j];
   }
 }
+#endif
 
 struct Plan { int mt, nt, ntiles, I, W, full_rounds, R, q; };
 
@@ -165,9 +266,9 @@ __device__ __forceinline__ float epilogue_value(float alpha, int act, float* __r
 // K-iterations per workgroup, raw partial tiles to the workspace).  Same main loop; launched back to back.
 template <bool A_KC, bool B_KC, bool VEC, bool GUARD, bool FULL_EPI, bool TAIL, bool DEFER>
 __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(const ofb_gemm_args g, const Plan p) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BM * LDP];
-  float* As = lds;                    // [2][BM][LDP]
-  float* Bs = lds + 2 * BM * LDP;     // [2][BN][LDP]
+  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * LDS_OPER_FLOATS];
+  float* As = lds;                          // [2 buffers] of one staged A tile
+  float* Bs = lds + 2 * LDS_OPER_FLOATS;    // [2 buffers] of one staged B tile
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
   const int v = ofb_xcd_remap(blockIdx.x, p.W);     // consecutive v share an XCD (and thus A/B panels in its L2)
@@ -189,10 +290,43 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
     if (B_KC) load_kc<VEC, GUARD>(rb, g.B, g.ldb, sg.n0, g.N, k0, g.K, t);
     else load_mc<VEC, GUARD>(rb, g.B, g.ldb, sg.n0, g.N, k0, g.K, t, nullptr, 1);
   };
-  auto lstore = [&](int buf) __attribute__((always_inline)) {
-    if (A_KC) store_kc(ra, As + buf * BM * LDP, t); else store_mc(ra, As + buf * BM * LDP, t);
-    if (B_KC) store_kc(rb, Bs + buf * BN * LDP, t); else store_mc(rb, Bs + buf * BN * LDP, t);
+  // fused bias gradient (weight-gradient launches): column sums of the stored A (= dY) for the workgroups that own the
+  // first column tile.
+  float bsum = 0.f;
+#if OFB_GEMM_BF16X6
+  f32x4 bsum4 = {0.f, 0.f, 0.f, 0.f};    // rows 4*(t/8) .. +3, this thread's k pairs; reduced over the 8 pair-lanes at unit end
+#endif
+  auto lstore = [&](int buf, int tile_n0) __attribute__((always_inline)) {
+#if OFB_GEMM_BF16X6
+    if (TAIL && !A_KC && g.a_colsum && tile_n0 == 0) bsum4 += ra.v[0] + ra.v[1];
+#endif
+    if (A_KC) store_kc(ra, As + buf * LDS_OPER_FLOATS, t); else store_mc(ra, As + buf * LDS_OPER_FLOATS, t);
+    if (B_KC) store_kc(rb, Bs + buf * LDS_OPER_FLOATS, t); else store_mc(rb, Bs + buf * LDS_OPER_FLOATS, t);
   };
+#if OFB_GEMM_BF16X6
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    // lane (row l31, k-half h) reads its 8 bf16 of each plane with one b128; A and B share the k <-> (half, j) map.
+    const char* a_s = reinterpret_cast<const char*>(As + buf * LDS_OPER_FLOATS) + h * SPL_BLK + (wm0 + l31) * 16;
+    const char* b_s = reinterpret_cast<const char*>(Bs + buf * LDS_OPER_FLOATS) + h * SPL_BLK + (wn0 + l31) * 16;
+    ofb_bf16x8 af[2][3], bf[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        af[i][pl] = *reinterpret_cast<const ofb_bf16x8*>(a_s + pl * SPL_PLANE + i * 32 * 16);
+        bf[i][pl] = *reinterpret_cast<const ofb_bf16x8*>(b_s + pl * SPL_PLANE + i * 32 * 16);
+      }
+    // six product terms, smallest first: (mid,mid) (hi,lo) (lo,hi) (hi,mid) (mid,hi) (hi,hi)
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[q]], bf[j][TB[q]], acc[i][j], 0, 0, 0);
+  };
+#else
   auto compute = [&](int buf) __attribute__((always_inline)) {
     // fragment reads: lane (row l31, half h) takes k = 8q + 4h + j (q < BK/8; j = 0..3) with one b128 per q; A and B
     // use the same k <-> (q, h, j) map, so each MFMA step (q, j) multiplies matching k's.
@@ -216,14 +350,15 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][q][j], bf[1][q][j], acc[1][1], 0, 0, 0);
       }
   };
+#endif
 
   int sidx = 0;
   Seg cur = get_seg<TAIL>(p, v, 0);
   if (!cur.ok) return;
-  // fused bias gradient (weight-gradient launches): column sums of the stored A (= dY), taken from the staged A tile
-  // by the workgroups that own the first column tile; thread t < 128 owns output row t of the tile.
-  float bsum = 0.f;
+  // f32 engine: the sums are taken from the staged f32 A tile (thread t < 128 owns output row t); the split engine adds
+  // the registers up while staging them (lstore) because its LDS image is no longer f32.
   auto colsum_acc = [&](int buf) {
+#if !OFB_GEMM_BF16X6
     if (TAIL && !A_KC && g.a_colsum && cur.n0 == 0 && t < BM) {
       const float* row = As + buf * BM * LDP + t * LDP;
 #pragma unroll
@@ -232,9 +367,10 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
         bsum += (u[0] + u[1]) + (u[2] + u[3]);
       }
     }
+#endif
   };
   gload(cur, cur.it0);
-  lstore(0);
+  lstore(0, cur.n0);
   __syncthreads();
   int buf = 0;
 
@@ -279,7 +415,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
       gload(cur, it + 1);
       compute(buf);
       __builtin_amdgcn_sched_barrier(0);            // every MFMA of this K-tile stays ahead of the wait / LDS refill
-      lstore(buf ^ 1);
+      lstore(buf ^ 1, cur.n0);
       if (pend) epi_store(G);
       __syncthreads();
       buf ^= 1;
@@ -294,7 +430,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
         gload(cur, it + 1);
         compute(buf);
         __builtin_amdgcn_sched_barrier(0);
-        lstore(buf ^ 1);
+        lstore(buf ^ 1, cur.n0);
         __syncthreads();
         buf ^= 1;
       }
@@ -320,7 +456,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
         pcs0 = g.colscale ? g.colscale[c0] : 1.f; pcs1 = g.colscale ? g.colscale[c0 + 32] : 1.f;
       }
       if (!has_next) break;
-      lstore(buf ^ 1);
+      lstore(buf ^ 1, nxt.n0);
       __syncthreads();
       buf ^= 1;
       ++sidx;
@@ -338,31 +474,41 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
   while (true) {
     // all K-iterations of this unit but the last: prefetch the next K-tile of the same unit
     for (int it = cur.it0; it + 1 < cur.it1; ++it) {
-#ifndef LAB_NO_GLOAD
       gload(cur, it + 1);
-#endif
       colsum_acc(buf);      // its LDS reads / adds are issued ahead of (and overlap) the MFMA block
       compute(buf);
       // keep every MFMA of this K-tile ahead of the vmcnt wait / LDS refill / barrier
       __builtin_amdgcn_sched_barrier(0);
-      lstore(buf ^ 1);
+      lstore(buf ^ 1, cur.n0);
       __syncthreads();
       buf ^= 1;
     }
     // last K-iteration: the NEXT unit's first K-tile goes in flight before this unit's stores
     const Seg nxt = get_seg<TAIL>(p, v, sidx + 1);
     const bool has_next = nxt.ok;
-#ifndef LAB_NO_GLOAD
     if (has_next) gload(nxt, nxt.it0);
-#endif
     colsum_acc(buf);
     compute(buf);
     __builtin_amdgcn_sched_barrier(0);
     if (TAIL) {
+#if OFB_GEMM_BF16X6
+      if (!A_KC && g.a_colsum && cur.n0 == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                 // sum over the 8 k-pair lanes (lane bits 0..2) that share these 4 rows
+          float s4 = bsum4[j];
+          s4 += __shfl_xor(s4, 1);
+          s4 += __shfl_xor(s4, 2);
+          s4 += __shfl_xor(s4, 4);
+          if ((t & 7) == 0) g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)cur.slot * BM + ((t >> 3) << 2) + j] = s4;
+          bsum4[j] = 0.f;
+        }
+      }
+#else
       if (!A_KC && g.a_colsum && cur.n0 == 0 && t < BM) {
         g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)cur.slot * BM + t] = bsum;
         bsum = 0.f;
       }
+#endif
       // raw partial tile -> workspace[slot][128][128] (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
       float* ws = g.workspace + (size_t)cur.slot * (BM * BN);
 #pragma unroll
@@ -459,7 +605,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
       }
     }
     if (!has_next) break;
-    lstore(buf ^ 1);
+    lstore(buf ^ 1, nxt.n0);
     __syncthreads();
     buf ^= 1;
     ++sidx;
@@ -524,10 +670,18 @@ void launch2(const ofb_gemm_args& g, const Plan& p, bool full, hipStream_t s) {
   const dim3 grid(p.W);
   if (p.full_rounds > 0) {
     if constexpr (!GUARD) {
-      if (A_KC && p.I >= 17) {      // deferred, distributed epilogue (needs 16 K-iterations of the next tile to hide under)
-        if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, true, false, true>), grid, dim3(256), 0, s, g, p);
-        else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, false, false, true>), grid, dim3(256), 0, s, g, p);
-      } else {
+      // deferred, distributed epilogue: needs 16 K-iterations of the next tile to hide under, and the register room of
+      // the row-wise staging (with the split engine only the x @ W^T form keeps pending + live accumulators spill-free)
+      constexpr bool CAN_DEFER = OFB_GEMM_BF16X6 ? (A_KC && B_KC) : A_KC;
+      bool deferred = false;
+      if constexpr (CAN_DEFER) {
+        if (p.I >= 17) {
+          deferred = true;
+          if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, true, false, true>), grid, dim3(256), 0, s, g, p);
+          else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, false, false, true>), grid, dim3(256), 0, s, g, p);
+        }
+      }
+      if (!deferred) {
         if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, true, false, false>), grid, dim3(256), 0, s, g, p);
         else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, false, false, false>), grid, dim3(256), 0, s, g, p);
       }
