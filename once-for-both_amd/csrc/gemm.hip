@@ -200,7 +200,7 @@ __device__ __forceinline__ void store_mc(const TileRegs& r, float* __restrict__ 
 }
 #endif
 
-struct Plan { int mt, nt, ntiles, I, W, full_rounds, R, q; };
+struct Plan { int mt, nt, ntiles, I, W, full_rounds, R, q, S, qs; };
 
 __host__ __device__ inline Plan make_plan(int M, int N, int K, int W) {
   Plan p;
@@ -211,7 +211,19 @@ __host__ __device__ inline Plan make_plan(int M, int N, int K, int W) {
   p.W = W;
   p.full_rounds = p.ntiles / W;
   p.R = p.ntiles - p.full_rounds * W;
+  // After >= 3 full rounds a remainder that fills at least half a round runs as one more (partly idle) data-parallel round:
+  // the idle share (< 1/8 of the launch) costs less than the partial-tile traffic and the fix-up launch of a streamed tail.
+  if (p.full_rounds >= 3 && 2 * p.R >= W) { p.full_rounds += 1; p.R = 0; }
   p.q = p.R ? (int)(((long long)p.R * p.I + W - 1) / W) : 0;      // K-iterations per workgroup in the streamed tail (q <= I)
+  // Split-major tail: when the W workgroups divide (almost) evenly over the R tail tiles, cut every tile's K range into the
+  // same S pieces and give workgroup v piece v / R of tile v % R.  Workgroups that run side by side on one XCD then walk the
+  // SAME K rows of different tiles and share them in its L2 (weight gradients: every token row of dY / X is needed by all
+  // tiles), where the flattened runs above place neighbours on different K ranges of one tile and nothing is shared.
+  p.S = 0; p.qs = 0;
+  if (p.R > 0) {
+    const int S = W / p.R;
+    if (S >= 2 && (W - S * p.R) * 10 <= W) { p.S = S; p.qs = (p.I + S - 1) / S; }
+  }
   return p;
 }
 
@@ -226,11 +238,21 @@ __device__ __forceinline__ Seg get_seg(const Plan p, int v, int idx) {
   if (!TAIL) {
     if (idx >= p.full_rounds) return s;
     const int tile = v + idx * p.W;
+    if (tile >= p.ntiles) return s;
     s.m0 = (tile / p.nt) * BM; s.n0 = (tile % p.nt) * BN; s.it0 = 0; s.it1 = p.I; s.ok = true;
     return s;
   }
   const int part = idx;
   if (part > 1 || p.R == 0) return s;
+  if (p.S > 0) {                          // split-major: one piece per workgroup, slot = v
+    if (part != 0) return s;
+    const int sp = v / p.R, tl = v - sp * p.R;
+    const int i0 = sp * p.qs, i1 = min(i0 + p.qs, p.I);
+    if (sp >= p.S || i0 >= i1) return s;
+    const int tile = p.full_rounds * p.W + tl;
+    s.m0 = (tile / p.nt) * BM; s.n0 = (tile % p.nt) * BN; s.it0 = i0; s.it1 = i1; s.slot = v; s.ok = true;
+    return s;
+  }
   // R * I < W * I <= 768 * (K/16): fits 32 bits for every K the host accepts (checked in ofb_gemm_f32)
   const int beg = v * p.q, tot = p.R * p.I;
   const int end = min(beg + p.q, tot);
@@ -522,41 +544,76 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
           }
         }
     } else if (!GUARD) {
-      // unguarded build (every tile is full): no per-element guards, so the stores issue back to back behind ONE wait
+      // unguarded build (every tile is full): no per-element guards, so loads / stores issue back to back behind ONE wait
       // (hipcc otherwise brackets every guarded store with s_waitcnt vmcnt(0), serialising 64 round trips per wave)
+      float biasv[2], csv[2];
 #pragma unroll
       for (int ni = 0; ni < 2; ++ni) {
         const int col = cur.n0 + wn0 + 32 * ni + l31;
-        const float bias = g.bias ? g.bias[col] : 0.f, cs = g.colscale ? g.colscale[col] : 1.f;
+        biasv[ni] = g.bias ? g.bias[col] : 0.f;
+        csv[ni] = g.colscale ? g.colscale[col] : 1.f;
+      }
+      if (FULL_EPI) {
+        // side inputs (residual / saved pre-activation / per-row scale) are requested one whole 32x32 block (16 values per
+        // lane) ahead of the block being finished, so ~32 loads per lane are in flight instead of 4: the epilogue is bound
+        // by memory latency, not bandwidth, and used to expose one round trip per 4 rows.
+        // `side` carries the saved pre-activation for the dGELU form and the residual otherwise (a launch that wants both
+        // reads its residual inside `finish`); the per-row scales of a 32-row band serve both of its column blocks.
+        f32x16 side[2], rsv[2];
+        const bool dg = g.act == OFB_ACT_DGELU;
+        const float* sp = dg ? g.aux : g.resid;
+        const int lds_ = dg ? g.ldaux : g.ldr;
+        auto request = [&](auto Bk, f32x16& sd_) __attribute__((always_inline)) {
+          constexpr int bk = decltype(Bk)::value, mi = bk >> 1, ni = bk & 1;
+          const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-          const int rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
-          if (FULL_EPI) {
-#pragma unroll
-            for (int rg = 0; rg < 4; ++rg) {
-              f32x4 rv = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f}, rsv = {1.f, 1.f, 1.f, 1.f};
-#pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4) {
-                const int row = rbase + r4 + 8 * rg;
-                if (g.resid) rv[r4] = g.resid[(size_t)row * g.ldr + col];
-                if (g.act == OFB_ACT_DGELU) av[r4] = g.aux[(size_t)row * g.ldaux + col];
-                if (g.rowscale) rsv[r4] = g.rowscale[g.rs_div == 1 ? row : row / g.rs_div];
-              }
-#pragma unroll
-              for (int r4 = 0; r4 < 4; ++r4) {
-                const int row = rbase + r4 + 8 * rg;
-                g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][4 * rg + r4], row, col, bias,
-                                                                cs, rsv[r4], rv[r4], av[r4]);
-              }
-              __builtin_amdgcn_sched_barrier(0);   // bound the side-input loads in flight (register pressure)
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-              g.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * g.ldc + col] = (acc[mi][ni][r] * g.alpha + bias) * cs;
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            sd_[r] = sp ? sp[(size_t)row * lds_ + col] : 0.f;
+            if (ni == 0) rsv[mi][r] = g.rowscale ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
           }
+        };
+        auto finish = [&](auto Bk, const f32x16& sd_) __attribute__((always_inline)) {
+          constexpr int bk = decltype(Bk)::value, mi = bk >> 1, ni = bk & 1;
+          const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase + (r & 3) + 8 * (r >> 2);
+            const float rvv = dg ? (g.resid ? g.resid[(size_t)row * g.ldr + col] : 0.f) : sd_[r];
+            g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][r], row, col, biasv[ni], csv[ni],
+                                                            rsv[mi][r], rvv, dg ? sd_[r] : 0.f);
+            acc[mi][ni][r] = 0.f;
+          }
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        request(I0{}, side[0]);
+        request(I1{}, side[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(I0{}, side[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        request(I2{}, side[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(I1{}, side[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        request(I3{}, side[1]);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(I2{}, side[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        finish(I3{}, side[1]);
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+          const int col = cur.n0 + wn0 + 32 * ni + l31;
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi) {
+            const int rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              g.C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * g.ldc + col] = (acc[mi][ni][r] * g.alpha + biasv[ni]) * csv[ni];
+              acc[mi][ni][r] = 0.f;
+            }
+          }
         }
       }
     } else {
@@ -623,24 +680,23 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, 
   const int tile = p.full_rounds * p.W + r;
   const int m0 = (tile / p.nt) * BM, n0 = (tile % p.nt) * BN;
   const int lo = r * p.I, hi = lo + p.I;         // this tile's run of flattened K-iterations
-  const int v0 = lo / p.q, v1 = (hi - 1) / p.q;
+  // contributors: split-major -> pieces i = 0 .. n-1 in slots i*R + r; flattened -> workgroups v0 .. v1 (slot 2v+1 when the
+  // workgroup's run started in the previous tile, else 2v)
+  const int v0 = p.S ? 0 : lo / p.q, v1 = p.S ? (p.I + p.qs - 1) / p.qs - 1 : (hi - 1) / p.q;
+  auto slot_of = [&](int v) { return p.S ? v * p.R + r : ((v * p.q < lo) ? 2 * v + 1 : 2 * v); };
   const int c = t & 127, col = n0 + c;
   constexpr int NJ = FIX_ROWS / 2;
   float sum[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) sum[j] = 0.f;
   for (int v = v0; v <= v1; ++v) {
-    const int slot = (v * p.q < lo) ? 2 * v + 1 : 2 * v;   // second segment if the run started in the previous tile
-    const float* ws = g.workspace + (size_t)slot * (BM * BN) + (size_t)(FIX_ROWS * part + (t >> 7)) * BN + c;
+    const float* ws = g.workspace + (size_t)slot_of(v) * (BM * BN) + (size_t)(FIX_ROWS * part + (t >> 7)) * BN + c;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) sum[j] += ws[(size_t)(2 * j) * BN];
   }
   if (g.a_colsum && n0 == 0 && part == 0 && t < BM && m0 + t < g.M) {
     float bs = 0.f;
-    for (int v = v0; v <= v1; ++v) {
-      const int slot = (v * p.q < lo) ? 2 * v + 1 : 2 * v;
-      bs += g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)slot * BM + t];
-    }
+    for (int v = v0; v <= v1; ++v) bs += g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)slot_of(v) * BM + t];
     g.a_colsum[m0 + t] = bs;
   }
   if (col >= g.N) return;
@@ -672,7 +728,10 @@ void launch2(const ofb_gemm_args& g, const Plan& p, bool full, hipStream_t s) {
     if constexpr (!GUARD) {
       // deferred, distributed epilogue: needs 16 K-iterations of the next tile to hide under, and the register room of
       // the row-wise staging (with the split engine only the x @ W^T form keeps pending + live accumulators spill-free)
-      constexpr bool CAN_DEFER = OFB_GEMM_BF16X6 ? (A_KC && B_KC) : A_KC;
+#ifndef OFB_GEMM_DEFER
+#define OFB_GEMM_DEFER 0
+#endif
+      constexpr bool CAN_DEFER = OFB_GEMM_DEFER && (OFB_GEMM_BF16X6 ? (A_KC && B_KC) : A_KC);
       bool deferred = false;
       if constexpr (CAN_DEFER) {
         if (p.I >= 17) {
