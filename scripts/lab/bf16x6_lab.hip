@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -26,6 +27,12 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #endif
 #ifndef ABL
 #define ABL 0
+#endif
+#ifndef STAMP
+#define STAMP 0
+#endif
+#ifndef PRIO
+#define PRIO 0
 #endif
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int BLK = 128 * 16 + 32;                 // bytes of one [128 rows][8 bf16] block (+pad)
@@ -167,6 +174,7 @@ __device__ __forceinline__ void stage2(const float4 (&r)[2], char* lds_oper, int
   }
 }
 
+__device__ unsigned long long g_stamp[4 * 4096];
 __global__ __launch_bounds__(256, 2) void gemm_v2(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
                                                   int M, int N, int K) {
   __shared__ __attribute__((aligned(16))) char lds[2 * STAGE2];
@@ -200,6 +208,9 @@ __global__ __launch_bounds__(256, 2) void gemm_v2(const float* __restrict__ A, c
   }
   __syncthreads();
   const int nk = K / 16;
+#if STAMP
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int kt = 0; kt < nk; ++kt) {
     char* cur = lds + (kt & 1) * STAGE2;
     char* nxt = lds + ((kt & 1) ^ 1) * STAGE2;
@@ -222,6 +233,10 @@ __global__ __launch_bounds__(256, 2) void gemm_v2(const float* __restrict__ A, c
       gload2(rb, B, K, n0, 16 * (kt + 2), t);
     }
     constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#if PRIO
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(PRIO);
+#endif
 #pragma unroll
     for (int q = 6 - TERMS; q < 6; ++q)
 #pragma unroll
@@ -229,6 +244,10 @@ __global__ __launch_bounds__(256, 2) void gemm_v2(const float* __restrict__ A, c
 #pragma unroll
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][TA[q]], fb[j][TB[q]], acc[i][j], 0, 0, 0);
+#if PRIO
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_setprio(0);
+#endif
 #if SCHED
 #pragma unroll
     for (int g = 0; g < 4 * TERMS; ++g) {
@@ -239,6 +258,12 @@ __global__ __launch_bounds__(256, 2) void gemm_v2(const float* __restrict__ A, c
 #endif
     __syncthreads();
   }
+#if STAMP
+  if (t == 0 && blockIdx.x < 4096) {
+    g_stamp[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+    g_stamp[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
+#endif
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -342,12 +367,125 @@ __global__ __launch_bounds__(256, 2) void gemm_v3(const float* __restrict__ A, c
       }
 }
 
+// ---- v4: ping-pong.  One 512-thread workgroup = two 4-wave groups, one wave of each per SIMD.  Group g owns output tile
+// (2p + g, n); both share the B tile.  In even phases group 0 issues MFMAs while group 1 splits / stages, in odd phases the
+// roles swap, so every SIMD's matrix pipe always has exactly one wave feeding it and the staging VALU runs beside it.
+constexpr int V4_A0 = 0, V4_A1 = OPER2, V4_B = 2 * OPER2;      // LDS: A0 | A1 | B[2]
+
+__device__ __forceinline__ void gload_rows(float4& r, const float* __restrict__ X, int ld, int row, int k0, int kq) {
+  r = *reinterpret_cast<const float4*>(X + (size_t)row * ld + k0 + 4 * kq);
+}
+__device__ __forceinline__ void stage_one(const float4& r, char* lds_oper, int row, int kq) {
+  const int half = kq >> 1, j0 = (kq & 1) * 4;
+  unsigned h0, m0, l0, h1, m1, l1;
+  split2(r.x, r.y, h0, m0, l0);
+  split2(r.z, r.w, h1, m1, l1);
+  char* p = lds_oper + half * BLK2 + row * 16 + j0 * 2;
+  *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+  *reinterpret_cast<uint2*>(p + PLANE2) = make_uint2(m0, m1);
+  *reinterpret_cast<uint2*>(p + 2 * PLANE2) = make_uint2(l0, l1);
+}
+
+__global__ __launch_bounds__(512, 2) void gemm_v4(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                  int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) char lds[4 * OPER2];
+  const int t = threadIdx.x, grp = t >> 8, tg = t & 255, lane = t & 63, w = tg >> 6, l31 = lane & 31, hf = lane >> 5;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int mt = M / BM, nt = N / BN, mp = (mt + 1) / 2;
+  const int chunk = (mp * nt + 7) / 8;
+  const int tile = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+  if (blockIdx.x / 8 >= chunk || tile >= mp * nt) return;
+  const int mtile = 2 * (tile / nt) + grp, n0 = (tile % nt) * BN;
+  const bool valid = mtile < mt;
+  const int m0 = (valid ? mtile : mt - 1) * BM;          // an unpaired last tile: group 1 shadows a valid tile and does not store
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // staging items of this thread: A_g rows (tg>>2) and (tg>>2)+64, k-quad tg&3; B half g: row 64*grp + (tg>>2), k-quad tg&3
+  const int srow = tg >> 2, kq = tg & 3;
+  float4 ra0, ra1, rb;
+  char* const LA = lds + (grp ? V4_A1 : V4_A0);
+  const int nk = K / 16;
+  auto loadA = [&](int k) { gload_rows(ra0, A, K, m0 + srow, 16 * k, kq); gload_rows(ra1, A, K, m0 + srow + 64, 16 * k, kq); };
+  auto loadB = [&](int k) { gload_rows(rb, B, K, n0 + 64 * grp + srow, 16 * k, kq); };
+  auto stageA = [&]() { stage_one(ra0, LA, srow, kq); stage_one(ra1, LA, srow + 64, kq); };
+  auto stageB = [&](int k) { stage_one(rb, lds + V4_B + (k & 1) * OPER2, 64 * grp + srow, kq); };
+  auto compute = [&](int k) {
+    const char* cb = lds + V4_B + (k & 1) * OPER2;
+    bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        fa[i][p] = *reinterpret_cast<const bf16x8*>(LA + p * PLANE2 + hf * BLK2 + (wm + 32 * i + l31) * 16);
+        fb[i][p] = *reinterpret_cast<const bf16x8*>(cb + p * PLANE2 + hf * BLK2 + (wn + 32 * i + l31) * 16);
+      }
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int q = 6 - TERMS; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][TA[q]], fb[j][TB[q]], acc[i][j], 0, 0, 0);
+  };
+  // prologue
+  if (grp == 0) { loadA(0); loadB(0); stageA(); stageB(0); }
+  else { loadB(0); stageB(0); loadA(0); if (nk > 1) loadB(1); }
+  __syncthreads();
+#if STAMP
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int k = 0; k < nk; ++k) {
+    // even phase: group 0 computes k, group 1 stages A1(k) and its half of B(k+1)
+    if (grp == 0) {
+      if (k + 1 < nk) { loadA(k + 1); loadB(k + 1); }
+      compute(k);
+    } else {
+      stageA();
+      if (k + 1 < nk) stageB(k + 1);
+    }
+    __syncthreads();
+    // odd phase: group 1 computes k, group 0 stages A0(k+1) and its half of B(k+1)
+    if (grp == 0) {
+      if (k + 1 < nk) { stageA(); stageB(k + 1); }
+    } else {
+      if (k + 1 < nk) { loadA(k + 1); if (k + 2 < nk) loadB(k + 2); }
+      compute(k);
+    }
+    __syncthreads();
+  }
+#if STAMP
+  if (t == 0 && blockIdx.x < 4096) {
+    g_stamp[4 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
+    g_stamp[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0;
+  }
+#endif
+  if (!valid) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf, col = n0 + wn + 32 * j + l31;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
 #ifndef KERNEL
 #define KERNEL gemm_bf16x6
 #endif
+#ifndef NTHREADS
+#define NTHREADS 256
+#endif
 #define STR2(x) #x
 #define STR(x) STR2(x)
-#define NAME STR(KERNEL) " pad=" STR(PAD2) " sched=" STR(SCHED) " order=" STR(ORDER) " abl=" STR(ABL)
+#define NAME STR(KERNEL) " pad=" STR(PAD2) " sched=" STR(SCHED) " order=" STR(ORDER) " abl=" STR(ABL) " prio=" STR(PRIO)
 int main(int argc, char** argv) {
   int M = argc > 1 ? atoi(argv[1]) : 25216, N = argc > 2 ? atoi(argv[2]) : 1536, K = argc > 3 ? atoi(argv[3]) : 384;
   std::vector<float> hA((size_t)M * K), hB((size_t)N * K);
@@ -360,12 +498,12 @@ int main(int argc, char** argv) {
   hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
   dim3 grid(((M / BM) * (N / BN) + 7) / 8 * 8);
-  for (int i = 0; i < 1500; ++i) hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);   // clock ramp
+  for (int i = 0; i < 1500; ++i) hipLaunchKernelGGL(KERNEL, grid, dim3(NTHREADS), 0, 0, dA, dB, dC, M, N, K);   // clock ramp
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int reps = 30;
   hipEventRecord(e0);
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, 0, dA, dB, dC, M, N, K);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(KERNEL, grid, dim3(NTHREADS), 0, 0, dA, dB, dC, M, N, K);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   std::vector<float> hC((size_t)M * N);
@@ -378,6 +516,17 @@ int main(int argc, char** argv) {
     worst = fmax(worst, fabs(hC[(size_t)i * N + j] - ref) / mag);
     worst32 = fmax(worst32, fabs((double)f32 - ref) / mag);
   }
+#if STAMP
+  {
+    std::vector<unsigned long long> st(4 * 4096);
+    hipMemcpyFromSymbol(st.data(), HIP_SYMBOL(g_stamp), st.size() * 8);
+    std::vector<double> cyc, clk;
+    const int nwg = (M / BM) * (N / BN) < 4096 ? (M / BM) * (N / BN) : 4096;
+    for (int i = 0; i < nwg; ++i) if (st[4 * i + 1]) { cyc.push_back((double)st[4 * i] / (K / 16)); clk.push_back((double)st[4 * i] / st[4 * i + 1] * 0.1); }
+    std::sort(cyc.begin(), cyc.end()); std::sort(clk.begin(), clk.end());
+    printf("   in-kernel: median %.0f cycles per k16-iteration per workgroup, clock %.2f GHz (median over %zu workgroups)\n", cyc[cyc.size() / 2], clk[clk.size() / 2], cyc.size());
+  }
+#endif
   printf("%s TERMS=%d M=%d N=%d K=%d: %.3f ms  %.1f TF (algorithmic)  max|err|/sum|ab| = %.2e (f32 fma chain: %.2e)\n", NAME, TERMS, M, N, K, ms,
          2.0 * M * N * K / ms / 1e9, worst, worst32);
   return 0;
