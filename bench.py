@@ -24,6 +24,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0                                                  
 # The GEMM computes every f32 product as six bf16 MFMA terms (exact 3-way operand split, f32 accumulate): the matrix pipe
 # executes 6 hardware flops per algorithmic flop, so the ceiling for ALGORITHMIC f32 flops is the bf16 peak / 6.
 GEMM_MFMA_TERMS = 6
+INIT_STEPS = 6
 PEAK_GEMM_TFLOPS = PEAK_BF16_MFMA_TFLOPS / GEMM_MFMA_TERMS
 PROF_TAGS = ['gemm_f32', 'attention_fwd', 'layernorm_fwd', 'layernorm_bwd', 'attention_bwd', 'norm_targets', 'adamw']
 
@@ -115,6 +116,11 @@ def main():
     def step():
         return engine.search_step(model, crit, imgs, labels, 1.0, (opt_p, opt_a, opt_d), reducer=reducer)
 
+    # one-time initialisation, not steady state: the first step loads the code objects and grows the caching allocator to its
+    # final 8 GiB, and the 5th step of a fresh process pays a single ~100 ms host-side stall (scripts/step_times.py shows it
+    # once in 60 steps).  These INIT_STEPS run before the W warm-up steps so that the timed region starts from a settled process.
+    for _ in range(INIT_STEPS):
+        step()
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -175,7 +181,7 @@ def main():
                vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload=f'{args.model} OFB search step + PMIM branch (configs[1]): bs {args.batch}/GPU, 224x224 synthetic '
                                     'images, fwd + OFBSearchLOSS + bwd + 3x AdamW, drop_path 0.1, w_p 0.99, keep ratio 0.95',
-                           global_batch=eff_bs, parallelism=f'dp{world}', step_tflops_per_gpu=round(step_tflops, 2),
+                           global_batch=eff_bs, parallelism=f'dp{world}', init_steps=INIT_STEPS, step_tflops_per_gpu=round(step_tflops, 2),
                            step_frac_of_f32_mfma_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)),
                roofline=roof)
     if world == 1 and not args.no_cpu_baseline:

@@ -12,14 +12,15 @@ m.correct_require_grad(0.5, 0.5, 0, 0.5); m.adjust_masking_ratio(0.0, 20, 100); 
 opts = engine.build_optimizers(m, 1e-4)
 crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, 0.5, 0.5, 0.0, 0.5, 5.0)
 imgs = torch.randn(B, 3, 224, 224, device=dev); labels = torch.randint(0, 1000, (B,), device=dev)
-for _ in range(3): engine.search_step(m, crit, imgs, labels, 1.0, opts)
+for _ in range(12): engine.search_step(m, crit, imgs, labels, 1.0, opts)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(5): engine.search_step(m, crit, imgs, labels, 1.0, opts)
-t1 = time.perf_counter()
-torch.cuda.synchronize()
-t2 = time.perf_counter()
-print(f'B={B}: host enqueue {1e3*(t1-t0)/5:.2f} ms/step, wall {1e3*(t2-t0)/5:.2f} ms/step')
+for rep in range(3):
+    t0 = time.perf_counter()
+    for _ in range(10): engine.search_step(m, crit, imgs, labels, 1.0, opts)
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    print(f'B={B}: host enqueue {1e3*(t1-t0)/10:.2f} ms/step, wall {1e3*(t2-t0)/10:.2f} ms/step')
 import cProfile, pstats
 pr = cProfile.Profile(); pr.enable()
 for _ in range(3): engine.search_step(m, crit, imgs, labels, 1.0, opts)
