@@ -497,6 +497,11 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
     // all K-iterations of this unit but the last: prefetch the next K-tile of the same unit
     for (int it = cur.it0; it + 1 < cur.it1; ++it) {
       gload(cur, it + 1);
+      // pin the prefetch ahead of the MFMA block: left alone, hipcc lets the loaded tile share VGPRs with the fragments and
+      // sinks the global loads behind the last MFMAs, exposing their whole latency in front of the LDS refill
+#ifndef LAB_NO_LOAD_PIN
+      __builtin_amdgcn_sched_barrier(0);
+#endif
       colsum_acc(buf);      // its LDS reads / adds are issued ahead of (and overlap) the MFMA block
       compute(buf);
       // keep every MFMA of this K-tile ahead of the vmcnt wait / LDS refill / barrier
@@ -509,6 +514,9 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
     const Seg nxt = get_seg<TAIL>(p, v, sidx + 1);
     const bool has_next = nxt.ok;
     if (has_next) gload(nxt, nxt.it0);
+#ifndef LAB_NO_LOAD_PIN
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     colsum_acc(buf);
     compute(buf);
     __builtin_amdgcn_sched_barrier(0);

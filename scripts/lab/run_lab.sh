@@ -1,5 +1,5 @@
 #!/bin/bash
-# Ablation lab for the f32 GEMM main loop (diagnostic only; builds throw-away variants under /tmp on the GPU box).
+# Ablation lab for the GEMM main loop (pass -D flags; do not use single-letter macro names: they collide with parameter names) (diagnostic only; builds throw-away variants under /tmp on the GPU box).
 cd "$(dirname "$0")/../.."
 SRC=once-for-both_amd/csrc
 i=0
