@@ -477,11 +477,238 @@ __global__ __launch_bounds__(512, 2) void gemm_v4(const float* __restrict__ A, c
       }
 }
 
+// ---- v5: ping-pong as v4 but each phase covers KS k-steps of 16 (longer MFMA bursts amortise the barrier + fragment-read head)
+#ifndef KS
+#define KS 2
+#endif
+constexpr int OPER5 = KS * OPER2;                                  // one operand tile of KS k-steps: [ks][plane][half][row][8]
+constexpr int V5_A0 = 0, V5_A1 = OPER5, V5_B = 2 * OPER5;          // LDS: A0 | A1 | B[2]
+
+__global__ __launch_bounds__(512, 2) void gemm_v5(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                  int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int t = threadIdx.x, grp = t >> 8, tg = t & 255, lane = t & 63, w = tg >> 6, l31 = lane & 31, hf = lane >> 5;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int mt = M / BM, nt = N / BN, mp = (mt + 1) / 2;
+  const int chunk = (mp * nt + 7) / 8;
+  const int tile = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+  if (blockIdx.x / 8 >= chunk || tile >= mp * nt) return;
+  const int mtile = 2 * (tile / nt) + grp, n0 = (tile % nt) * BN;
+  const bool valid = mtile < mt;
+  const int m0 = (valid ? mtile : mt - 1) * BM;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int srow = tg >> 2, kq = tg & 3;
+  float4 ra0[KS], ra1[KS], rb[KS];
+  char* const LA = lds + (grp ? V5_A1 : V5_A0);
+  const int nk = K / (16 * KS);                       // phases pairs
+  auto loadA = [&](int k) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { gload_rows(ra0[s], A, K, m0 + srow, 16 * (KS * k + s), kq); gload_rows(ra1[s], A, K, m0 + srow + 64, 16 * (KS * k + s), kq); }
+  };
+  auto loadB = [&](int k) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) gload_rows(rb[s], B, K, n0 + 64 * grp + srow, 16 * (KS * k + s), kq);
+  };
+  auto stageA = [&]() {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) { stage_one(ra0[s], LA + s * OPER2, srow, kq); stage_one(ra1[s], LA + s * OPER2, srow + 64, kq); }
+  };
+  auto stageB = [&](int k) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) stage_one(rb[s], lds + V5_B + (k & 1) * OPER5 + s * OPER2, 64 * grp + srow, kq);
+  };
+  auto compute = [&](int k) {
+#if PRIO
+    __builtin_amdgcn_s_setprio(PRIO);
+#endif
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const char* ca = LA + s * OPER2;
+      const char* cb = lds + V5_B + (k & 1) * OPER5 + s * OPER2;
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          fa[i][p] = *reinterpret_cast<const bf16x8*>(ca + p * PLANE2 + hf * BLK2 + (wm + 32 * i + l31) * 16);
+          fb[i][p] = *reinterpret_cast<const bf16x8*>(cb + p * PLANE2 + hf * BLK2 + (wn + 32 * i + l31) * 16);
+        }
+      constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+      for (int q = 6 - TERMS; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][TA[q]], fb[j][TB[q]], acc[i][j], 0, 0, 0);
+    }
+#if PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+  if (grp == 0) { loadA(0); loadB(0); stageA(); stageB(0); }
+  else { loadB(0); stageB(0); loadA(0); if (nk > 1) loadB(1); }
+  __syncthreads();
+#if STAMP
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  for (int k = 0; k < nk; ++k) {
+    if (grp == 0) {
+      if (k + 1 < nk) { loadA(k + 1); loadB(k + 1); }
+      compute(k);
+    } else {
+      stageA();
+      if (k + 1 < nk) stageB(k + 1);
+    }
+    __syncthreads();
+    if (grp == 0) {
+      if (k + 1 < nk) { stageA(); stageB(k + 1); }
+    } else {
+      if (k + 1 < nk) { loadA(k + 1); if (k + 2 < nk) loadB(k + 2); }
+      compute(k);
+    }
+    __syncthreads();
+  }
+#if STAMP
+  if (t == 0 && blockIdx.x < 4096) {
+    g_stamp[4 * blockIdx.x] = (__builtin_amdgcn_s_memtime() - c0) / KS;
+    g_stamp[4 * blockIdx.x + 1] = (__builtin_amdgcn_s_memrealtime() - r0) / KS;
+  }
+#endif
+  if (!valid) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf, col = n0 + wn + 32 * j + l31;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
+// ---- v6: dual-tile ping-pong.  Two independent 128x128 tiles per 512-thread workgroup (group g = tile g), every phase ends
+// in a workgroup barrier; group 0 computes in even phases and stages in odd ones, group 1 the other way round.  Single-
+// buffered LDS per group: a group stages tile-step k+1 right after it finished reading step k.
+constexpr int OPER6 = KS * OPER2;
+
+__global__ __launch_bounds__(512, 2) void gemm_v6(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ C,
+                                                  int M, int N, int K) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int t = threadIdx.x, grp = t >> 8, tg = t & 255, lane = t & 63, w = tg >> 6, l31 = lane & 31, hf = lane >> 5;
+  const int wm = (w >> 1) * 64, wn = (w & 1) * 64;
+  const int mt = M / BM, nt = N / BN, ntl = mt * nt, np = (ntl + 1) / 2;
+  const int chunk = (np + 7) / 8;
+  const int pair = (blockIdx.x % 8) * chunk + blockIdx.x / 8;
+  if (blockIdx.x / 8 >= chunk || pair >= np) return;
+  const int tile_raw = 2 * pair + grp;
+  const bool valid = tile_raw < ntl;
+  const int tile = valid ? tile_raw : ntl - 1;
+  const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int srow = tg >> 2, kq = tg & 3;
+  float4 ra0[KS], ra1[KS], rb0[KS], rb1[KS];
+  char* const LA = lds + grp * 2 * OPER6;
+  char* const LB = LA + OPER6;
+  const int nk = K / (16 * KS);
+  auto load = [&](int k) {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const int k0 = 16 * (KS * k + s);
+      gload_rows(ra0[s], A, K, m0 + srow, k0, kq); gload_rows(ra1[s], A, K, m0 + srow + 64, k0, kq);
+      gload_rows(rb0[s], B, K, n0 + srow, k0, kq); gload_rows(rb1[s], B, K, n0 + srow + 64, k0, kq);
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      stage_one(ra0[s], LA + s * OPER2, srow, kq); stage_one(ra1[s], LA + s * OPER2, srow + 64, kq);
+      stage_one(rb0[s], LB + s * OPER2, srow, kq); stage_one(rb1[s], LB + s * OPER2, srow + 64, kq);
+    }
+  };
+  auto compute = [&]() {
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+      const char* ca = LA + s * OPER2;
+      const char* cb = LB + s * OPER2;
+      bf16x8 fa[2][3], fb[2][3];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          fa[i][p] = *reinterpret_cast<const bf16x8*>(ca + p * PLANE2 + hf * BLK2 + (wm + 32 * i + l31) * 16);
+          fb[i][p] = *reinterpret_cast<const bf16x8*>(cb + p * PLANE2 + hf * BLK2 + (wn + 32 * i + l31) * 16);
+        }
+      constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+      for (int q = 6 - TERMS; q < 6; ++q)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][TA[q]], fb[j][TB[q]], acc[i][j], 0, 0, 0);
+    }
+  };
+  // prologue: both groups stage step 0; group 1 then waits one extra phase
+  load(0); stage();
+  if (nk > 1) load(1);
+  __syncthreads();
+#if STAMP
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  // phases p = 0 .. 2 nk: group 0 computes step p/2 in even phases and stages step p/2 + 1 in odd ones; group 1 computes step
+  // (p-1)/2 in odd phases and stages the next step in the following even phase.
+  for (int p = 0; p <= 2 * nk; ++p) {
+    const int ph = p - grp;                      // this group's own phase clock
+    if (ph >= 0 && ph < 2 * nk) {
+      const int k = ph >> 1;
+      if ((ph & 1) == 0) {
+        compute();
+      } else if (k + 1 < nk) {
+        stage();                                 // step k+1 (loaded during compute)
+        if (k + 2 < nk) load(k + 2);
+      }
+    }
+    __syncthreads();
+  }
+#if STAMP
+  if (t == 0 && blockIdx.x < 4096) {
+    g_stamp[4 * blockIdx.x] = (__builtin_amdgcn_s_memtime() - c0) / KS;
+    g_stamp[4 * blockIdx.x + 1] = (__builtin_amdgcn_s_memrealtime() - r0) / KS;
+  }
+#endif
+  if (!valid) return;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * hf, col = n0 + wn + 32 * j + l31;
+        C[(size_t)row * N + col] = acc[i][j][r];
+      }
+}
+
 #ifndef KERNEL
 #define KERNEL gemm_bf16x6
 #endif
 #ifndef NTHREADS
 #define NTHREADS 256
+#endif
+#ifndef DYN_LDS
+#define DYN_LDS 0
 #endif
 #define STR2(x) #x
 #define STR(x) STR2(x)
@@ -498,12 +725,13 @@ int main(int argc, char** argv) {
   hipMemcpy(dA, hA.data(), hA.size() * 4, hipMemcpyHostToDevice);
   hipMemcpy(dB, hB.data(), hB.size() * 4, hipMemcpyHostToDevice);
   dim3 grid(((M / BM) * (N / BN) + 7) / 8 * 8);
-  for (int i = 0; i < 1500; ++i) hipLaunchKernelGGL(KERNEL, grid, dim3(NTHREADS), 0, 0, dA, dB, dC, M, N, K);   // clock ramp
+  if (DYN_LDS) hipFuncSetAttribute((const void*)KERNEL, hipFuncAttributeMaxDynamicSharedMemorySize, DYN_LDS);
+  for (int i = 0; i < 1500; ++i) hipLaunchKernelGGL(KERNEL, grid, dim3(NTHREADS), DYN_LDS, 0, dA, dB, dC, M, N, K);   // clock ramp
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   const int reps = 30;
   hipEventRecord(e0);
-  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(KERNEL, grid, dim3(NTHREADS), 0, 0, dA, dB, dC, M, N, K);
+  for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(KERNEL, grid, dim3(NTHREADS), DYN_LDS, 0, dA, dB, dC, M, N, K);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1); ms /= reps;
   std::vector<float> hC((size_t)M * N);
