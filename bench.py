@@ -176,10 +176,11 @@ def main():
     step_tflops = value * GFLOP_PER_IMG[args.model] / 1e3 / world
     log(f'loss_total {loss_val:.4f}; step {ms_step:.2f} ms; whole-step {step_tflops:.1f} TFLOP/s/GPU '
         f'({step_tflops / PEAK_F32_MFMA_TFLOPS:.1%} of the f32 MFMA peak)')
+    cfg_tag = 'configs[1]' if (args.model, args.batch) == ('deit_small', 128) else ('configs[3]' if args.model == 'deit_base' else 'off-config size')
     res = dict(metric='images/sec OFB-search step, DeiT-S bs=128/GPU @1/2/4/8 MI355X', value=round(value, 2), unit='images/s', n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling='weak',
                vs_baseline=None, dtype='f32', data='synthetic',
-               config=dict(workload=f'{args.model} OFB search step + PMIM branch (configs[1]): bs {args.batch}/GPU, 224x224 synthetic '
+               config=dict(workload=f'{args.model} OFB search step + PMIM branch ({cfg_tag}): bs {args.batch}/GPU, 224x224 synthetic '
                                     'images, fwd + OFBSearchLOSS + bwd + 3x AdamW, drop_path 0.1, w_p 0.99, keep ratio 0.95',
                            global_batch=eff_bs, parallelism=f'dp{world}', init_steps=INIT_STEPS, step_tflops_per_gpu=round(step_tflops, 2),
                            step_frac_of_f32_mfma_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)),
