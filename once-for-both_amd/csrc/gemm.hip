@@ -567,48 +567,54 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
         // by memory latency, not bandwidth, and used to expose one round trip per 4 rows.
         // `side` carries the saved pre-activation for the dGELU form and the residual otherwise (a launch that wants both
         // reads its residual inside `finish`); the per-row scales of a 32-row band serve both of its column blocks.
-        f32x16 side[2], rsv[2];
         const bool dg = g.act == OFB_ACT_DGELU;
         const float* sp = dg ? g.aux : g.resid;
         const int lds_ = dg ? g.ldaux : g.ldr;
-        auto request = [&](auto Bk, f32x16& sd_) __attribute__((always_inline)) {
-          constexpr int bk = decltype(Bk)::value, mi = bk >> 1, ni = bk & 1;
-          const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            sd_[r] = sp ? sp[(size_t)row * lds_ + col] : 0.f;
-            if (ni == 0) rsv[mi][r] = g.rowscale ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
-          }
-        };
-        auto finish = [&](auto Bk, const f32x16& sd_) __attribute__((always_inline)) {
-          constexpr int bk = decltype(Bk)::value, mi = bk >> 1, ni = bk & 1;
-          const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rbase + (r & 3) + 8 * (r >> 2);
-            const float rvv = dg ? (g.resid ? g.resid[(size_t)row * g.ldr + col] : 0.f) : sd_[r];
-            g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][r], row, col, biasv[ni], csv[ni],
-                                                            rsv[mi][r], rvv, dg ? sd_[r] : 0.f);
-            acc[mi][ni][r] = 0.f;
-          }
-        };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-        request(I0{}, side[0]);
-        request(I1{}, side[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(I0{}, side[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        request(I2{}, side[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(I1{}, side[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        request(I3{}, side[1]);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(I2{}, side[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        finish(I3{}, side[1]);
+        if (!sp && !g.rowscale) {
+          // nothing to fetch (bias / gate / GELU forms): finish and stream out all 64 values, no staging, no waits
+          auto stream_out = [&](auto Bk) __attribute__((always_inline)) {
+            constexpr int bk = decltype(Bk)::value, mi = bk >> 1, ni = bk & 1;
+            const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = rbase + (r & 3) + 8 * (r >> 2);
+              g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][r], row, col, biasv[ni], csv[ni],
+                                                              1.f, 0.f, 0.f);
+              acc[mi][ni][r] = 0.f;
+            }
+          };
+          stream_out(I0{}); stream_out(I1{}); stream_out(I2{}); stream_out(I3{});
+        } else {
+          // all four blocks' side inputs are requested before the first is finished: one exposed round trip per tile
+          f32x16 side[4], rsv[2];
+          auto request = [&](auto Bk) __attribute__((always_inline)) {
+            constexpr int bk = decltype(Bk)::value, mi = bk >> 1, ni = bk & 1;
+            const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = rbase + (r & 3) + 8 * (r >> 2);
+              side[bk][r] = sp ? sp[(size_t)row * lds_ + col] : 0.f;
+              if (ni == 0) rsv[mi][r] = g.rowscale ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
+            }
+          };
+          auto finish = [&](auto Bk) __attribute__((always_inline)) {
+            constexpr int bk = decltype(Bk)::value, mi = bk >> 1, ni = bk & 1;
+            const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int row = rbase + (r & 3) + 8 * (r >> 2);
+              const float rvv = dg ? (g.resid ? g.resid[(size_t)row * g.ldr + col] : 0.f) : side[bk][r];
+              g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][r], row, col, biasv[ni], csv[ni],
+                                                              rsv[mi][r], rvv, dg ? side[bk][r] : 0.f);
+              acc[mi][ni][r] = 0.f;
+            }
+          };
+          request(I0{}); request(I1{}); request(I2{}); request(I3{});
+          __builtin_amdgcn_sched_barrier(0);
+          finish(I0{}); finish(I1{}); finish(I2{}); finish(I3{});
+        }
       } else {
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {

@@ -39,6 +39,10 @@ F1 = 2. * M * HID * D
 out = [
     ('NTplain', time(case(x, w1, yh, M, HID, D, D, D, HID, 1, 1), F1)),
     ('NTfc1', time(case(x, w1, yh, M, HID, D, D, D, HID, 1, 1, bias=b1, colscale=g1, act=hip.ACT_GELU, aux=hp, ldaux=HID), F1)),
+    ('NTfc1-noaux', time(case(x, w1, yh, M, HID, D, D, D, HID, 1, 1, bias=b1, colscale=g1, act=hip.ACT_GELU), F1)),
+    ('NTbias', time(case(x, w1, yh, M, HID, D, D, D, HID, 1, 1, bias=b1, colscale=g1), F1)),
+    ('NNplain', time(case(x, w2, yh, M, HID, D, D, HID, HID, 1, 0), F1)),
+    ('NNrs', time(case(x, w2, yh, M, HID, D, D, HID, HID, 1, 0, rowscale=rs), F1)),
     ('NTfc2', time(case(h, w2, y, M, D, HID, HID, HID, D, 1, 1, bias=bD, rowscale=rs, resid=x, ldr=D), F1)),
     ('NNdH', time(case(x, w2, yh, M, HID, D, D, HID, HID, 1, 0, rowscale=rs, act=hip.ACT_DGELU, aux=hp, ldaux=HID), F1)),
     ('NNdX', time(case(h, w1, y, M, D, HID, HID, D, D, 1, 0, resid=x, ldr=D), F1)),
