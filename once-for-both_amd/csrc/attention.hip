@@ -29,112 +29,214 @@ __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
 // ------------------------------------------------------------------------------------------------------------------
-// forward
+// forward: streaming (flash) form on the bf16 matrix pipe at fp32 accuracy
 // ------------------------------------------------------------------------------------------------------------------
+// Same exact three-way bf16 split and six product terms as the GEMM (csrc/gemm.hip), here on v_mfma_f32_16x16x32_bf16:
+// lane l gives A[i = l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][col = l&15] (j = 0..7, one 16-byte fragment);
+// D[i = 4*(l>>4) + r][col = l&15].  Wave w owns query tile w; keys stream through LDS in blocks of 32 (two 16-key tiles),
+// double-buffered, each K / V value split ONCE per workgroup while it is staged:
+//   K planes  [3][32 keys][64 d + 8]      : A operand of S^T = K Q^T (fragment = 8 consecutive d of one key)
+//   V^T planes [3][64 ch][32 slots + 8]   : A operand of O^T = V^T P^T; slot (g, j) holds key 4g + j (j < 4) or 16 + 4g + j - 4,
+//                                           the keys whose P^T values lane group g owns in its two S^T accumulators, so the
+//                                           probabilities feed the next MFMA from registers (split into planes on the way).
+// Online softmax over the key blocks (running max m, running sum l, O rescaled when m grows); lse = m + log l.
+typedef __bf16 att_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 att_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float att_f32x2 __attribute__((ext_vector_type(2)));
+
+#define AF_KB 32                       // keys per block
+#define AF_NB ((ATT_NMAX + AF_KB - 1) / AF_KB)      // 7 blocks cover 224 >= 208 keys
+#define AF_KPITCH 144                  // bytes per K row of one plane: 64 bf16 + 16 pad
+#define AF_KPLANE (AF_KB * AF_KPITCH)
+#define AF_VPITCH 80                   // bytes per V^T row of one plane: 32 bf16 + 16 pad
+#define AF_VPLANE (ATT_DMAX * AF_VPITCH)
+#define AF_STAGE (3 * AF_KPLANE + 3 * AF_VPLANE)
+
+__device__ __forceinline__ unsigned att_pack(float a, float b) {
+  att_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, att_bf16x2));
+}
+__device__ __forceinline__ void att_split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+  hi = att_pack(a, b);
+  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+  mid = att_pack(ra, rb);
+  lo = att_pack(ra - __uint_as_float(mid << 16), rb - __uint_as_float(mid & 0xffff0000u));
+}
+// 8 floats -> three 8 x bf16 fragments
+__device__ __forceinline__ void att_split8(const float (&x)[8], att_bf16x8 (&out)[3]) {
+  unsigned h[4], m[4], l[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) att_split_pair(x[2 * i], x[2 * i + 1], h[i], m[i], l[i]);
+  out[0] = __builtin_bit_cast(att_bf16x8, make_uint4(h[0], h[1], h[2], h[3]));
+  out[1] = __builtin_bit_cast(att_bf16x8, make_uint4(m[0], m[1], m[2], m[3]));
+  out[2] = __builtin_bit_cast(att_bf16x8, make_uint4(l[0], l[1], l[2], l[3]));
+}
+__device__ __forceinline__ f32x4 att_mfma6(const att_bf16x8 (&a)[3], const att_bf16x8 (&b)[3], f32x4 c) {
+  // (mid,mid) (hi,lo) (lo,hi) (hi,mid) (mid,hi) (hi,hi): smallest terms first
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                float* __restrict__ lse, int B, int N, int H, int dh, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Ks = smem;                            // [208][68]
-  float* Vs = smem + ATT_NMAX * ATT_LD;        // [208][68]
+  __shared__ __attribute__((aligned(16))) char smem[2 * AF_STAGE];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, head = blockIdx.x % H;
   const int ldq = 3 * H * dh, ldo = H * dh;
   const float* qbase = qkv + (size_t)b * N * ldq + head * dh;
   const float* kbase = qbase + H * dh;
   const float* vbase = qbase + 2 * H * dh;
+  const int nb = (N + AF_KB - 1) / AF_KB;
 
-  for (int idx = t; idx < ATT_NMAX * 16; idx += ATT_THREADS) {
-    const int row = idx >> 4, c4 = (idx & 15) << 2;
-    f32x4 kv = zero4(), vv = zero4();
-    if (row < N && c4 < dh) {
-      kv = *reinterpret_cast<const f32x4*>(kbase + (size_t)row * ldq + c4);
-      vv = *reinterpret_cast<const f32x4*>(vbase + (size_t)row * ldq + c4);
-    }
-    *reinterpret_cast<f32x4*>(&Ks[row * ATT_LD + c4]) = kv;
-    *reinterpret_cast<f32x4*>(&Vs[row * ATT_LD + c4]) = vv;
-  }
-  __syncthreads();
-  if (w * ATT_T >= N) return;
-
-  const int q = w * ATT_T + c;
-  // this lane's query row segment [16g, 16g+16), pre-scaled: B operand of S^T = K Q^T
-  float qr[16];
+  // staging items: idx < 512 -> K float4 (key = idx/16, d = 4*(idx%16)); 512 <= idx < 1024 -> V float4, same coordinates
+  f32x4 sreg[2];
+  auto stage_load = [&](int kb) {
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int cc = 16 * g + 4 * u;
-    f32x4 v = zero4();
-    if (q < N && cc < dh) v = *reinterpret_cast<const f32x4*>(qbase + (size_t)q * ldq + cc);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) qr[4 * u + j] = v[j] * scale;
-  }
-  // S^T tiles: rows = keys (A = K rows from LDS), cols = queries.  Two key tiles per pass = two independent MFMA chains.
-  f32x4 S[ATT_NT + 1];
-#pragma unroll
-  for (int kt = 0; kt < ATT_NT + 1; kt += 2) {
-    f32x4 a0 = zero4(), a1 = zero4();
-    const float* k0 = &Ks[(kt * ATT_T + c) * ATT_LD + 16 * g];
-    const float* k1 = &Ks[(min(kt + 1, ATT_NT - 1) * ATT_T + c) * ATT_LD + 16 * g];     // tile 13 does not exist: recompute 12
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const f32x4 x0 = *reinterpret_cast<const f32x4*>(k0 + 4 * u);
-      const f32x4 x1 = *reinterpret_cast<const f32x4*>(k1 + 4 * u);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        a0 = mfma16(x0[j], qr[4 * u + j], a0);
-        a1 = mfma16(x1[j], qr[4 * u + j], a1);
+    for (int i = 0; i < 2; ++i) {
+      const int idx = t + ATT_THREADS * i;
+      sreg[i] = zero4();
+      if (idx < 1024) {
+        const int key = kb * AF_KB + ((idx & 511) >> 4), d4 = (idx & 15) << 2;
+        if (key < N && d4 < dh) sreg[i] = *reinterpret_cast<const f32x4*>(((idx < 512) ? kbase : vbase) + (size_t)key * ldq + d4);
       }
     }
-    S[kt] = a0;
-    S[kt + 1] = a1;
+  };
+  auto stage_store = [&](int buf) {
+    char* st = smem + buf * AF_STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = t + ATT_THREADS * i;
+      if (idx >= 1024) continue;
+      const int kk = (idx & 511) >> 4, d4 = (idx & 15) << 2;
+      unsigned h0, m0, l0, h1, m1, l1;
+      att_split_pair(sreg[i][0], sreg[i][1], h0, m0, l0);
+      att_split_pair(sreg[i][2], sreg[i][3], h1, m1, l1);
+      if (idx < 512) {
+        char* p = st + kk * AF_KPITCH + d4 * 2;
+        *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(p + AF_KPLANE) = make_uint2(m0, m1);
+        *reinterpret_cast<uint2*>(p + 2 * AF_KPLANE) = make_uint2(l0, l1);
+      } else {
+        // V[key kk][d4 + e] -> V^T planes row (d4 + e), slot of key kk: tile = kk>>4, g' = (kk&15)>>2, r = kk&3 -> 8g' + 4*tile + r
+        const int slot = (((kk & 15) >> 2) << 3) + ((kk >> 4) << 2) + (kk & 3);
+        char* p = st + 3 * AF_KPLANE + d4 * AF_VPITCH + slot * 2;
+        const unsigned hs[2] = {h0, h1}, ms[2] = {m0, m1}, ls[2] = {l0, l1};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int sh = (e & 1) * 16;
+          unsigned short* q0 = reinterpret_cast<unsigned short*>(p + e * AF_VPITCH);
+          q0[0] = (unsigned short)(hs[e >> 1] >> sh);
+          *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(q0) + AF_VPLANE) = (unsigned short)(ms[e >> 1] >> sh);
+          *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(q0) + 2 * AF_VPLANE) = (unsigned short)(ls[e >> 1] >> sh);
+        }
+      }
+    }
+  };
+  stage_load(0);
+  stage_store(0);
+
+  // this lane's query row (pre-scaled), d-slices [8g, 8g+8) and [32 + 8g, 32 + 8g + 8), as B-operand planes
+  const int q = w * ATT_T + c;
+  att_bf16x8 qf[2][3];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    float x[8];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int d0 = 32 * ks + 8 * g + 4 * u;
+      f32x4 v = zero4();
+      if (q < N && d0 < dh) v = *reinterpret_cast<const f32x4*>(qbase + (size_t)q * ldq + d0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) x[4 * u + j] = v[j] * scale;
+    }
+    att_split8(x, qf[ks]);
   }
-  // row softmax over keys: this lane holds keys {kt*16 + 4g + r}; the other three kslot groups hold the rest
-  float m = -INFINITY;
-#pragma unroll
-  for (int kt = 0; kt < ATT_NT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float s = (kt * ATT_T + 4 * g + r < N) ? S[kt][r] : -INFINITY;
-      S[kt][r] = s;
-      m = fmaxf(m, s);
-    }
-  m = fmaxf(m, __shfl_xor(m, 16, 64));
-  m = fmaxf(m, __shfl_xor(m, 32, 64));
-  float l = 0.f;
-#pragma unroll
-  for (int kt = 0; kt < ATT_NT; ++kt)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float pv = __expf(S[kt][r] - m);
-      S[kt][r] = pv;
-      l += pv;
-    }
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  // O = P V: the P^T accumulators are the A operand (reduction over their row index = key); 4 independent chains
   f32x4 O[4];
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) O[dt] = zero4();
+  float m_run = -INFINITY, l_run = 0.f;
+  __syncthreads();
+
+  const bool active = w * ATT_T < N;
+  for (int kb = 0; kb < nb; ++kb) {
+    const char* st = smem + (kb & 1) * AF_STAGE;
+    if (kb + 1 < nb) stage_load(kb + 1);
+    if (active) {
+      // S^T tiles of this key block: rows = keys, lane column = query
+      f32x4 S[2];
 #pragma unroll
-  for (int kt = 0; kt < ATT_NT; ++kt)
+      for (int tk = 0; tk < 2; ++tk) {
+        f32x4 acc = zero4();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* vp = &Vs[(kt * ATT_T + 4 * g + r) * ATT_LD + c];
+        for (int ks = 0; ks < 2; ++ks) {
+          att_bf16x8 kf[3];
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) O[dt] = mfma16(S[kt][r], vp[16 * dt], O[dt]);
+          for (int pl = 0; pl < 3; ++pl)
+            kf[pl] = *reinterpret_cast<const att_bf16x8*>(st + pl * AF_KPLANE + (16 * tk + c) * AF_KPITCH + (32 * ks + 8 * g) * 2);
+          acc = att_mfma6(kf, qf[ks], acc);
+        }
+        S[tk] = acc;
+      }
+      // online softmax: this lane holds keys kb*32 + 16 tk + 4g + r of query c
+      float mb = -INFINITY;
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float sv = (kb * AF_KB + 16 * tk + 4 * g + r < N) ? S[tk][r] : -INFINITY;
+          S[tk][r] = sv;
+          mb = fmaxf(mb, sv);
+        }
+      mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
+      mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+      const float m_new = fmaxf(m_run, mb);                 // finite from block 0 on (key 0 is always valid)
+      const float alpha = __expf(m_run - m_new);
+      m_run = m_new;
+      float p8[8];
+      float ls = 0.f;
+#pragma unroll
+      for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __expf(S[tk][r] - m_new);
+          p8[4 * tk + r] = pv;                               // k-slot j = 4 tk + r of group g
+          ls += pv;
+        }
+      l_run = l_run * alpha + ls;
+      att_bf16x8 pf[3];
+      att_split8(p8, pf);
+      // O^T[ch][query] = alpha * O^T + V^T P^T
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+        att_bf16x8 vf[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+          vf[pl] = *reinterpret_cast<const att_bf16x8*>(st + 3 * AF_KPLANE + pl * AF_VPLANE + (16 * dt + c) * AF_VPITCH + g * 16);
+        O[dt] *= alpha;
+        O[dt] = att_mfma6(vf, pf, O[dt]);
+      }
     }
+    if (kb + 1 < nb) stage_store((kb + 1) & 1);
+    __syncthreads();
+  }
+  if (!active) return;
+  float l = l_run;
+  l += __shfl_xor(l, 16, 64);
+  l += __shfl_xor(l, 32, 64);
   const float linv = 1.0f / l;
-  if (g == 0 && q < N) lse[((size_t)b * H + head) * N + q] = m + logf(l);
-  // O[dt][r] = O[query 4g + r of the tile][channel 16 dt + c]
+  if (q < N) {
+    if (g == 0) lse[((size_t)b * H + head) * N + q] = m_run + logf(l);
+    // O[dt][r] = O^T[channel 16 dt + 4g + r][query c]: four consecutive channels of this lane's query
+    float* op = out + ((size_t)b * N + q) * ldo + head * dh;
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qrow = 4 * g + r;
-    const float li = __shfl(linv, qrow, 64);
-    const int qq = w * ATT_T + qrow;
-    if (qq < N) {
-      float* op = out + ((size_t)b * N + qq) * ldo + head * dh + c;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        if (16 * dt + c < dh) op[16 * dt] = O[dt][r] * li;
+    for (int dt = 0; dt < 4; ++dt) {
+      const int ch = 16 * dt + 4 * g;
+      if (ch < dh) *reinterpret_cast<f32x4*>(op + ch) = O[dt] * linv;
     }
   }
 }
@@ -316,7 +418,6 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
   }
 }
 
-constexpr size_t FWD_LDS = (size_t)(2 * ATT_NMAX * ATT_LD) * sizeof(float);
 constexpr size_t BWD_LDS =
     (size_t)(ATT_NMAX * ATT_LD + 4 * ATT_T * ATT_LD + ATT_T * ATT_DSLD + ATT_NT * ATT_T * ATT_DMAX + 2 * ATT_NMAX) * sizeof(float);
 
@@ -335,15 +436,10 @@ extern "C" int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32
   if (!qkv || !out || !lse) return OFB_EINVAL;
   if (int rc = check_shape(B, N, H, dh)) return rc;
   if (!ofb_aligned16(qkv)) return OFB_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)FWD_LDS) != hipSuccess)
-      return (int)hipGetLastError();
-    attr_set = true;
-  }
+  if (!ofb_aligned16(out) || ((H * dh) & 3)) return OFB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   ofb_prof_pre(1, s, 4.0 * B * H * (double)N * N * dh);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(ATT_THREADS), FWD_LDS, s, qkv, out, lse, B, N, H, dh, scale);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(ATT_THREADS), 0, s, qkv, out, lse, B, N, H, dh, scale);
   ofb_prof_post(1, s);
   return ofb_launch_status();
 }
