@@ -243,6 +243,46 @@ typedef struct ofb_ema_tensor { float* ema; const float* src; int64_t n; } ofb_e
 int ofb_ema_update(const ofb_ema_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float decay, float one_minus_decay,
                    void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Input side of the step.
+ * Mixup / CutMix (timm `Mixup` as called by engine.py:35-36,99-100; built at search.py:651-655, finetune.py:310):
+ * one parameter record per sample, so the 'batch', 'pair' and 'elem' modes share the kernels.  Sample b is mixed with
+ * the ORIGINAL sample B-1-b (x.flip(0)) in place:  x[b] = x[b]*lam + x[B-1-b]*one_minus_lam  (products and sum rounded
+ * separately, as torch's mul_/add_ do), or, for use_cutmix, x[b][:, yl:yh, xl:xh] = x[B-1-b][:, yl:yh, xl:xh].
+ * ofb_mixup_targets: out[b][c] = y1*lam + y2*one_minus_lam with y1/y2 the smoothed one-hot rows of labels[b] /
+ * labels[B-1-b] (on_value = 1 - smoothing + smoothing/C, off_value = smoothing/C; timm mixup_target).
+ * ofb_soft_cross_entropy: timm SoftTargetCrossEntropy (search.py:581-583, finetune.py:390-393):
+ * loss[0] = mean_b sum_c -target[b][c]*log_softmax(logits[b])[c]; grad = d loss / d logits; row_loss [B] scratch.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ofb_mix_param {
+  float lam, one_minus_lam;
+  int32_t use_cutmix;
+  int32_t yl, yh, xl, xh;
+} ofb_mix_param;
+int ofb_mixup_batch(float* x, const ofb_mix_param* params_dev, int32_t B, int32_t C, int32_t H, int32_t W, void* stream);
+int ofb_mixup_targets(const int64_t* labels, const ofb_mix_param* params_dev, float* out, int32_t B, int32_t num_classes,
+                      float on_value, float off_value, void* stream);
+int ofb_soft_cross_entropy(const float* logits, const float* target, float* row_loss, float* loss, float* grad, int32_t B,
+                           int32_t C, void* stream);
+
+/* RandomResizedCrop(+interpolation) -> RandomHorizontalFlip -> ToTensor -> Normalize of the reference's build_transform
+ * (datasets.py:127-163; eval: Resize + CenterCrop is the same call with a fixed box) on DECODED uint8 HWC RGB images that
+ * sit in one device buffer.  Per sample: byte offset and size of the source image, the crop box (top, left, height,
+ * width in source pixels), flip, filter (0 = bilinear, 1 = bicubic).  Resampling follows PIL's Image.resize(box=...)
+ * (separable, support stretched by the down-scale factor, 8-bit intermediate rounded half up), horizontal pass first.
+ * out: f32 [B][3][S][S] = ((v/255) - mean[c]) / std[c] (mean3/std3: HOST arrays of 3 floats); out_u8 (optional):
+ * the resized uint8 pixels in the same CHW layout.  scratch: ofb_crop_resize_scratch_bytes(B, S, max_src_h) bytes,
+ * max_src_h >= every sample's src_h. */
+typedef struct ofb_crop_param {
+  int64_t offset;
+  int32_t src_h, src_w;
+  int32_t top, left, height, width;
+  int32_t flip, cubic;
+} ofb_crop_param;
+int64_t ofb_crop_resize_scratch_bytes(int32_t B, int32_t out_size, int32_t max_src_h);
+int ofb_crop_resize_norm(const uint8_t* src, const ofb_crop_param* params_dev, int32_t B, int32_t out_size, int32_t max_src_h,
+                         const float* mean3, const float* std3, float* out, uint8_t* out_u8, uint8_t* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,355 @@
+"""Input side of the training step: sampler, GPU crop/resize/flip/normalize, Mixup/CutMix, soft targets.
+
+Mirrors what the reference takes from `samplers.py`, `datasets.build_transform` and the timm fork (`Mixup`,
+`SoftTargetCrossEntropy`, `RandomResizedCropAndInterpolation`); the arithmetic runs in csrc/data.hip.  Host code only draws
+the random parameters (same generators and draw order as the reference stack: `np.random` for Mixup, Python `random` for the
+crop) and uploads one small parameter table per batch.
+"""
+import math
+import random
+
+import numpy as np
+import torch
+
+from . import hip
+
+IMAGENET_DEFAULT_MEAN = (0.485, 0.456, 0.406)
+IMAGENET_DEFAULT_STD = (0.229, 0.224, 0.225)
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# samplers.py:8-59
+# -----------------------------------------------------------------------------------------------------------------
+class RASampler(torch.utils.data.Sampler):
+    """Repeated-augmentation sampler (reference samplers.py:8-59): epoch-seeded permutation, every index repeated 3x,
+    strided by rank, truncated to len // 256 * 256 / world samples.  Host-only index logic."""
+
+    def __init__(self, dataset, num_replicas=None, rank=None, shuffle=True):
+        import torch.distributed as dist
+        if num_replicas is None:
+            if not dist.is_available() or not dist.is_initialized():
+                raise RuntimeError('Requires distributed package to be available')
+            num_replicas = dist.get_world_size()
+        if rank is None:
+            if not dist.is_available() or not dist.is_initialized():
+                raise RuntimeError('Requires distributed package to be available')
+            rank = dist.get_rank()
+        self.dataset, self.num_replicas, self.rank, self.epoch = dataset, num_replicas, rank, 0
+        self.num_samples = int(math.ceil(len(self.dataset) * 3.0 / self.num_replicas))
+        self.total_size = self.num_samples * self.num_replicas
+        self.num_selected_samples = int(math.floor(len(self.dataset) // 256 * 256 / self.num_replicas))
+        self.shuffle = shuffle
+
+    def __iter__(self):
+        g = torch.Generator()
+        g.manual_seed(self.epoch)
+        n = len(self.dataset)
+        idx = torch.randperm(n, generator=g) if self.shuffle else torch.arange(n)
+        idx = torch.repeat_interleave(idx, 3)
+        if self.total_size > idx.numel():
+            idx = torch.cat([idx, idx[:self.total_size - idx.numel()]])
+        assert idx.numel() == self.total_size
+        idx = idx[self.rank:self.total_size:self.num_replicas]
+        assert idx.numel() == self.num_samples
+        return iter(idx[:self.num_selected_samples].tolist())
+
+    def __len__(self):
+        return self.num_selected_samples
+
+    def set_epoch(self, epoch):
+        self.epoch = epoch
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# timm Mixup (search.py:481-484, 651-655; finetune.py:310) on the resident batch
+# -----------------------------------------------------------------------------------------------------------------
+def rand_bbox(img_shape, lam, margin=0., count=None):
+    ratio = np.sqrt(1 - lam)
+    img_h, img_w = img_shape[-2:]
+    cut_h, cut_w = int(img_h * ratio), int(img_w * ratio)
+    margin_y, margin_x = int(margin * cut_h), int(margin * cut_w)
+    cy = np.random.randint(0 + margin_y, img_h - margin_y, size=count)
+    cx = np.random.randint(0 + margin_x, img_w - margin_x, size=count)
+    yl = np.clip(cy - cut_h // 2, 0, img_h)
+    yh = np.clip(cy + cut_h // 2, 0, img_h)
+    xl = np.clip(cx - cut_w // 2, 0, img_w)
+    xh = np.clip(cx + cut_w // 2, 0, img_w)
+    return yl, yh, xl, xh
+
+
+def rand_bbox_minmax(img_shape, minmax, count=None):
+    assert len(minmax) == 2
+    img_h, img_w = img_shape[-2:]
+    cut_h = np.random.randint(int(img_h * minmax[0]), int(img_h * minmax[1]), size=count)
+    cut_w = np.random.randint(int(img_w * minmax[0]), int(img_w * minmax[1]), size=count)
+    yl = np.random.randint(0, img_h - cut_h, size=count)
+    xl = np.random.randint(0, img_w - cut_w, size=count)
+    return yl, yl + cut_h, xl, xl + cut_w
+
+
+def cutmix_bbox_and_lam(img_shape, lam, ratio_minmax=None, correct_lam=True, count=None):
+    if ratio_minmax is not None:
+        yl, yu, xl, xu = rand_bbox_minmax(img_shape, ratio_minmax, count=count)
+    else:
+        yl, yu, xl, xu = rand_bbox(img_shape, lam, count=count)
+    if correct_lam or ratio_minmax is not None:
+        bbox_area = (yu - yl) * (xu - xl)
+        lam = 1. - bbox_area / float(img_shape[-2] * img_shape[-1])
+    return (yl, yu, xl, xu), lam
+
+
+class Mixup:
+    """timm `Mixup` call contract: `x, soft_target = mixup_fn(x, target)`; x (device, f32, NCHW) is mixed IN PLACE by one
+    kernel, the soft targets come from a second one.  Random draws follow timm's order on the global `np.random` state."""
+
+    def __init__(self, mixup_alpha=1., cutmix_alpha=0., cutmix_minmax=None, prob=1.0, switch_prob=0.5, mode='batch',
+                 correct_lam=True, label_smoothing=0.1, num_classes=1000):
+        self.mixup_alpha, self.cutmix_alpha, self.cutmix_minmax = mixup_alpha, cutmix_alpha, cutmix_minmax
+        if self.cutmix_minmax is not None:
+            assert len(self.cutmix_minmax) == 2
+            self.cutmix_alpha = 1.0
+        self.mix_prob, self.switch_prob = prob, switch_prob
+        self.label_smoothing, self.num_classes = label_smoothing, num_classes
+        self.mode, self.correct_lam, self.mixup_enabled = mode, correct_lam, True
+
+    def _params_per_elem(self, batch_size):
+        lam = np.ones(batch_size, dtype=np.float32)
+        use_cutmix = np.zeros(batch_size, dtype=bool)
+        if self.mixup_enabled:
+            if self.mixup_alpha > 0. and self.cutmix_alpha > 0.:
+                use_cutmix = np.random.rand(batch_size) < self.switch_prob
+                lam_mix = np.where(use_cutmix, np.random.beta(self.cutmix_alpha, self.cutmix_alpha, size=batch_size),
+                                   np.random.beta(self.mixup_alpha, self.mixup_alpha, size=batch_size))
+            elif self.mixup_alpha > 0.:
+                lam_mix = np.random.beta(self.mixup_alpha, self.mixup_alpha, size=batch_size)
+            elif self.cutmix_alpha > 0.:
+                use_cutmix = np.ones(batch_size, dtype=bool)
+                lam_mix = np.random.beta(self.cutmix_alpha, self.cutmix_alpha, size=batch_size)
+            else:
+                assert False, 'One of mixup_alpha > 0., cutmix_alpha > 0., cutmix_minmax not None should be true.'
+            lam = np.where(np.random.rand(batch_size) < self.mix_prob, lam_mix.astype(np.float32), lam)
+        return lam, use_cutmix
+
+    def _params_per_batch(self):
+        lam, use_cutmix = 1., False
+        if self.mixup_enabled and np.random.rand() < self.mix_prob:
+            if self.mixup_alpha > 0. and self.cutmix_alpha > 0.:
+                use_cutmix = np.random.rand() < self.switch_prob
+                lam_mix = np.random.beta(self.cutmix_alpha, self.cutmix_alpha) if use_cutmix else \
+                    np.random.beta(self.mixup_alpha, self.mixup_alpha)
+            elif self.mixup_alpha > 0.:
+                lam_mix = np.random.beta(self.mixup_alpha, self.mixup_alpha)
+            elif self.cutmix_alpha > 0.:
+                use_cutmix = True
+                lam_mix = np.random.beta(self.cutmix_alpha, self.cutmix_alpha)
+            else:
+                assert False, 'One of mixup_alpha > 0., cutmix_alpha > 0., cutmix_minmax not None should be true.'
+            lam = float(lam_mix)
+        return lam, use_cutmix
+
+    def plan(self, shape):
+        """Draws this batch's parameters: returns a list of per-sample records
+        (lam, use_cutmix, (yl, yh, xl, xh)); lam is the value that also weights the targets."""
+        B = shape[0]
+        box0 = (0, 0, 0, 0)
+        if self.mode == 'batch':
+            lam, use_cutmix = self._params_per_batch()
+            if lam == 1.:
+                return [(1.0, False, box0)] * B
+            if use_cutmix:
+                (yl, yh, xl, xh), lam = cutmix_bbox_and_lam(shape, lam, ratio_minmax=self.cutmix_minmax, correct_lam=self.correct_lam)
+                return [(float(lam), True, (int(yl), int(yh), int(xl), int(xh)))] * B
+            return [(float(lam), False, box0)] * B
+        n = B if self.mode == 'elem' else B // 2
+        lam_batch, use_cutmix = self._params_per_elem(n)
+        rec = []
+        for i in range(n):
+            lam = lam_batch[i]
+            if lam != 1. and use_cutmix[i]:
+                (yl, yh, xl, xh), lam = cutmix_bbox_and_lam(shape, lam, ratio_minmax=self.cutmix_minmax, correct_lam=self.correct_lam)
+                lam_batch[i] = lam
+                rec.append((float(lam_batch[i]), True, (int(yl), int(yh), int(xl), int(xh))))
+            else:
+                rec.append((float(lam), False, box0))
+        if self.mode == 'pair':
+            rec = rec + rec[::-1]
+        return rec
+
+    def __call__(self, x, target):
+        assert len(x) % 2 == 0, 'Batch size should be even when using this'
+        if self.mode not in ('batch', 'pair', 'elem'):
+            raise ValueError(self.mode)
+        if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 4:
+            raise hip.OfbError('Mixup expects a contiguous float32 NCHW device batch')
+        B, Cc, H, W = x.shape
+        rec = self.plan(x.shape)
+        tab = (hip.MixParam * B)()
+        for b, (lam, cm, (yl, yh, xl, xh)) in enumerate(rec):
+            t = tab[b]
+            t.lam, t.one_minus_lam, t.use_cutmix = lam, 1. - lam, int(cm)
+            t.yl, t.yh, t.xl, t.xh = yl, yh, xl, xh
+        dev_tab, host = hip.upload_structs(tab, x.device)
+        if any(r[0] != 1. for r in rec):
+            hip.mixup_batch(x, dev_tab, B, Cc, H, W)
+        off_value = self.label_smoothing / self.num_classes
+        on_value = 1. - self.label_smoothing + off_value
+        soft = torch.empty(B, self.num_classes, device=x.device, dtype=torch.float32)
+        hip.mixup_targets(target.contiguous(), dev_tab, soft, B, self.num_classes, on_value, off_value)
+        self._keep = (dev_tab, host)
+        return x, soft
+
+
+class _SoftCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target):
+        logits = logits if logits.is_contiguous() else logits.contiguous()
+        target = target if target.is_contiguous() else target.contiguous()
+        Bn, Cn = logits.shape
+        row = torch.empty(Bn, device=logits.device, dtype=torch.float32)
+        loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+        grad = torch.empty_like(logits)
+        hip.soft_cross_entropy(logits, target, row, loss, grad, Bn, Cn)
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        (grad,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        hip.scale_by_scalar(grad, up.contiguous().reshape(1), out, grad.numel())
+        return out, None
+
+
+class SoftTargetCrossEntropy(torch.nn.Module):
+    """timm SoftTargetCrossEntropy (search.py:581-583): mean_b sum_c -target * log_softmax(x); fused forward + gradient."""
+
+    def forward(self, x, target):
+        return _SoftCE.apply(x.float(), target.float())
+
+
+# -----------------------------------------------------------------------------------------------------------------
+# build_transform (datasets.py:127-163) on the GPU, from decoded uint8 HWC images
+# -----------------------------------------------------------------------------------------------------------------
+def random_resized_crop_params(height, width, scale=(0.08, 1.0), ratio=(3. / 4., 4. / 3.)):
+    """timm RandomResizedCropAndInterpolation.get_params (Python `random` draws): returns (top, left, h, w)."""
+    area = height * width
+    for _ in range(10):
+        target_area = random.uniform(*scale) * area
+        log_ratio = (math.log(ratio[0]), math.log(ratio[1]))
+        aspect_ratio = math.exp(random.uniform(*log_ratio))
+        w = int(round(math.sqrt(target_area * aspect_ratio)))
+        h = int(round(math.sqrt(target_area / aspect_ratio)))
+        if w <= width and h <= height:
+            i = random.randint(0, height - h)
+            j = random.randint(0, width - w)
+            return i, j, h, w
+    in_ratio = width / height
+    if in_ratio < min(ratio):
+        w = width
+        h = int(round(w / min(ratio)))
+    elif in_ratio > max(ratio):
+        h = height
+        w = int(round(h * max(ratio)))
+    else:
+        w, h = width, height
+    return (height - h) // 2, (width - w) // 2, h, w
+
+
+def center_crop_params(height, width, input_size=224):
+    """Resize(int(256/224*input_size)) + CenterCrop(input_size) (datasets.py:147-153) as ONE box in source pixels: the short
+    side maps to `size`, the crop takes input_size/size of it around the centre."""
+    size = int((256 / 224) * input_size)
+    short = min(height, width)
+    side = short * input_size / size
+    top, left = (height - side) / 2., (width - side) / 2.
+    return int(round(top)), int(round(left)), int(round(side)), int(round(side))
+
+
+class DeviceTransform:
+    """uint8 HWC images -> normalized f32 NCHW batch on the device in two launches (resample rows, resample columns + flip +
+    ToTensor + Normalize).  `images`: list of HxWx3 uint8 arrays / tensors (decoded elsewhere)."""
+
+    def __init__(self, input_size=224, is_train=True, interpolation='bicubic', hflip=0.5, scale=(0.08, 1.0),
+                 ratio=(3. / 4., 4. / 3.), mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD, device='cuda'):
+        self.S, self.is_train, self.cubic = input_size, is_train, int(interpolation == 'bicubic')
+        self.hflip, self.scale, self.ratio, self.mean, self.std = hflip, scale, ratio, tuple(mean), tuple(std)
+        self.device = torch.device(device)
+
+    def plan(self, sizes):
+        out = []
+        for (h, w) in sizes:
+            if self.is_train:
+                top, left, ch, cw = random_resized_crop_params(h, w, self.scale, self.ratio)
+                flip = int(random.random() < self.hflip)
+            else:
+                top, left, ch, cw = center_crop_params(h, w, self.S)
+                flip = 0
+            out.append((top, left, ch, cw, flip))
+        return out
+
+    def __call__(self, images, plan=None, want_u8=False):
+        imgs = [torch.from_numpy(np.array(im, copy=True)) if not torch.is_tensor(im) else im.contiguous() for im in images]
+        sizes = [(int(t.shape[0]), int(t.shape[1])) for t in imgs]
+        plan = self.plan(sizes) if plan is None else plan
+        B = len(imgs)
+        offs, total = [], 0
+        for t in imgs:
+            if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+                raise hip.OfbError('DeviceTransform expects HxWx3 uint8 images')
+            offs.append(total)
+            total += (t.numel() + 15) // 16 * 16
+        flat = torch.empty(total, dtype=torch.uint8).pin_memory()
+        for t, o in zip(imgs, offs):
+            flat[o:o + t.numel()] = t.reshape(-1)
+        src = flat.to(self.device, non_blocking=True)
+        tab = (hip.CropParam * B)()
+        for b, ((h, w), o, (top, left, ch, cw, flip)) in enumerate(zip(sizes, offs, plan)):
+            t = tab[b]
+            t.offset, t.src_h, t.src_w = o, h, w
+            t.top, t.left, t.height, t.width, t.flip, t.cubic = top, left, ch, cw, flip, self.cubic
+        dev_tab, host = hip.upload_structs(tab, self.device)
+        max_h = max(h for h, _ in sizes)
+        scratch = torch.empty(hip.crop_resize_scratch_bytes(B, self.S, max_h), device=self.device, dtype=torch.uint8)
+        out = torch.empty(B, 3, self.S, self.S, device=self.device, dtype=torch.float32)
+        out_u8 = torch.empty(B, 3, self.S, self.S, device=self.device, dtype=torch.uint8) if want_u8 else None
+        hip.crop_resize_norm(src, dev_tab, B, self.S, max_h, self.mean, self.std, out, out_u8, scratch)
+        self._keep = (dev_tab, host, flat, src, scratch)
+        return (out, out_u8) if want_u8 else out
+
+
+class DeviceLoader:
+    """Wraps an iterable of (list of uint8 images, int64 labels): the crop/resize of batch i+1 runs on a side stream while
+    the step of batch i computes (the reference overlaps the same work in DataLoader worker processes)."""
+
+    def __init__(self, batches, transform, mixup_fn=None):
+        self.batches, self.transform, self.mixup_fn = batches, transform, mixup_fn
+        self.stream = torch.cuda.Stream(device=transform.device)
+
+    def _prepare(self, item):
+        images, labels = item
+        with torch.cuda.stream(self.stream):
+            x = self.transform(images)
+            y = torch.as_tensor(labels, dtype=torch.int64).to(self.transform.device, non_blocking=True)
+            if self.mixup_fn is not None:
+                x, y = self.mixup_fn(x, y)
+        ev = torch.cuda.Event()
+        ev.record(self.stream)
+        return x, y, ev
+
+    def __iter__(self):
+        it = iter(self.batches)
+        nxt = None
+        for item in it:
+            cur, nxt = nxt, self._prepare(item)
+            if cur is not None:
+                yield self._hand_over(cur)
+        if nxt is not None:
+            yield self._hand_over(nxt)
+
+    @staticmethod
+    def _hand_over(prep):
+        x, y, ev = prep
+        torch.cuda.current_stream().wait_event(ev)
+        x.record_stream(torch.cuda.current_stream())
+        y.record_stream(torch.cuda.current_stream())
+        return x, y

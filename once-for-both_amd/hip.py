@@ -44,6 +44,7 @@ SYMBOLS = [
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets',
     'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
+    'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm',
 ]
 
 
@@ -327,3 +328,43 @@ def patch_mask(noise, mask, B, L, len_keep, masked_ids=None):
 
 def diag_mfma_peak(out, blocks, iters):
     check(lib().ofb_diag_mfma_peak(ptr(out), _i(blocks), _i(iters), stream()), 'ofb_diag_mfma_peak')
+
+
+class MixParam(C.Structure):
+    _fields_ = [('lam', C.c_float), ('one_minus_lam', C.c_float), ('use_cutmix', C.c_int32),
+                ('yl', C.c_int32), ('yh', C.c_int32), ('xl', C.c_int32), ('xh', C.c_int32)]
+
+
+class CropParam(C.Structure):
+    _fields_ = [('offset', C.c_int64), ('src_h', C.c_int32), ('src_w', C.c_int32), ('top', C.c_int32), ('left', C.c_int32),
+                ('height', C.c_int32), ('width', C.c_int32), ('flip', C.c_int32), ('cubic', C.c_int32)]
+
+
+def mixup_batch(x, params_dev, B, Cc, H, W):
+    check(lib().ofb_mixup_batch(ptr(_f32c(x, 'x')), ptr(params_dev), _i(B), _i(Cc), _i(H), _i(W), stream()), 'ofb_mixup_batch')
+
+
+def mixup_targets(labels, params_dev, out, B, ncls, on_value, off_value):
+    if labels.dtype != torch.int64 or not labels.is_contiguous():
+        raise OfbError('labels must be a contiguous int64 tensor')
+    check(lib().ofb_mixup_targets(ptr(labels), ptr(params_dev), ptr(out), _i(B), _i(ncls), _f(on_value), _f(off_value), stream()),
+          'ofb_mixup_targets')
+
+
+def soft_cross_entropy(logits, target, row_loss, loss, grad, B, Cn):
+    check(lib().ofb_soft_cross_entropy(ptr(_f32c(logits, 'logits')), ptr(_f32c(target, 'target')), ptr(row_loss), ptr(loss), ptr(grad),
+                                       _i(B), _i(Cn), stream()), 'ofb_soft_cross_entropy')
+
+
+def crop_resize_scratch_bytes(B, S, max_src_h):
+    f = lib().ofb_crop_resize_scratch_bytes
+    f.restype = C.c_int64
+    return int(f(_i(B), _i(S), _i(max_src_h)))
+
+
+def crop_resize_norm(src_u8, params_dev, B, S, max_src_h, mean, std, out, out_u8, scratch):
+    if src_u8.dtype != torch.uint8 or scratch.dtype != torch.uint8:
+        raise OfbError('source / scratch must be uint8 device tensors')
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    check(lib().ofb_crop_resize_norm(ptr(src_u8), ptr(params_dev), _i(B), _i(S), _i(max_src_h), m3, s3, ptr(out), ptr(out_u8), ptr(scratch),
+                                     stream()), 'ofb_crop_resize_norm')
