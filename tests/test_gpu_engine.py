@@ -70,3 +70,38 @@ def test_train_one_epoch_finetune_vit():
     assert last['loss'] < first['loss'], (first, last)
     ev = engine.evaluate(data[:2], m, dev)
     assert 0.0 <= ev['acc1'] <= ev['acc5'] <= 100.0 and ev['loss'] > 0
+
+
+def test_train_one_epoch_with_mixup_soft_targets():
+    """finetune.py's default recipe: Mixup(0.8, 1.0) + SoftTargetCrossEntropy (finetune.py:310,390-393) through the engine; the
+    first step's loss is checked against the CPU oracle's Mixup + soft-target CE on the same logits."""
+    import numpy as np
+    import ofb_amd
+    from ofb_amd import engine
+    from ofb_amd.optim import AdamW
+    from ofb_amd.losses import DistillationLoss
+    from oracle import data_oracle as DO
+    torch.manual_seed(0)
+    dev = torch.device('cuda')
+    m = ofb_amd.VisionTransformer(embed_dim=192, depth=2, num_heads=3, num_classes=5, drop_path_rate=0.0).to(dev)
+    torch.nn.init.normal_(m.head.weight, std=0.02)
+    data = _loader(1, 8, 5)
+    # oracle side: mix on the CPU, run the HIP model on the mixed batch, soft CE in fp64
+    np.random.seed(7)
+    xr, tr = DO.Mixup(0.8, 1.0, num_classes=5)(data[0][0].clone(), data[0][1])
+    m.eval()
+    with torch.no_grad():
+        ref = float(DO.soft_target_cross_entropy(m(xr.to(dev)).double().cpu(), tr.double()))
+    opt = AdamW(m.parameters(), None, lr=1e-3, weight_decay=0.05)
+    crit = DistillationLoss(ofb_amd.SoftTargetCrossEntropy(), None, 'none', 0.5, 1.0)
+    args = types.SimpleNamespace(accum_iter=1)
+    np.random.seed(7)
+    first = engine.train_one_epoch(m, crit, data, opt, _Sched(), dev, 0, mixup_fn=ofb_amd.Mixup(0.8, 1.0, num_classes=5), args=args,
+                                   set_training_mode=False)
+    assert abs(first['loss'] - ref) <= 1e-4 * abs(ref), (first, ref)          # north_star tolerance 1e-3; measured ~1e-6
+    np.random.seed(7)
+    fixed = [(data[0][0].clone(), data[0][1])] * 8
+    mix = ofb_amd.Mixup(0.8, 1.0, prob=0.0, num_classes=5)                     # lam = 1: pure label smoothing targets, a fixed objective
+    a = engine.train_one_epoch(m, crit, fixed[:1], opt, _Sched(), dev, 1, mixup_fn=mix, args=args, set_training_mode=False)
+    b = engine.train_one_epoch(m, crit, fixed, opt, _Sched(), dev, 2, mixup_fn=mix, args=args, set_training_mode=False)
+    assert b['loss'] < a['loss'], (a, b)
