@@ -61,6 +61,11 @@ def cpu_baseline(log):
 
 
 def main():
+    # stdout carries exactly ONE line (the JSON): library banners written to fd 1 (RCCL prints its version block there when
+    # the communicator comes up) are sent to stderr instead, and the JSON goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -82,7 +87,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or (args.force_dp and 'MASTER_ADDR' in os.environ):      # --force-dp under torchrun: a one-rank RCCL group
         dist.init_process_group('nccl', init_method='env://', device_id=dev)
 
     def log(*a):
@@ -106,7 +111,7 @@ def main():
     opt_p, opt_a, opt_d = engine.build_optimizers(model, lr)
     crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, attn_w=0.5, mlp_w=0.5,
                          patch_w=0.0, embedding_w=0.5, flops_w=5.0)
-    reducer = ofb_amd.dp.GradAllReducer(list(model.parameters())) if (world > 1 or args.force_dp) else None
+    reducer = ofb_amd.dp.GradAllReducer(list(model.parameters()), force_collective=args.force_dp) if (world > 1 or args.force_dp) else None
 
     torch.manual_seed(1234 + rank)                           # per-rank data / mask / DropPath streams (search.py:381)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -187,8 +192,9 @@ def main():
                roofline=roof)
     if world == 1 and not args.no_cpu_baseline:
         res['cpu_baseline'] = cpu_baseline(log)
-    print(json.dumps(res), flush=True)
-    if world > 1:
+    sys.stdout.flush()
+    os.write(real_stdout, (json.dumps(res) + '\n').encode())
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

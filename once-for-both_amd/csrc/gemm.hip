@@ -703,8 +703,24 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, 
   float sum[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) sum[j] = 0.f;
-  for (int v = v0; v <= v1; ++v) {
-    const float* ws = g.workspace + (size_t)slot_of(v) * (BM * BN) + (size_t)(FIX_ROWS * part + (t >> 7)) * BN + c;
+  // four contributors per trip: 4 * NJ independent loads in flight per thread (the sums stay in contributor order)
+  const size_t roff = (size_t)(FIX_ROWS * part + (t >> 7)) * BN + c;
+  int v = v0;
+  for (; v + 3 <= v1; v += 4) {
+    float x[4][NJ];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* ws = g.workspace + (size_t)slot_of(v + u) * (BM * BN) + roff;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) x[u][j] = ws[(size_t)(2 * j) * BN];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) sum[j] += x[u][j];
+  }
+  for (; v <= v1; ++v) {
+    const float* ws = g.workspace + (size_t)slot_of(v) * (BM * BN) + roff;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) sum[j] += ws[(size_t)(2 * j) * BN];
   }

@@ -12,8 +12,10 @@ import torch.distributed as dist
 
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None):
+    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, force_collective=False):
         self.group = process_group
+        # force_collective: issue the all-reduce even in a one-rank group (rehearses the RCCL path on a single GPU)
+        self.force_collective = bool(force_collective) and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in params if p.requires_grad]
         self.buckets, cur, size = [], [], 0
@@ -42,14 +44,14 @@ class GradAllReducer:
         """call after compress() replaced Parameters (fixes the reference's silent de-sync, SURVEY D-6)."""
         for h in self._handles:
             h.remove()
-        self.__init__(params, process_group=self.group)
+        self.__init__(params, process_group=self.group, force_collective=self.force_collective)
 
     def _launch(self, bi):
         ps = [p for p in self.buckets[bi] if p.grad is not None]
         if not ps:
             return
         flat = torch.cat([p.grad.reshape(-1) for p in ps])
-        if self.world > 1:
+        if self.world > 1 or self.force_collective:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             work = None
