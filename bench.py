@@ -60,6 +60,44 @@ def cpu_baseline(log):
                 sample=f'DeiT-S OFB search step (fwd+loss+bwd), bs {bs}, fp32, 1 warm-up + {n} timed steps of the oracle')
 
 
+
+# configs[4]: the released OFB-DeiT-C shapes are not available, so a subnet at the same budget (~1.7 GMAC, ~8 M
+# parameters) is synthesised by forcing every module's alpha onto one cell and letting compress() cut the search model.
+FT_EMBED = 264
+FT_BLOCKS = [(4, 48, 576), (4, 40, 768), (6, 32, 768), (4, 56, 960)] * 3          # (heads, head dim, mlp hidden) per block
+
+
+def build_finetune_subnet(ofb_amd, dev, ncls):
+    import torch
+    from ofb_amd import utils
+    search = ofb_amd.create_model('deit_small_patch16_224_mim', method='search', num_classes=ncls, drop_path_rate=0.1, attn_search=True,
+                                  mlp_search=True, embed_search=True, patch_search=False, mae=True, mask_ratio=1.0)
+    search.correct_require_grad(0.5, 0.5, 0, 0.5)
+    search.to(dev)
+
+    def force(mod, i, j):
+        a = torch.full_like(mod.alpha.data, -8.0)
+        a[i, j] = 0.0
+        mod.alpha.data.copy_(a)
+
+    pe = search.patch_embed
+    force(pe, 0, pe._chan_thr().index(FT_EMBED))
+    for blk, (h, dh, hid) in zip(search.blocks, FT_BLOCKS):
+        force(blk.attn, list(blk.attn.head_num_list).index(h), blk.attn._chan_thr().index(dh))
+        force(blk.mlp, 0, blk.mlp._chan_thr().index(hid))
+    finish, *_ = search.compress(1.0)
+    assert finish, 'forced alphas must finish the search in one compress()'
+    model = ofb_amd.create_model('deit_small_patch16_224_finetune', num_classes=ncls, drop_path_rate=0.1).to(dev)
+    utils.intersect(model, search)
+    n, d = 197, FT_EMBED
+    macs = 196 * 768 * d + d * ncls
+    for h, dh, hid in FT_BLOCKS:
+        hd = h * dh
+        macs += n * d * 3 * hd + 2 * n * n * hd + n * hd * d + 2 * n * d * hid
+    params = sum(p.numel() for p in model.parameters())
+    return model, macs, params
+
+
 def main():
     # stdout carries exactly ONE line (the JSON): library banners written to fd 1 (RCCL prints its version block there when
     # the communicator comes up) are sent to stderr instead, and the JSON goes to the saved descriptor at the end.
@@ -72,6 +110,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=128, help='images per GPU (BASELINE config: 128)')
     ap.add_argument('--model', default='deit_small', choices=list(GFLOP_PER_IMG))
+    ap.add_argument('--mode', default='search', choices=['search', 'finetune'],
+                    help="search: the BASELINE metric (default); finetune: configs[4], a pruned OFB-DeiT-C-like subnet (not a bench line)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip per-kernel HIP-event timing')
     ap.add_argument('--force-dp', action='store_true', help='exercise the DP bucket path even with one rank (debug)')
@@ -100,17 +140,36 @@ def main():
 
     torch.manual_seed(0)                                     # identical init on every rank (DDP would broadcast rank 0)
     ncls = 1000
-    model = ofb_amd.create_model(f'{args.model}_patch16_224_mim', method='search', num_classes=ncls, drop_path_rate=0.1,
-                                 attn_search=True, mlp_search=True, embed_search=True, patch_search=False, mae=True,
-                                 mask_ratio=1.0)
-    model.correct_require_grad(0.5, 0.5, 0, 0.5)
-    model.adjust_masking_ratio(0.0, 20, 100)                 # epoch-0 state: keep ratio 0.95, w_p 0.99
-    model.to(dev).train()
     eff_bs = args.batch * world
-    lr = 2.5e-4 * eff_bs / 256
-    opt_p, opt_a, opt_d = engine.build_optimizers(model, lr)
-    crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, attn_w=0.5, mlp_w=0.5,
-                         patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+    gflop_img = GFLOP_PER_IMG[args.model]
+    ft_info = None
+    if args.mode == 'search':
+        model = ofb_amd.create_model(f'{args.model}_patch16_224_mim', method='search', num_classes=ncls, drop_path_rate=0.1,
+                                     attn_search=True, mlp_search=True, embed_search=True, patch_search=False, mae=True,
+                                     mask_ratio=1.0)
+        model.correct_require_grad(0.5, 0.5, 0, 0.5)
+        model.adjust_masking_ratio(0.0, 20, 100)             # epoch-0 state: keep ratio 0.95, w_p 0.99
+        model.to(dev).train()
+        lr = 2.5e-4 * eff_bs / 256
+        opt_p, opt_a, opt_d = engine.build_optimizers(model, lr)
+        crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, attn_w=0.5, mlp_w=0.5,
+                             patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+    else:
+        # finetune.py's recipe on the pruned subnet: eval-mode semantics (finetune.py:445), Mixup(0.8, 1.0) + SoftTargetCrossEntropy
+        # (:310, :390-393), AdamW (lr 2.5e-4 * eff_bs / 512, wd 0.05), ModelEma every micro-step (:52, engine.py:62-63)
+        import numpy as np
+        from ofb_amd.optim import AdamW
+        from ofb_amd.utils import ModelEma
+        model, macs, nparams = build_finetune_subnet(ofb_amd, dev, ncls)
+        model.train(False)
+        gflop_img = 3 * 2 * macs / 1e9                       # forward + 2x backward, 2 flops per MAC
+        ft_info = dict(gmacs_per_img=round(macs / 1e9, 3), params_m=round(nparams / 1e6, 2), embed_dim=FT_EMBED,
+                       blocks_heads_headdim_hidden=FT_BLOCKS[:4], pattern_repeats=3)
+        opt_ft = AdamW(model.parameters(), None, lr=2.5e-4 * eff_bs / 512, weight_decay=0.05)
+        crit_ft = DistillationLoss(ofb_amd.SoftTargetCrossEntropy(), None, 'none', 0.5, 1.0)
+        mixup_fn = ofb_amd.Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=ncls)
+        ema = ModelEma(model, decay=0.99996)
+        np.random.seed(1234 + rank)
     reducer = ofb_amd.dp.GradAllReducer(list(model.parameters()), force_collective=args.force_dp) if (world > 1 or args.force_dp) else None
 
     torch.manual_seed(1234 + rank)                           # per-rank data / mask / DropPath streams (search.py:381)
@@ -118,8 +177,23 @@ def main():
     imgs = torch.randn(args.batch, 3, 224, 224, device=dev, generator=gen)
     labels = torch.randint(0, ncls, (args.batch,), device=dev, generator=gen)
 
-    def step():
-        return engine.search_step(model, crit, imgs, labels, 1.0, (opt_p, opt_a, opt_d), reducer=reducer)
+    if args.mode == 'search':
+        def step():
+            return engine.search_step(model, crit, imgs, labels, 1.0, (opt_p, opt_a, opt_d), reducer=reducer)
+    else:
+        def step():                                          # one micro-step of engine.train_one_epoch (engine.py:30-63)
+            x, soft = mixup_fn(imgs, labels)                 # in place on the resident batch (it stays a valid mixed batch)
+            loss = crit_ft(x, model(x), soft)
+            if reducer is not None:
+                reducer.prescaled = True
+                loss = loss * reducer.grad_scale
+            loss.backward()
+            if reducer is not None:
+                reducer.finalize()
+            opt_ft.step()
+            opt_ft.zero_grad(set_to_none=True)
+            ema.update(model)
+            return None, None, None, loss
 
     # one-time initialisation, not steady state: the first step loads the code objects and grows the caching allocator to its
     # final 8 GiB, and the 5th step of a fresh process pays a single ~100 ms host-side stall (scripts/step_times.py shows it
@@ -178,19 +252,27 @@ def main():
                         mfma_issued_tflops=round(ach * GEMM_MFMA_TERMS, 1),
                         launches_per_step=round(n / prof_steps, 1), avg_launch_us=round(ms / n * 1e3, 2),
                         share_of_step=round(ms / prof_steps / ms_step, 3), sampled_steps=prof_steps)
-    step_tflops = value * GFLOP_PER_IMG[args.model] / 1e3 / world
+    step_tflops = value * gflop_img / 1e3 / world
     log(f'loss_total {loss_val:.4f}; step {ms_step:.2f} ms; whole-step {step_tflops:.1f} TFLOP/s/GPU '
         f'({step_tflops / PEAK_F32_MFMA_TFLOPS:.1%} of the f32 MFMA peak)')
     cfg_tag = 'configs[1]' if (args.model, args.batch) == ('deit_small', 128) else ('configs[3]' if args.model == 'deit_base' else 'off-config size')
-    res = dict(metric='images/sec OFB-search step, DeiT-S bs=128/GPU @1/2/4/8 MI355X', value=round(value, 2), unit='images/s', n_gpus=world,
+    if args.mode == 'search':
+        metric = 'images/sec OFB-search step, DeiT-S bs=128/GPU @1/2/4/8 MI355X'
+        workload = (f'{args.model} OFB search step + PMIM branch ({cfg_tag}): bs {args.batch}/GPU, 224x224 synthetic images, fwd + '
+                    'OFBSearchLOSS + bwd + 3x AdamW, drop_path 0.1, w_p 0.99, keep ratio 0.95')
+    else:
+        metric = 'images/sec finetune step, pruned OFB-DeiT-C-like subnet (configs[4]; NOT the BASELINE metric)'
+        workload = (f'configs[4]: finetune micro-step of a synthesised ~1.7 GMAC subnet (search model cut by compress()), bs {args.batch}/GPU, '
+                    'Mixup/CutMix in place + SoftTargetCrossEntropy + bwd + AdamW + ModelEma, eval-mode semantics')
+    res = dict(metric=metric, value=round(value, 2), unit='images/s', n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling='weak',
                vs_baseline=None, dtype='f32', data='synthetic',
-               config=dict(workload=f'{args.model} OFB search step + PMIM branch ({cfg_tag}): bs {args.batch}/GPU, 224x224 synthetic '
-                                    'images, fwd + OFBSearchLOSS + bwd + 3x AdamW, drop_path 0.1, w_p 0.99, keep ratio 0.95',
-                           global_batch=eff_bs, parallelism=f'dp{world}', init_steps=INIT_STEPS, step_tflops_per_gpu=round(step_tflops, 2),
-                           step_frac_of_f32_mfma_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)),
+               config=dict(workload=workload, global_batch=eff_bs, parallelism=f'dp{world}', init_steps=INIT_STEPS,
+                           step_tflops_per_gpu=round(step_tflops, 2), step_frac_of_f32_mfma_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)),
                roofline=roof)
-    if world == 1 and not args.no_cpu_baseline:
+    if ft_info:
+        res['config']['subnet'] = ft_info
+    if world == 1 and not args.no_cpu_baseline and args.mode == 'search':
         res['cpu_baseline'] = cpu_baseline(log)
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(res) + '\n').encode())
