@@ -227,6 +227,23 @@ __host__ __device__ inline Plan make_plan(int M, int N, int K, int W) {
   return p;
 }
 
+
+// tile id -> (row block, column tile).  OFB_GEMM_PANEL = c > 0: the column tiles are walked in panels of c (row-major inside a
+// panel), so the workgroups that run side by side on one XCD share c weight slices instead of all nt of them.
+#ifndef OFB_GEMM_PANEL
+#define OFB_GEMM_PANEL 0
+#endif
+__host__ __device__ __forceinline__ void tile_coord(const Plan& p, int tile, int& m0, int& n0) {
+#if OFB_GEMM_PANEL > 0
+  const int per = p.mt * OFB_GEMM_PANEL;
+  const int panel = tile / per, within = tile - panel * per;
+  const int c = min(OFB_GEMM_PANEL, p.nt - panel * OFB_GEMM_PANEL);
+  m0 = (within / c) * BM; n0 = (panel * OFB_GEMM_PANEL + within % c) * BN;
+#else
+  m0 = (tile / p.nt) * BM; n0 = (tile % p.nt) * BN;
+#endif
+}
+
 // One unit of work: K-iterations [it0, it1) of output tile `tile`; slot < 0 -> full tile, fused epilogue to C;
 // slot >= 0 -> raw partial tile to workspace[slot].
 struct Seg { int m0, n0, it0, it1, slot; bool ok; };
@@ -239,7 +256,7 @@ __device__ __forceinline__ Seg get_seg(const Plan p, int v, int idx) {
     if (idx >= p.full_rounds) return s;
     const int tile = v + idx * p.W;
     if (tile >= p.ntiles) return s;
-    s.m0 = (tile / p.nt) * BM; s.n0 = (tile % p.nt) * BN; s.it0 = 0; s.it1 = p.I; s.ok = true;
+    tile_coord(p, tile, s.m0, s.n0); s.it0 = 0; s.it1 = p.I; s.ok = true;
     return s;
   }
   const int part = idx;
@@ -250,7 +267,7 @@ __device__ __forceinline__ Seg get_seg(const Plan p, int v, int idx) {
     const int i0 = sp * p.qs, i1 = min(i0 + p.qs, p.I);
     if (sp >= p.S || i0 >= i1) return s;
     const int tile = p.full_rounds * p.W + tl;
-    s.m0 = (tile / p.nt) * BM; s.n0 = (tile % p.nt) * BN; s.it0 = i0; s.it1 = i1; s.slot = v; s.ok = true;
+    tile_coord(p, tile, s.m0, s.n0); s.it0 = i0; s.it1 = i1; s.slot = v; s.ok = true;
     return s;
   }
   // R * I < W * I <= 768 * (K/16): fits 32 bits for every K the host accepts (checked in ofb_gemm_f32)
@@ -267,7 +284,7 @@ __device__ __forceinline__ Seg get_seg(const Plan p, int v, int idx) {
     tl = a + 1; i0 = 0; i1 = n0 - first;
   }
   const int tile = p.full_rounds * p.W + tl;
-  s.m0 = (tile / p.nt) * BM; s.n0 = (tile % p.nt) * BN; s.it0 = i0; s.it1 = i1; s.slot = 2 * v + part; s.ok = true;
+  tile_coord(p, tile, s.m0, s.n0); s.it0 = i0; s.it1 = i1; s.slot = 2 * v + part; s.ok = true;
   return s;
 }
 
@@ -692,7 +709,8 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
 __global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, const Plan p) {
   const int r = blockIdx.x, part = blockIdx.y, t = threadIdx.x;
   const int tile = p.full_rounds * p.W + r;
-  const int m0 = (tile / p.nt) * BM, n0 = (tile % p.nt) * BN;
+  int m0, n0;
+  tile_coord(p, tile, m0, n0);
   const int lo = r * p.I, hi = lo + p.I;         // this tile's run of flattened K-iterations
   // contributors: split-major -> pieces i = 0 .. n-1 in slots i*R + r; flattened -> workgroups v0 .. v1 (slot 2v+1 when the
   // workgroup's run started in the previous tile, else 2v)

@@ -3,7 +3,7 @@
 # each -D flag set in turn, runs bench.py, restores the default build at the end.  usage: ab_bench.sh "<flags A>" "<flags B>" ...
 cd "$(dirname "$0")/../.."
 SRC=once-for-both_amd/csrc
-OBJS="$SRC/build/rowops.o $SRC/build/attention.o $SRC/build/gate.o $SRC/build/misc.o $SRC/build/prof.o"
+OBJS=$(ls $SRC/build/*.o | grep -v "/gemm.o")
 cp $SRC/libofb_hip.so /tmp/libofb_hip.orig.so
 for rep in 1 2; do
 for v in "$@"; do
