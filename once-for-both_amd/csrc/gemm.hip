@@ -702,11 +702,13 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
 }
 
 // Sums the partial tiles of each streamed tail tile in workgroup order and applies the epilogue.
-// grid (R, 16): block (r, part) handles rows [8*part, 8*part+8) of tail tile r (weight gradients have only a few dozen
-// tail tiles, each with ~30 contributors: 16 blocks per tile keep every CU busy).
-#define FIX_PARTS 16
+// grid (R, 32), 128 threads: block (r, part) handles rows [4*part, 4*part+4) of tail tile r, one float4 (4 columns) per thread.
+// The kernel is bound by loads in flight, not bandwidth (weight gradients: a few dozen tail tiles with ~14-30 contributors
+// each): 16-byte loads, eight contributors per trip, 32 blocks per tile.  The sums stay in contributor order (deterministic).
+#define FIX_PARTS 32
 #define FIX_ROWS (BM / FIX_PARTS)
-__global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, const Plan p) {
+#define FIX_THREADS (FIX_ROWS * BN / 4)
+__global__ __launch_bounds__(FIX_THREADS) void gemm_fixup_kernel(const ofb_gemm_args g, const Plan p) {
   const int r = blockIdx.x, part = blockIdx.y, t = threadIdx.x;
   const int tile = p.full_rounds * p.W + r;
   int m0, n0;
@@ -716,47 +718,43 @@ __global__ __launch_bounds__(256) void gemm_fixup_kernel(const ofb_gemm_args g, 
   // workgroup's run started in the previous tile, else 2v)
   const int v0 = p.S ? 0 : lo / p.q, v1 = p.S ? (p.I + p.qs - 1) / p.qs - 1 : (hi - 1) / p.q;
   auto slot_of = [&](int v) { return p.S ? v * p.R + r : ((v * p.q < lo) ? 2 * v + 1 : 2 * v); };
-  const int c = t & 127, col = n0 + c;
-  constexpr int NJ = FIX_ROWS / 2;
-  float sum[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) sum[j] = 0.f;
-  // four contributors per trip: 4 * NJ independent loads in flight per thread (the sums stay in contributor order)
-  const size_t roff = (size_t)(FIX_ROWS * part + (t >> 7)) * BN + c;
+  const int lrow = FIX_ROWS * part + t / (BN / 4), c4 = (t % (BN / 4)) * 4;
+  const size_t roff = (size_t)lrow * BN + c4;
+  f32x4 sum = {0.f, 0.f, 0.f, 0.f};
   int v = v0;
-  for (; v + 3 <= v1; v += 4) {
-    float x[4][NJ];
+  for (; v + 7 <= v1; v += 8) {
+    f32x4 x[8];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float* ws = g.workspace + (size_t)slot_of(v + u) * (BM * BN) + roff;
+    for (int u = 0; u < 8; ++u) x[u] = *reinterpret_cast<const f32x4*>(g.workspace + (size_t)slot_of(v + u) * (BM * BN) + roff);
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) x[u][j] = ws[(size_t)(2 * j) * BN];
+    for (int u = 0; u < 8; ++u) sum += x[u];
+  }
+  for (; v <= v1; ++v) sum += *reinterpret_cast<const f32x4*>(g.workspace + (size_t)slot_of(v) * (BM * BN) + roff);
+  if (g.a_colsum && n0 == 0 && part < BM / FIX_THREADS) {
+    const int rr = part * FIX_THREADS + t;
+    if (m0 + rr < g.M) {
+      float bs = 0.f;
+      for (int u = v0; u <= v1; ++u) bs += g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)slot_of(u) * BM + rr];
+      g.a_colsum[m0 + rr] = bs;
     }
-#pragma unroll
-    for (int u = 0; u < 4; ++u)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j) sum[j] += x[u][j];
   }
-  for (; v <= v1; ++v) {
-    const float* ws = g.workspace + (size_t)slot_of(v) * (BM * BN) + roff;
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) sum[j] += ws[(size_t)(2 * j) * BN];
+  const int row = m0 + lrow, col0 = n0 + c4;
+  if (row >= g.M || col0 >= g.N) return;
+  const float rsv = g.rowscale ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
+  const bool full4 = col0 + 3 < g.N;
+  if (full4 && !g.bias && !g.colscale && !g.resid && g.act == OFB_ACT_NONE && !g.rowscale && g.alpha == 1.0f && (g.ldc & 3) == 0 &&
+      ((reinterpret_cast<uintptr_t>(g.C) & 15) == 0)) {
+    *reinterpret_cast<f32x4*>(g.C + (size_t)row * g.ldc + col0) = sum;       // plain weight gradient: one 16-byte store
+    return;
   }
-  if (g.a_colsum && n0 == 0 && part == 0 && t < BM && m0 + t < g.M) {
-    float bs = 0.f;
-    for (int v = v0; v <= v1; ++v) bs += g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)slot_of(v) * BM + t];
-    g.a_colsum[m0 + t] = bs;
-  }
-  if (col >= g.N) return;
-  const float bias = g.bias ? g.bias[col] : 0.f, cs = g.colscale ? g.colscale[col] : 1.f;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int row = m0 + FIX_ROWS * part + (t >> 7) + 2 * j;
-    if (row >= g.M) continue;
+  for (int k = 0; k < 4; ++k) {
+    const int col = col0 + k;
+    if (col >= g.N) break;
+    const float bias = g.bias ? g.bias[col] : 0.f, cs = g.colscale ? g.colscale[col] : 1.f;
     const float rv = g.resid ? g.resid[(size_t)row * g.ldr + col] : 0.f;
     const float av = (g.act == OFB_ACT_DGELU) ? g.aux[(size_t)row * g.ldaux + col] : 0.f;
-    const float rsv = g.rowscale ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
-    g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, sum[j], row, col, bias, cs, rsv, rv, av);
+    g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, sum[k], row, col, bias, cs, rsv, rv, av);
   }
 }
 
@@ -869,7 +867,7 @@ extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream) {
   else if (g.a_kc) rc = launch<true, false>(g, p, vec, s);
   else rc = launch<false, false>(g, p, vec, s);
   if (rc == 0 && p.R) {
-    hipLaunchKernelGGL(gemm_fixup_kernel, dim3(p.R, FIX_PARTS), dim3(256), 0, s, g, p);
+    hipLaunchKernelGGL(gemm_fixup_kernel, dim3(p.R, FIX_PARTS), dim3(FIX_THREADS), 0, s, g, p);
     rc = ofb_launch_status();
   }
   ofb_prof_post(0, s);
