@@ -1,63 +1,66 @@
-// f32 GEMM with fused epilogues.  Block tile 128x128x16, 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles (64 accumulator
-// VGPRs).  Two matrix engines share everything but the LDS image and the inner product (OFB_GEMM_BF16X6):
+// f32 GEMM with fused epilogues on the bf16 matrix pipe at fp32 accuracy.
 //
-//  1 (default)  f32 operands are split EXACTLY into three bf16 values (x = hi + mid + lo, round-to-nearest residual chain)
-//               while they are staged to LDS, and every K-step issues the six leading product terms (mid*mid, hi*lo, lo*hi,
-//               hi*mid, mid*hi, hi*hi; the dropped ones are <= 2^-24 relative) on v_mfma_f32_32x32x16_bf16 with f32
-//               accumulation.  Measured error equals that of an f32 fma chain (1.3e-7 of sum|a*b| at K = 384..1536); the
-//               bf16 matrix pipe has 16x the f32-MFMA rate, so six terms still run ~1.6x faster than the f32 MFMA form.
-//               LDS image per operand tile: 3 planes x 2 k-halves x [128 rows][8 bf16] (fragment = one ds_read_b128).
-//  0            v_mfma_f32_32x32x2_f32 on f32 tiles staged [mn][k] (row pitch 20 floats): bit-exact f32 fma chains.
+// f32 operands are split EXACTLY into three bf16 values (x = hi + mid + lo, round-to-nearest residual chain) while they are
+// staged to LDS, and every K-step issues the six leading product terms (mid*mid, hi*lo, lo*hi, hi*mid, mid*hi, hi*hi; the
+// dropped ones are <= 2^-24 relative) on v_mfma_f32_32x32x16_bf16 with f32 accumulation.  Measured error equals that of an f32
+// fma chain (1.3e-7 of sum|a*b| at K = 384..1536).  LDS image per operand tile: 3 planes x 2 k-halves x [rows][8 bf16]
+// (fragment = one ds_read_b128).
 //
-// Operands go global -> registers -> LDS with a one-tile prefetch; K-contiguous operands are written row-wise,
-// MN-contiguous ones are transposed on the way in, so the three storage combinations the Linear layers need
-// (x@W^T, dY@W, dY^T@X) share one inner loop.
+// Operands go global -> registers -> LDS with a one-tile prefetch; K-contiguous operands are written row-wise, MN-contiguous
+// ones are transposed on the way in, so the three storage combinations the Linear layers need (x@W^T, dY@W, dY^T@X) share one
+// inner loop.
 //
-// Scheduling (hybrid stream-K): W = CUs x 3 persistent workgroups.  Output tiles that fill whole rounds of W are
-// computed data-parallel with the epilogue fused; the R = tiles mod W remaining tiles are cut along K into W equal
-// runs of K-iterations (a run touches at most two tiles), written as raw partial tiles to a workspace and summed
-// by a small fix-up kernel that applies the same epilogue.  Every workgroup therefore issues the same number of
-// MFMAs (within one K-iteration) whatever the tile count, and weight gradients (few tiles, long K = all tokens) need
-// no separate split-K path.  Partials are summed in a fixed order: results are run-to-run deterministic.
+// Two tile configurations of the same kernel (template parameter TC):
+//   T128: 128x128x16 block tile, 4 waves (2x2), wave tile 64x64 (64 accumulator VGPRs), two workgroups per CU;
+//   T256: 256x256x16 block tile, 8 waves (2x4), wave tile 128x64 (128 accumulator VGPRs), one workgroup per CU.
+// The inner loop is bound by VALU ISSUE, not by the matrix pipe: per wave and K-step T128 carries ~100 VALU (73 of them the
+// split, the rest addressing) + 12 ds_read_b128 + 6 ds_write2 + 4 global loads beside 24 MFMAs (768 matrix-pipe cycles against
+// ~700 issue cycles of everything else, two waves per SIMD).  T256 stages the same 16 values per thread and K-step but feeds 48
+// MFMAs with them, which lifts the main loop from ~160 to ~220 TFLOP/s (lab: scripts/lab/gemm_w_lab.hip); it is used where its
+// 256-wide tiles fit the shape (ofb_gemm_f32: choose_tile).
+//
+// Scheduling (hybrid stream-K): W persistent workgroups (CUs x workgroups per CU).  Output tiles that fill whole rounds of W
+// are computed data-parallel with the epilogue fused; the R = tiles mod W remaining tiles are cut along K into W equal runs of
+// K-iterations (a run touches at most two tiles), written as raw partial tiles to a workspace and summed by a small fix-up
+// kernel that applies the same epilogue.  Every workgroup therefore issues the same number of MFMAs (within one K-iteration)
+// whatever the tile count, and weight gradients (few tiles, long K = all tokens) need no separate split-K path.  Partials are
+// summed in a fixed order: results are run-to-run deterministic.
 #include "ofb_common.h"
 #include <type_traits>
 
-#define BM 128
-#define BN 128
-#ifndef BK
 #define BK 16
-#endif
-#define LDP (BK + 4)   // LDS row pitch in floats ([mn][k] layout): 80-B / 144-B rows keep b128 fragment reads conflict-free
-#define NLD (BM * BK / 4 / 256)   // float4 loads per thread and operand tile
-#ifndef GEMM_WAVES_PER_SIMD
-#define GEMM_WAVES_PER_SIMD 2
-#endif
-#ifndef OFB_GEMM_BF16X6
-#define OFB_GEMM_BF16X6 1
-#endif
-#if OFB_GEMM_BF16X6
-static_assert(BK == 16, "the bf16x6 engine stages one 32x32x16 MFMA K-step per tile");
-#define SPL_BLK (BM * 16 + 16)       // bytes of one [128 rows][8 bf16] block (+16: the two k-halves land on different banks)
-#define SPL_PLANE (2 * SPL_BLK)      // k-halves
-#define SPL_OPER (3 * SPL_PLANE)     // hi / mid / lo planes
-#define LDS_OPER_FLOATS (SPL_OPER / 4)
-#else
-#define LDS_OPER_FLOATS (BM * LDP)
-#endif
 
 namespace {
 
-struct TileRegs { f32x4 v[NLD]; };
+template <int BM_, int BN_, int WM_, int WN_, int WG_PER_CU_>
+struct Tile {
+  static constexpr int BM = BM_, BN = BN_, WM = WM_, WN = WN_, WG_PER_CU = WG_PER_CU_;
+  static constexpr int NT = 64 * WM * WN;                       // threads
+  static constexpr int MI = BM / (32 * WM), NI = BN / (32 * WN);  // 32x32 blocks per wave
+  static constexpr int WPS = WG_PER_CU * WM * WN / 4;           // waves per SIMD (launch bound)
+  static constexpr int BLK_A = BM * 16 + 16, PLANE_A = 2 * BLK_A, OPER_A = 3 * PLANE_A;   // +16: the k-halves land on different banks
+  static constexpr int BLK_B = BN * 16 + 16, PLANE_B = 2 * BLK_B, OPER_B = 3 * PLANE_B;
+  static constexpr int LDS_BYTES = 2 * (OPER_A + OPER_B);
+  static_assert(BM * BK / 4 == 2 * NT && BN * BK / 4 == 2 * NT, "the loaders stage exactly two float4 per thread and operand");
+};
+using T128 = Tile<128, 128, 2, 2, 2>;
+using T256 = Tile<256, 256, 2, 4, 1>;
 
-// K-contiguous storage X[o*ld + k]: 512 float4 per tile, 2 per thread (o = idx>>2, kq = idx&3) -> one ds_write_b128 each.
-template <bool VEC, bool GUARD>
+struct TileRegs { f32x4 v[2]; };
+
+// K-contiguous storage X[o*ld + k]: 2 float4 per thread (o = idx>>2, kq = idx&3).
+template <int NT, bool VEC, bool GUARD>
 __device__ __forceinline__ void load_kc(TileRegs& r, const float* __restrict__ X, int ld, int o0, int O, int k0, int kend,
                                         int t) {
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = t + 256 * i, o = o0 + idx / (BK / 4), k = k0 + ((idx % (BK / 4)) << 2);
-    if (!GUARD) {      // full tiles only (M, N multiples of 128, K multiple of BK): no bounds checks at all
-      r.v[i] = *reinterpret_cast<const f32x4*>(X + (size_t)o * ld + k);
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + NT * i, o = o0 + idx / (BK / 4), k = k0 + ((idx % (BK / 4)) << 2);
+    if (!GUARD) {      // full tiles only (M, N multiples of the tile, K multiple of BK): no bounds checks at all
+      // wave-uniform base (SGPR pair, advanced per K-step by scalar adds) + a 32-bit per-thread byte offset that is constant
+      // for the whole launch: global_load ... v_off, s[base] - no vector address arithmetic in the K loop
+      const char* ub = reinterpret_cast<const char*>(X + (size_t)o0 * ld + k0);
+      const unsigned voff = (unsigned)((idx / (BK / 4)) * ld + ((idx % (BK / 4)) << 2)) * 4u;
+      r.v[i] = *reinterpret_cast<const f32x4*>(ub + voff);
       continue;
     }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -74,7 +77,6 @@ __device__ __forceinline__ void load_kc(TileRegs& r, const float* __restrict__ X
     r.v[i] = v;
   }
 }
-#if OFB_GEMM_BF16X6
 typedef __bf16 ofb_bf16x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 ofb_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float ofb_f32x2 __attribute__((ext_vector_type(2)));
@@ -90,44 +92,39 @@ __device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsig
   mid = pack_bf16(ra, rb);
   lo = pack_bf16(ra - __uint_as_float(mid << 16), rb - __uint_as_float(mid & 0xffff0000u));
 }
+// (tried: the residual of a packed half in ONE instruction, v_dot2_f32_bf16(pair, (-1, 0) | (0, -1), x) - exact, 7 instead of 9
+// VALU per pair.  Through __builtin_amdgcn_fdot2_f32_bf16 hipcc selects the destructive v_dot2c form and adds a copy per value, so
+// the count does not drop; as inline asm the compiler no longer sees that a DOT result may not be read by another VALU instruction
+// for 3 wait states (the hardware does not interlock it: garbage).  scripts/lab/dot2_check.hip)
 // K-contiguous tile: thread item (row = idx/4, k = 4*(idx%4) .. +3) -> 4 bf16 (8 B) per plane at [k>>3][row][k&7]
-__device__ __forceinline__ void store_kc(const TileRegs& r, float* __restrict__ S, int t) {
-  char* base = reinterpret_cast<char*>(S);
+template <int NT, int BLK, int PLANE>
+__device__ __forceinline__ void store_kc(const TileRegs& r, char* __restrict__ base, int t) {
 #pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = t + 256 * i, row = idx >> 2, kq = idx & 3;
+  for (int i = 0; i < 2; ++i) {
+    const int idx = t + NT * i, row = idx >> 2, kq = idx & 3;
     unsigned h0, m0, l0, h1, m1, l1;
     split_pair(r.v[i][0], r.v[i][1], h0, m0, l0);
     split_pair(r.v[i][2], r.v[i][3], h1, m1, l1);
-    char* p = base + (kq >> 1) * SPL_BLK + row * 16 + (kq & 1) * 8;
+    char* p = base + (kq >> 1) * BLK + row * 16 + (kq & 1) * 8;
     *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(p + SPL_PLANE) = make_uint2(m0, m1);
-    *reinterpret_cast<uint2*>(p + 2 * SPL_PLANE) = make_uint2(l0, l1);
+    *reinterpret_cast<uint2*>(p + PLANE) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(p + 2 * PLANE) = make_uint2(l0, l1);
   }
 }
-#else
-__device__ __forceinline__ void store_kc(const TileRegs& r, float* __restrict__ S, int t) {
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = t + 256 * i;
-    *reinterpret_cast<f32x4*>(&S[(idx / (BK / 4)) * LDP + ((idx % (BK / 4)) << 2)]) = r.v[i];
-  }
-}
-#endif
-#if OFB_GEMM_BF16X6
 // MN-contiguous storage X[k*ld + o]: thread t takes rows o = 4*(t/8) .. +3 at the k PAIR (2*(t%8), 2*(t%8)+1): v[0] = even k,
 // v[1] = odd k, so that each output row's two values pack into one bf16x2 LDS word per plane (the transpose costs
-// 12 ds_write_b32 per thread and tile instead of 24 ds_write_b16).
+// 12 ds_write_b32 per thread and tile instead of 24 ds_write_b16).  NT threads cover NT/2 rows.
 template <bool VEC, bool GUARD>
 __device__ __forceinline__ void load_mc(TileRegs& r, const float* __restrict__ X, int ld, int o0, int O, int k0, int kend,
                                         int t, const float* __restrict__ kscale, int ks_div) {
-  static_assert(NLD == 2, "pair loader assumes 2 float4 per thread");
   const int o = o0 + ((t >> 3) << 2);
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int k = k0 + 2 * (t & 7) + i;
     if (!GUARD) {
-      f32x4 u = *reinterpret_cast<const f32x4*>(X + (size_t)k * ld + o);
+      const char* ub = reinterpret_cast<const char*>(X + (size_t)k0 * ld + o0);
+      const unsigned voff = (unsigned)((2 * (t & 7) + i) * ld + ((t >> 3) << 2)) * 4u;
+      f32x4 u = *reinterpret_cast<const f32x4*>(ub + voff);
       if (kscale) u *= kscale[ks_div == 1 ? k : k / ks_div];
       r.v[i] = u;
       continue;
@@ -147,65 +144,28 @@ __device__ __forceinline__ void load_mc(TileRegs& r, const float* __restrict__ X
     r.v[i] = v;
   }
 }
-__device__ __forceinline__ void store_mc(const TileRegs& r, float* __restrict__ S, int t) {
+template <int BLK, int PLANE>
+__device__ __forceinline__ void store_mc(const TileRegs& r, char* __restrict__ lds_oper, int t) {
   const int kp = t & 7, row0 = (t >> 3) << 2;
-  char* base = reinterpret_cast<char*>(S) + (kp >> 2) * SPL_BLK + (kp & 3) * 4;
+  char* base = lds_oper + (kp >> 2) * BLK + (kp & 3) * 4;
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     unsigned h, m, l;
     split_pair(r.v[0][j], r.v[1][j], h, m, l);
     char* p = base + (row0 + j) * 16;
     *reinterpret_cast<unsigned*>(p) = h;
-    *reinterpret_cast<unsigned*>(p + SPL_PLANE) = m;
-    *reinterpret_cast<unsigned*>(p + 2 * SPL_PLANE) = l;
+    *reinterpret_cast<unsigned*>(p + PLANE) = m;
+    *reinterpret_cast<unsigned*>(p + 2 * PLANE) = l;
   }
 }
-#else
-// MN-contiguous storage X[k*ld + o]: kk = idx&15, oq = idx>>4 (consecutive lanes take consecutive k rows so that the
-// transposing b32 writes S[(4oq+j)][kk] hit 32 distinct banks).
-template <bool VEC, bool GUARD>
-__device__ __forceinline__ void load_mc(TileRegs& r, const float* __restrict__ X, int ld, int o0, int O, int k0, int kend,
-                                        int t, const float* __restrict__ kscale, int ks_div) {
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = t + 256 * i, k = k0 + (idx % BK), o = o0 + ((idx / BK) << 2);
-    if (!GUARD) {
-      f32x4 u = *reinterpret_cast<const f32x4*>(X + (size_t)k * ld + o);
-      if (kscale) u *= kscale[ks_div == 1 ? k : k / ks_div];
-      r.v[i] = u;
-      continue;
-    }
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (k < kend) {
-      const float* p = X + (size_t)k * ld + o;
-      if (VEC) {
-        if (o < O) v = *reinterpret_cast<const f32x4*>(p);
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (o + j < O) v[j] = p[j];
-      }
-      if (kscale) v *= kscale[ks_div == 1 ? k : k / ks_div];
-    }
-    r.v[i] = v;
-  }
-}
-__device__ __forceinline__ void store_mc(const TileRegs& r, float* __restrict__ S, int t) {
-#pragma unroll
-  for (int i = 0; i < NLD; ++i) {
-    const int idx = t + 256 * i, kk = idx % BK, o = (idx / BK) << 2;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) S[(o + j) * LDP + kk] = r.v[i][j];
-  }
-}
-#endif
 
-struct Plan { int mt, nt, ntiles, I, W, full_rounds, R, q, S, qs; };
+struct Plan { int bm, bn, mt, nt, ntiles, I, W, full_rounds, R, q, S, qs; };
 
-__host__ __device__ inline Plan make_plan(int M, int N, int K, int W) {
+__host__ __device__ inline Plan make_plan(int M, int N, int K, int W, int bm, int bn) {
   Plan p;
-  p.mt = (M + BM - 1) / BM;
-  p.nt = (N + BN - 1) / BN;
+  p.bm = bm; p.bn = bn;
+  p.mt = (M + bm - 1) / bm;
+  p.nt = (N + bn - 1) / bn;
   p.ntiles = p.mt * p.nt;
   p.I = (K + BK - 1) / BK;
   p.W = W;
@@ -227,21 +187,8 @@ __host__ __device__ inline Plan make_plan(int M, int N, int K, int W) {
   return p;
 }
 
-
-// tile id -> (row block, column tile).  OFB_GEMM_PANEL = c > 0: the column tiles are walked in panels of c (row-major inside a
-// panel), so the workgroups that run side by side on one XCD share c weight slices instead of all nt of them.
-#ifndef OFB_GEMM_PANEL
-#define OFB_GEMM_PANEL 0
-#endif
 __host__ __device__ __forceinline__ void tile_coord(const Plan& p, int tile, int& m0, int& n0) {
-#if OFB_GEMM_PANEL > 0
-  const int per = p.mt * OFB_GEMM_PANEL;
-  const int panel = tile / per, within = tile - panel * per;
-  const int c = min(OFB_GEMM_PANEL, p.nt - panel * OFB_GEMM_PANEL);
-  m0 = (within / c) * BM; n0 = (panel * OFB_GEMM_PANEL + within % c) * BN;
-#else
-  m0 = (tile / p.nt) * BM; n0 = (tile % p.nt) * BN;
-#endif
+  m0 = (tile / p.nt) * p.bm; n0 = (tile % p.nt) * p.bn;
 }
 
 // One unit of work: K-iterations [it0, it1) of output tile `tile`; slot < 0 -> full tile, fused epilogue to C;
@@ -303,212 +250,75 @@ __device__ __forceinline__ float epilogue_value(float alpha, int act, float* __r
 
 // TAIL = false: the full rounds (tile = v, v + W, ...; fused epilogue).  TAIL = true: the streamed remainder (<= 2 runs of
 // K-iterations per workgroup, raw partial tiles to the workspace).  Same main loop; launched back to back.
-template <bool A_KC, bool B_KC, bool VEC, bool GUARD, bool FULL_EPI, bool TAIL, bool DEFER>
-__global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(const ofb_gemm_args g, const Plan p) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * 2 * LDS_OPER_FLOATS];
-  float* As = lds;                          // [2 buffers] of one staged A tile
-  float* Bs = lds + 2 * LDS_OPER_FLOATS;    // [2 buffers] of one staged B tile
+template <class TC, bool A_KC, bool B_KC, bool VEC, bool GUARD, bool FULL_EPI, bool TAIL>
+__global__ __launch_bounds__(TC::NT, TC::WPS) void gemm_f32_kernel(const ofb_gemm_args g, const Plan p) {
+  constexpr int BM = TC::BM, BN = TC::BN, MI = TC::MI, NI = TC::NI, NT = TC::NT;
+  __shared__ __attribute__((aligned(16))) char lds[TC::LDS_BYTES];
+  char* const As = lds;                       // [2 buffers] of one staged A tile
+  char* const Bs = lds + 2 * TC::OPER_A;      // [2 buffers] of one staged B tile
 
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, l31 = lane & 31, h = lane >> 5;
   const int v = ofb_xcd_remap(blockIdx.x, p.W);     // consecutive v share an XCD (and thus A/B panels in its L2)
-  const int wm0 = (w >> 1) * 64, wn0 = (w & 1) * 64;
+  const int wm0 = (w / TC::WN) * (32 * MI), wn0 = (w % TC::WN) * (32 * NI);
 
-  f32x16 acc[2][2];
+  f32x16 acc[MI][NI];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < NI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   TileRegs ra, rb;
   auto gload = [&](const Seg& sg, int it) __attribute__((always_inline)) {
     const int k0 = it * BK;
-    if (A_KC) load_kc<VEC, GUARD>(ra, g.A, g.lda, sg.m0, g.M, k0, g.K, t);
+    if (A_KC) load_kc<NT, VEC, GUARD>(ra, g.A, g.lda, sg.m0, g.M, k0, g.K, t);
     else load_mc<VEC, GUARD>(ra, g.A, g.lda, sg.m0, g.M, k0, g.K, t, g.kscale, g.ks_div);
-    if (B_KC) load_kc<VEC, GUARD>(rb, g.B, g.ldb, sg.n0, g.N, k0, g.K, t);
+    if (B_KC) load_kc<NT, VEC, GUARD>(rb, g.B, g.ldb, sg.n0, g.N, k0, g.K, t);
     else load_mc<VEC, GUARD>(rb, g.B, g.ldb, sg.n0, g.N, k0, g.K, t, nullptr, 1);
   };
-  // fused bias gradient (weight-gradient launches): column sums of the stored A (= dY) for the workgroups that own the
-  // first column tile.
-  float bsum = 0.f;
-#if OFB_GEMM_BF16X6
-  f32x4 bsum4 = {0.f, 0.f, 0.f, 0.f};    // rows 4*(t/8) .. +3, this thread's k pairs; reduced over the 8 pair-lanes at unit end
-#endif
+  // fused bias gradient (weight-gradient launches): column sums of the stored A (= dY) for the workgroups that own the first
+  // column tile, added up from the staging registers: rows 4*(t/8) .. +3, this thread's k pairs; reduced over the 8 pair-lanes
+  // at unit end
+  f32x4 bsum4 = {0.f, 0.f, 0.f, 0.f};
   auto lstore = [&](int buf, int tile_n0) __attribute__((always_inline)) {
-#if OFB_GEMM_BF16X6
     if (TAIL && !A_KC && g.a_colsum && tile_n0 == 0) bsum4 += ra.v[0] + ra.v[1];
-#endif
-    if (A_KC) store_kc(ra, As + buf * LDS_OPER_FLOATS, t); else store_mc(ra, As + buf * LDS_OPER_FLOATS, t);
-    if (B_KC) store_kc(rb, Bs + buf * LDS_OPER_FLOATS, t); else store_mc(rb, Bs + buf * LDS_OPER_FLOATS, t);
+    if (A_KC) store_kc<NT, TC::BLK_A, TC::PLANE_A>(ra, As + buf * TC::OPER_A, t);
+    else store_mc<TC::BLK_A, TC::PLANE_A>(ra, As + buf * TC::OPER_A, t);
+    if (B_KC) store_kc<NT, TC::BLK_B, TC::PLANE_B>(rb, Bs + buf * TC::OPER_B, t);
+    else store_mc<TC::BLK_B, TC::PLANE_B>(rb, Bs + buf * TC::OPER_B, t);
   };
-#if OFB_GEMM_BF16X6
   auto compute = [&](int buf) __attribute__((always_inline)) {
     // lane (row l31, k-half h) reads its 8 bf16 of each plane with one b128; A and B share the k <-> (half, j) map.
-    const char* a_s = reinterpret_cast<const char*>(As + buf * LDS_OPER_FLOATS) + h * SPL_BLK + (wm0 + l31) * 16;
-    const char* b_s = reinterpret_cast<const char*>(Bs + buf * LDS_OPER_FLOATS) + h * SPL_BLK + (wn0 + l31) * 16;
-    ofb_bf16x8 af[2][3], bf[2][3];
+    const char* a_s = As + buf * TC::OPER_A + h * TC::BLK_A + (wm0 + l31) * 16;
+    const char* b_s = Bs + buf * TC::OPER_B + h * TC::BLK_B + (wn0 + l31) * 16;
+    ofb_bf16x8 af[MI][3], bf[NI][3];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-      for (int pl = 0; pl < 3; ++pl) {
-        af[i][pl] = *reinterpret_cast<const ofb_bf16x8*>(a_s + pl * SPL_PLANE + i * 32 * 16);
-        bf[i][pl] = *reinterpret_cast<const ofb_bf16x8*>(b_s + pl * SPL_PLANE + i * 32 * 16);
-      }
+      for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const ofb_bf16x8*>(a_s + pl * TC::PLANE_A + i * 32 * 16);
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const ofb_bf16x8*>(b_s + pl * TC::PLANE_B + j * 32 * 16);
     // six product terms, smallest first: (mid,mid) (hi,lo) (lo,hi) (hi,mid) (mid,hi) (hi,hi)
     constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NI; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[q]], bf[j][TB[q]], acc[i][j], 0, 0, 0);
   };
-#else
-  auto compute = [&](int buf) __attribute__((always_inline)) {
-    // fragment reads: lane (row l31, half h) takes k = 8q + 4h + j (q < BK/8; j = 0..3) with one b128 per q; A and B
-    // use the same k <-> (q, h, j) map, so each MFMA step (q, j) multiplies matching k's.
-    const float* a_s = As + buf * BM * LDP + (wm0 + l31) * LDP + 4 * h;
-    const float* b_s = Bs + buf * BN * LDP + (wn0 + l31) * LDP + 4 * h;
-    f32x4 af[2][BK / 8], bf[2][BK / 8];
-#pragma unroll
-    for (int q = 0; q < BK / 8; ++q) {
-      af[0][q] = *reinterpret_cast<const f32x4*>(a_s + 8 * q);
-      af[1][q] = *reinterpret_cast<const f32x4*>(a_s + 32 * LDP + 8 * q);
-      bf[0][q] = *reinterpret_cast<const f32x4*>(b_s + 8 * q);
-      bf[1][q] = *reinterpret_cast<const f32x4*>(b_s + 32 * LDP + 8 * q);
-    }
-#pragma unroll
-    for (int q = 0; q < BK / 8; ++q)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][q][j], bf[0][q][j], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[0][q][j], bf[1][q][j], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][q][j], bf[0][q][j], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[1][q][j], bf[1][q][j], acc[1][1], 0, 0, 0);
-      }
-  };
-#endif
 
   int sidx = 0;
   Seg cur = get_seg<TAIL>(p, v, 0);
   if (!cur.ok) return;
-  // f32 engine: the sums are taken from the staged f32 A tile (thread t < 128 owns output row t); the split engine adds
-  // the registers up while staging them (lstore) because its LDS image is no longer f32.
-  auto colsum_acc = [&](int buf) {
-#if !OFB_GEMM_BF16X6
-    if (TAIL && !A_KC && g.a_colsum && cur.n0 == 0 && t < BM) {
-      const float* row = As + buf * BM * LDP + t * LDP;
-#pragma unroll
-      for (int q = 0; q < BK / 4; ++q) {
-        const f32x4 u = *reinterpret_cast<const f32x4*>(row + 4 * q);
-        bsum += (u[0] + u[1]) + (u[2] + u[3]);
-      }
-    }
-#endif
-  };
   gload(cur, cur.it0);
   lstore(0, cur.n0);
   __syncthreads();
   int buf = 0;
-
-  if constexpr (DEFER) {
-    // ---- full rounds, full tiles, >= 17 K-iterations: DEFERRED, DISTRIBUTED epilogue -------------------------------
-    // A finished tile's accumulators move to `pacc` and are written out 4 rows x (mi, ni) at a time during the first 16
-    // K-iterations of the NEXT tile (that stretch of the K loop is unrolled so every group index is static): side
-    // inputs are requested before the MFMA block and consumed after it, stores drain while the next MFMA block runs.
-    // The epilogue's HBM traffic is thereby spread under the matrix work instead of arriving as one burst per round
-    // during which every co-resident workgroup idles its MFMA pipe.
-    f32x16 pacc[2][2];
-    bool pend = false;
-    int pm0 = 0, pn0 = 0;
-    float pbias0 = 0.f, pbias1 = 0.f, pcs0 = 1.f, pcs1 = 1.f;
-    f32x4 e_rv = {0.f, 0.f, 0.f, 0.f}, e_av = {0.f, 0.f, 0.f, 0.f}, e_rs = {1.f, 1.f, 1.f, 1.f};
-    auto epi_load = [&](auto G) __attribute__((always_inline)) {          // request the side inputs of group G
-      constexpr int gi = decltype(G)::value, ni = gi >> 3, mi = (gi >> 2) & 1, rg = gi & 3;
-      if (!FULL_EPI) return;
-      const int col = pn0 + wn0 + 32 * ni + l31, rbase = pm0 + wm0 + 32 * mi + 4 * h + 8 * rg;
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int row = rbase + r4;
-        if (g.resid) e_rv[r4] = g.resid[(size_t)row * g.ldr + col];
-        if (g.act == OFB_ACT_DGELU) e_av[r4] = g.aux[(size_t)row * g.ldaux + col];
-        if (g.rowscale) e_rs[r4] = g.rowscale[g.rs_div == 1 ? row : row / g.rs_div];
-      }
-    };
-    auto epi_store = [&](auto G) __attribute__((always_inline)) {         // finish and store group G
-      constexpr int gi = decltype(G)::value, ni = gi >> 3, mi = (gi >> 2) & 1, rg = gi & 3;
-      const int col = pn0 + wn0 + 32 * ni + l31, rbase = pm0 + wm0 + 32 * mi + 4 * h + 8 * rg;
-      const float bias = ni ? pbias1 : pbias0, cs = ni ? pcs1 : pcs0;
-#pragma unroll
-      for (int r4 = 0; r4 < 4; ++r4) {
-        const int row = rbase + r4;
-        const float a = pacc[mi][ni][4 * rg + r4];
-        if (FULL_EPI) g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, a, row, col, bias, cs, e_rs[r4], e_rv[r4], e_av[r4]);
-        else g.C[(size_t)row * g.ldc + col] = (a * g.alpha + bias) * cs;
-      }
-    };
-    auto kstep = [&](int it, auto G) __attribute__((always_inline)) {     // one K-iteration (not the tile's last) + group G
-      if (pend) epi_load(G);
-      gload(cur, it + 1);
-      compute(buf);
-      __builtin_amdgcn_sched_barrier(0);            // every MFMA of this K-tile stays ahead of the wait / LDS refill
-      lstore(buf ^ 1, cur.n0);
-      if (pend) epi_store(G);
-      __syncthreads();
-      buf ^= 1;
-    };
-#define OFB_IC(n) std::integral_constant<int, n>{}
-    while (true) {
-      kstep(0, OFB_IC(0));   kstep(1, OFB_IC(1));   kstep(2, OFB_IC(2));   kstep(3, OFB_IC(3));
-      kstep(4, OFB_IC(4));   kstep(5, OFB_IC(5));   kstep(6, OFB_IC(6));   kstep(7, OFB_IC(7));
-      kstep(8, OFB_IC(8));   kstep(9, OFB_IC(9));   kstep(10, OFB_IC(10)); kstep(11, OFB_IC(11));
-      kstep(12, OFB_IC(12)); kstep(13, OFB_IC(13)); kstep(14, OFB_IC(14)); kstep(15, OFB_IC(15));
-      for (int it = 16; it + 1 < p.I; ++it) {                              // the rest of the K loop (host guarantees I >= 17)
-        gload(cur, it + 1);
-        compute(buf);
-        __builtin_amdgcn_sched_barrier(0);
-        lstore(buf ^ 1, cur.n0);
-        __syncthreads();
-        buf ^= 1;
-      }
-      const Seg nxt = get_seg<false>(p, v, sidx + 1);
-      const bool has_next = nxt.ok;
-      if (has_next) gload(nxt, 0);
-      compute(buf);
-      __builtin_amdgcn_sched_barrier(0);
-      // this tile becomes the pending one
-#pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-          pacc[mi][ni] = acc[mi][ni];
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-        }
-      pend = true;
-      pm0 = cur.m0; pn0 = cur.n0;
-      {
-        const int c0 = pn0 + wn0 + l31;
-        pbias0 = g.bias ? g.bias[c0] : 0.f; pbias1 = g.bias ? g.bias[c0 + 32] : 0.f;
-        pcs0 = g.colscale ? g.colscale[c0] : 1.f; pcs1 = g.colscale ? g.colscale[c0 + 32] : 1.f;
-      }
-      if (!has_next) break;
-      lstore(buf ^ 1, nxt.n0);
-      __syncthreads();
-      buf ^= 1;
-      ++sidx;
-      cur = nxt;
-    }
-    // the worker's last tile: plain epilogue
-#define OFB_FLUSH(n) epi_load(OFB_IC(n)); epi_store(OFB_IC(n));
-    OFB_FLUSH(0) OFB_FLUSH(1) OFB_FLUSH(2) OFB_FLUSH(3) OFB_FLUSH(4) OFB_FLUSH(5) OFB_FLUSH(6) OFB_FLUSH(7)
-    OFB_FLUSH(8) OFB_FLUSH(9) OFB_FLUSH(10) OFB_FLUSH(11) OFB_FLUSH(12) OFB_FLUSH(13) OFB_FLUSH(14) OFB_FLUSH(15)
-#undef OFB_FLUSH
-#undef OFB_IC
-    return;
-  }
 
   while (true) {
     // all K-iterations of this unit but the last: prefetch the next K-tile of the same unit
@@ -516,10 +326,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
       gload(cur, it + 1);
       // pin the prefetch ahead of the MFMA block: left alone, hipcc lets the loaded tile share VGPRs with the fragments and
       // sinks the global loads behind the last MFMAs, exposing their whole latency in front of the LDS refill
-#ifndef LAB_NO_LOAD_PIN
       __builtin_amdgcn_sched_barrier(0);
-#endif
-      colsum_acc(buf);      // its LDS reads / adds are issued ahead of (and overlap) the MFMA block
       compute(buf);
       // keep every MFMA of this K-tile ahead of the vmcnt wait / LDS refill / barrier
       __builtin_amdgcn_sched_barrier(0);
@@ -531,14 +338,10 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
     const Seg nxt = get_seg<TAIL>(p, v, sidx + 1);
     const bool has_next = nxt.ok;
     if (has_next) gload(nxt, nxt.it0);
-#ifndef LAB_NO_LOAD_PIN
     __builtin_amdgcn_sched_barrier(0);
-#endif
-    colsum_acc(buf);
     compute(buf);
     __builtin_amdgcn_sched_barrier(0);
     if (TAIL) {
-#if OFB_GEMM_BF16X6
       if (!A_KC && g.a_colsum && cur.n0 == 0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {                 // sum over the 8 k-pair lanes (lane bits 0..2) that share these 4 rows
@@ -550,18 +353,12 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
           bsum4[j] = 0.f;
         }
       }
-#else
-      if (!A_KC && g.a_colsum && cur.n0 == 0 && t < BM) {
-        g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)cur.slot * BM + t] = bsum;
-        bsum = 0.f;
-      }
-#endif
-      // raw partial tile -> workspace[slot][128][128] (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
+      // raw partial tile -> workspace[slot][BM][BN] (C/D layout: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5))
       float* ws = g.workspace + (size_t)cur.slot * (BM * BN);
 #pragma unroll
-      for (int mi = 0; mi < 2; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             ws[(wm0 + 32 * mi + 4 * h + (r & 3) + 8 * (r >> 2)) * BN + wn0 + 32 * ni + l31] = acc[mi][ni][r];
@@ -571,73 +368,91 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
     } else if (!GUARD) {
       // unguarded build (every tile is full): no per-element guards, so loads / stores issue back to back behind ONE wait
       // (hipcc otherwise brackets every guarded store with s_waitcnt vmcnt(0), serialising 64 round trips per wave)
-      float biasv[2], csv[2];
+      float biasv[NI], csv[NI];
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
         const int col = cur.n0 + wn0 + 32 * ni + l31;
         biasv[ni] = g.bias ? g.bias[col] : 0.f;
         csv[ni] = g.colscale ? g.colscale[col] : 1.f;
       }
       if (FULL_EPI) {
-        // side inputs (residual / saved pre-activation / per-row scale) are requested one whole 32x32 block (16 values per
-        // lane) ahead of the block being finished, so ~32 loads per lane are in flight instead of 4: the epilogue is bound
-        // by memory latency, not bandwidth, and used to expose one round trip per 4 rows.
-        // `side` carries the saved pre-activation for the dGELU form and the residual otherwise (a launch that wants both
-        // reads its residual inside `finish`); the per-row scales of a 32-row band serve both of its column blocks.
+        // side inputs (residual / saved pre-activation / per-row scale) of a whole 32-row band (NI blocks, 16 values per lane
+        // each) are requested one band ahead of the band being finished, so ~32 loads per lane are in flight instead of 4: the
+        // epilogue is bound by memory latency, not bandwidth.  `side` carries the saved pre-activation for the dGELU form and the
+        // residual otherwise (a launch that wants both reads its residual inside `finish`).
         const bool dg = g.act == OFB_ACT_DGELU;
         const float* sp = dg ? g.aux : g.resid;
         const int lds_ = dg ? g.ldaux : g.ldr;
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         if (!sp && !g.rowscale) {
-          // nothing to fetch (bias / gate / GELU forms): finish and stream out all 64 values, no staging, no waits
-          auto stream_out = [&](auto Bk) __attribute__((always_inline)) {
-            constexpr int bk = decltype(Bk)::value, mi = bk >> 1, ni = bk & 1;
-            const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
+          // nothing to fetch (bias / gate / GELU forms): finish and stream out, no staging, no waits
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = rbase + (r & 3) + 8 * (r >> 2);
-              g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][r], row, col, biasv[ni], csv[ni],
-                                                              1.f, 0.f, 0.f);
-              acc[mi][ni][r] = 0.f;
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+              const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][r], row, col, biasv[ni], csv[ni],
+                                                                1.f, 0.f, 0.f);
+                acc[mi][ni][r] = 0.f;
+              }
             }
-          };
-          stream_out(I0{}); stream_out(I1{}); stream_out(I2{}); stream_out(I3{});
         } else {
-          // all four blocks' side inputs are requested before the first is finished: one exposed round trip per tile
-          f32x16 side[4], rsv[2];
-          auto request = [&](auto Bk) __attribute__((always_inline)) {
-            constexpr int bk = decltype(Bk)::value, mi = bk >> 1, ni = bk & 1;
-            const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
+          f32x16 side[2][NI], rsv[2];
+          auto request = [&](auto Mi) __attribute__((always_inline)) {
+            constexpr int mi = decltype(Mi)::value;
+            const int rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = rbase + (r & 3) + 8 * (r >> 2);
-              side[bk][r] = sp ? sp[(size_t)row * lds_ + col] : 0.f;
-              if (ni == 0) rsv[mi][r] = g.rowscale ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
+            for (int ni = 0; ni < NI; ++ni) {
+              const int col = cur.n0 + wn0 + 32 * ni + l31;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                side[mi & 1][ni][r] = sp ? sp[(size_t)row * lds_ + col] : 0.f;
+                if (ni == 0) rsv[mi & 1][r] = g.rowscale ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
+              }
             }
           };
-          auto finish = [&](auto Bk) __attribute__((always_inline)) {
-            constexpr int bk = decltype(Bk)::value, mi = bk >> 1, ni = bk & 1;
-            const int col = cur.n0 + wn0 + 32 * ni + l31, rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
+          auto finish = [&](auto Mi) __attribute__((always_inline)) {
+            constexpr int mi = decltype(Mi)::value;
+            const int rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int row = rbase + (r & 3) + 8 * (r >> 2);
-              const float rvv = dg ? (g.resid ? g.resid[(size_t)row * g.ldr + col] : 0.f) : side[bk][r];
-              g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][r], row, col, biasv[ni], csv[ni],
-                                                              rsv[mi][r], rvv, dg ? side[bk][r] : 0.f);
-              acc[mi][ni][r] = 0.f;
+            for (int ni = 0; ni < NI; ++ni) {
+              const int col = cur.n0 + wn0 + 32 * ni + l31;
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int row = rbase + (r & 3) + 8 * (r >> 2);
+                const float rvv = dg ? (g.resid ? g.resid[(size_t)row * g.ldr + col] : 0.f) : side[mi & 1][ni][r];
+                g.C[(size_t)row * g.ldc + col] = epilogue_value(g.alpha, g.act, g.aux, g.ldaux, acc[mi][ni][r], row, col, biasv[ni], csv[ni],
+                                                                rsv[mi & 1][r], rvv, dg ? side[mi & 1][ni][r] : 0.f);
+                acc[mi][ni][r] = 0.f;
+              }
             }
           };
-          request(I0{}); request(I1{}); request(I2{}); request(I3{});
+          using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+          using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+          static_assert(MI == 2 || MI == 4, "epilogue bands are unrolled for 2 or 4 row blocks per wave");
+          request(I0{}); request(I1{});
           __builtin_amdgcn_sched_barrier(0);
-          finish(I0{}); finish(I1{}); finish(I2{}); finish(I3{});
+          finish(I0{});
+          if constexpr (MI == 4) {
+            request(I2{});
+            __builtin_amdgcn_sched_barrier(0);
+            finish(I1{});
+            request(I3{});
+            __builtin_amdgcn_sched_barrier(0);
+            finish(I2{}); finish(I3{});
+          } else {
+            finish(I1{});
+          }
         }
       } else {
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
+        for (int ni = 0; ni < NI; ++ni) {
           const int col = cur.n0 + wn0 + 32 * ni + l31;
 #pragma unroll
-          for (int mi = 0; mi < 2; ++mi) {
+          for (int mi = 0; mi < MI; ++mi) {
             const int rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -649,7 +464,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
       }
     } else {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
         const int col = cur.n0 + wn0 + 32 * ni + l31;
         const bool colok = col < g.N;
         float bias = 0.f, cs = 1.f;
@@ -658,7 +473,7 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
           if (g.colscale) cs = g.colscale[col];
         }
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
           const int rbase = cur.m0 + wm0 + 32 * mi + 4 * h;
           if (FULL_EPI) {
             // per group of 4 rows: gather the side inputs first (independent loads in flight together), then compute + store
@@ -702,13 +517,13 @@ __global__ __launch_bounds__(256, GEMM_WAVES_PER_SIMD) void gemm_f32_kernel(cons
 }
 
 // Sums the partial tiles of each streamed tail tile in workgroup order and applies the epilogue.
-// grid (R, 32), 128 threads: block (r, part) handles rows [4*part, 4*part+4) of tail tile r, one float4 (4 columns) per thread.
-// The kernel is bound by loads in flight, not bandwidth (weight gradients: a few dozen tail tiles with ~14-30 contributors
-// each): 16-byte loads, eight contributors per trip, 32 blocks per tile.  The sums stay in contributor order (deterministic).
-#define FIX_PARTS 32
-#define FIX_ROWS (BM / FIX_PARTS)
-#define FIX_THREADS (FIX_ROWS * BN / 4)
-__global__ __launch_bounds__(FIX_THREADS) void gemm_fixup_kernel(const ofb_gemm_args g, const Plan p) {
+// grid (R, BM / 4), BN threads: block (r, part) handles rows [4*part, 4*part+4) of tail tile r, one float4 (4 columns) per
+// thread; 16-byte loads, eight contributors per trip.  The sums stay in contributor order (deterministic).
+#define FIX_ROWS 4
+template <class TC>
+__global__ __launch_bounds__(TC::BN) void gemm_fixup_kernel(const ofb_gemm_args g, const Plan p) {
+  constexpr int BM = TC::BM, BN = TC::BN, FIX_THREADS = FIX_ROWS * BN / 4;
+  static_assert(FIX_THREADS == BN && BM <= BN, "one block per 4 rows; the first block also sums the BM fused bias partials");
   const int r = blockIdx.x, part = blockIdx.y, t = threadIdx.x;
   const int tile = p.full_rounds * p.W + r;
   int m0, n0;
@@ -730,13 +545,10 @@ __global__ __launch_bounds__(FIX_THREADS) void gemm_fixup_kernel(const ofb_gemm_
     for (int u = 0; u < 8; ++u) sum += x[u];
   }
   for (; v <= v1; ++v) sum += *reinterpret_cast<const f32x4*>(g.workspace + (size_t)slot_of(v) * (BM * BN) + roff);
-  if (g.a_colsum && n0 == 0 && part < BM / FIX_THREADS) {
-    const int rr = part * FIX_THREADS + t;
-    if (m0 + rr < g.M) {
-      float bs = 0.f;
-      for (int u = v0; u <= v1; ++u) bs += g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)slot_of(u) * BM + rr];
-      g.a_colsum[m0 + rr] = bs;
-    }
+  if (g.a_colsum && n0 == 0 && part == 0 && t < BM && m0 + t < g.M) {
+    float bs = 0.f;
+    for (int u = v0; u <= v1; ++u) bs += g.workspace[(size_t)2 * p.W * (BM * BN) + (size_t)slot_of(u) * BM + t];
+    g.a_colsum[m0 + t] = bs;
   }
   const int row = m0 + lrow, col0 = n0 + c4;
   if (row >= g.M || col0 >= g.N) return;
@@ -767,79 +579,104 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, i
   }
 }
 
-template <bool A_KC, bool B_KC, bool VEC, bool GUARD>
+template <class TC, bool A_KC, bool B_KC, bool VEC, bool GUARD>
 void launch2(const ofb_gemm_args& g, const Plan& p, bool full, hipStream_t s) {
-  const dim3 grid(p.W);
+  const dim3 grid(p.W), block(TC::NT);
   if (p.full_rounds > 0) {
-    if constexpr (!GUARD) {
-      // deferred, distributed epilogue: needs 16 K-iterations of the next tile to hide under, and the register room of
-      // the row-wise staging (with the split engine only the x @ W^T form keeps pending + live accumulators spill-free)
-#ifndef OFB_GEMM_DEFER
-#define OFB_GEMM_DEFER 0
-#endif
-      constexpr bool CAN_DEFER = OFB_GEMM_DEFER && (OFB_GEMM_BF16X6 ? (A_KC && B_KC) : A_KC);
-      bool deferred = false;
-      if constexpr (CAN_DEFER) {
-        if (p.I >= 17) {
-          deferred = true;
-          if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, true, false, true>), grid, dim3(256), 0, s, g, p);
-          else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, false, false, true>), grid, dim3(256), 0, s, g, p);
-        }
-      }
-      if (!deferred) {
-        if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, true, false, false>), grid, dim3(256), 0, s, g, p);
-        else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, false, false, false, false>), grid, dim3(256), 0, s, g, p);
-      }
-    } else {
-      if (full) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, true, false, false>), grid, dim3(256), 0, s, g, p);
-      else hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, false, false, false>), grid, dim3(256), 0, s, g, p);
-    }
+    if (full) hipLaunchKernelGGL((gemm_f32_kernel<TC, A_KC, B_KC, VEC, GUARD, true, false>), grid, block, 0, s, g, p);
+    else hipLaunchKernelGGL((gemm_f32_kernel<TC, A_KC, B_KC, VEC, GUARD, false, false>), grid, block, 0, s, g, p);
   }
-  if (p.R > 0) hipLaunchKernelGGL((gemm_f32_kernel<A_KC, B_KC, VEC, GUARD, false, true, false>), grid, dim3(256), 0, s, g, p);
+  if (p.R > 0) hipLaunchKernelGGL((gemm_f32_kernel<TC, A_KC, B_KC, VEC, GUARD, false, true>), grid, block, 0, s, g, p);
 }
 
-template <bool A_KC, bool B_KC>
+template <class TC, bool A_KC, bool B_KC>
 int launch(const ofb_gemm_args& g, const Plan& p, bool vec, hipStream_t s) {
   const bool full = g.act != OFB_ACT_NONE || g.rowscale || g.resid;
-  // unguarded kernels need every tile full: M, N multiples of 128 and K a multiple of the K-step
-  const bool guard = !vec || (g.M % BM) || (g.N % BN) || (g.K % BK);
-  if (!vec) launch2<A_KC, B_KC, false, true>(g, p, full, s);
-  else if (guard) launch2<A_KC, B_KC, true, true>(g, p, full, s);
-  else launch2<A_KC, B_KC, true, false>(g, p, full, s);
+  // unguarded kernels need every tile full: M, N multiples of the tile and K a multiple of the K-step
+  const bool guard = !vec || (g.M % TC::BM) || (g.N % TC::BN) || (g.K % BK);
+  if (!vec) launch2<TC, A_KC, B_KC, false, true>(g, p, full, s);
+  else if (guard) launch2<TC, A_KC, B_KC, true, true>(g, p, full, s);
+  else launch2<TC, A_KC, B_KC, true, false>(g, p, full, s);
   return ofb_launch_status();
 }
 
-int worker_count() {
-  static int W = 0;
-  if (W == 0) {
+int cu_count() {
+  static int n = 0;
+  if (n == 0) {
     hipDeviceProp_t prop;
     int devid = 0;
-    W = 256 * GEMM_WAVES_PER_SIMD;
+    n = 256;
     if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.multiProcessorCount > 0)
-      W = prop.multiProcessorCount * GEMM_WAVES_PER_SIMD;
+      n = prop.multiProcessorCount;
   }
-  return W;
+  return n;
 }
 
+// Tile choice.  T256 feeds twice the MFMAs per staged value, and its bare main loop is 1.35x faster at long K with an even tile
+// count (lab: 223 vs ~165 TFLOP/s at 32768 x 2048 x 2048), but on the step's shapes it LOSES (same-box A/B, DeiT-S 35.1 vs 31.5
+// ms/step, DeiT-B 54.2 vs 53.3): K is 384..1536, so a 256x256 tile lives for only 24..96 K-steps and its prologue / epilogue are
+// not hidden by a second workgroup on the CU, its stream-K partial tiles are 256 KB each, and 594 tiles over 256 workers round
+// badly.  The default build therefore compiles T128 only; -DOFB_GEMM_TILE=256 forces T256, -DOFB_GEMM_TILE=1 enables the
+// per-shape choice below (K-contiguous-A launches that pad by at most 1/8 in 256-blocks and fill a round of workers).
+#ifndef OFB_GEMM_TILE
+#define OFB_GEMM_TILE 128
+#endif
+bool use_t256(const ofb_gemm_args& g) {
+#if OFB_GEMM_TILE == 128
+  return false;
+#elif OFB_GEMM_TILE == 256
+  return true;
+#else
+  if (!g.a_kc) return false;
+  const long long mp = ofb_cdiv(g.M, 256) * 256LL, np = ofb_cdiv(g.N, 256) * 256LL;
+  if (mp * np * 8 > (long long)g.M * g.N * 9) return false;                 // more than 1/8 of the MFMA work would be padding
+  return (mp / 256) * (np / 256) >= cu_count();
+#endif
+}
+
+template <class TC>
 Plan plan_for(const ofb_gemm_args& g) {
-  int W = worker_count();
-  const int tiles = ofb_cdiv(g.M, BM) * ofb_cdiv(g.N, BN);
+  int W = cu_count() * TC::WG_PER_CU;
+  const int tiles = ofb_cdiv(g.M, TC::BM) * ofb_cdiv(g.N, TC::BN);
   const long long iters = (long long)tiles * ofb_cdiv(g.K, BK);
   if (iters < W) W = (int)iters;                    // tiny problems: one K-iteration per workgroup
-  return make_plan(g.M, g.N, g.K, W);
+  return make_plan(g.M, g.N, g.K, W, TC::BM, TC::BN);
+}
+Plan plan_any(const ofb_gemm_args& g, bool& t256) {
+  t256 = use_t256(g);
+#if OFB_GEMM_TILE == 128
+  return plan_for<T128>(g);
+#else
+  return t256 ? plan_for<T256>(g) : plan_for<T128>(g);
+#endif
+}
+
+template <class TC>
+int run(const ofb_gemm_args& g, const Plan& p, bool vec, hipStream_t s) {
+  int rc;
+  if (g.a_kc && g.b_kc) rc = launch<TC, true, true>(g, p, vec, s);
+  else if (g.a_kc) rc = launch<TC, true, false>(g, p, vec, s);
+  else rc = launch<TC, false, false>(g, p, vec, s);
+  if (rc == 0 && p.R) {
+    hipLaunchKernelGGL(gemm_fixup_kernel<TC>, dim3(p.R, TC::BM / FIX_ROWS), dim3(TC::BN), 0, s, g, p);
+    rc = ofb_launch_status();
+  }
+  return rc;
 }
 
 }  // namespace
 
 extern "C" int64_t ofb_gemm_workspace_bytes(const ofb_gemm_args* args) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
-  const Plan p = plan_for(*args);
-  return p.R ? (int64_t)2 * p.W * (BM * BN + BM) * (int64_t)sizeof(float) : 0;
+  bool t256;
+  const Plan p = plan_any(*args, t256);
+  return p.R ? (int64_t)2 * p.W * ((int64_t)p.bm * p.bn + p.bm) * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int32_t ofb_gemm_is_streamed(const ofb_gemm_args* args) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
-  return plan_for(*args).full_rounds == 0 ? 1 : 0;
+  bool t256;
+  return plan_any(*args, t256).full_rounds == 0 ? 1 : 0;
 }
 
 extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream) {
@@ -853,7 +690,8 @@ extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream) {
   if (g.a_colsum && g.a_kc != 0) return OFB_EINVAL;
   // minimum leading dimensions for the declared storage
   if (g.lda < (g.a_kc ? g.K : g.M) || g.ldb < (g.b_kc ? g.K : g.N) || g.ldc < g.N) return OFB_EINVAL;
-  const Plan p = plan_for(g);
+  bool t256;
+  const Plan p = plan_any(g, t256);
   if ((long long)p.W * p.I > 0x7fffffffLL / 2) return OFB_ELIMIT;
   if (g.a_colsum && p.full_rounds > 0) return OFB_ELIMIT;   // fused column sums ride on the streamed tail only (see ofb_gemm_is_streamed)
   if (p.R && (!g.workspace || g.workspace_bytes < ofb_gemm_workspace_bytes(args))) return OFB_EINVAL;
@@ -862,14 +700,11 @@ extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream) {
   vec = vec && ((g.a_kc ? g.K : g.M) % 4 == 0) && ((g.b_kc ? g.K : g.N) % 4 == 0);
   hipStream_t s = (hipStream_t)stream;
   ofb_prof_pre(0, s, 2.0 * g.M * g.N * (double)g.K);
-  int rc;
-  if (g.a_kc && g.b_kc) rc = launch<true, true>(g, p, vec, s);
-  else if (g.a_kc) rc = launch<true, false>(g, p, vec, s);
-  else rc = launch<false, false>(g, p, vec, s);
-  if (rc == 0 && p.R) {
-    hipLaunchKernelGGL(gemm_fixup_kernel, dim3(p.R, FIX_PARTS), dim3(FIX_THREADS), 0, s, g, p);
-    rc = ofb_launch_status();
-  }
+#if OFB_GEMM_TILE == 128
+  const int rc = run<T128>(g, p, vec, s);
+#else
+  const int rc = t256 ? run<T256>(g, p, vec, s) : run<T128>(g, p, vec, s);
+#endif
   ofb_prof_post(0, s);
   return rc;
 }

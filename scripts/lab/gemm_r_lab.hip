@@ -28,6 +28,9 @@ constexpr int BM = 128, BK = 16;
 #ifndef ABL
 #define ABL 0            // bit 0: no split VALU; bit 1: no DMA inside the loop; bit 2: no MFMA
 #endif
+#ifndef FRAGPF
+#define FRAGPF 0            // 1: fragments of K-step t+1 are read into a second register set while K-step t multiplies (needs STAGES 3)
+#endif
 #ifndef WPS
 #define WPS 2            // waves per SIMD = workgroups per CU (4-wave workgroups)
 #endif
@@ -171,7 +174,93 @@ __global__ __launch_bounds__(256, WPS) void gemm_r_kernel(const float* __restric
 #endif
   };
 
-#if STAGES == 2
+#if FRAGPF
+  // ---- fragment prefetch: register double buffer, DMA two K-steps ahead, one barrier per K-step --------------------------
+  constexpr int PERF = 2 + 3 * RB;
+  f32x4 ra_lo[2][2], ra_hi[2][2];
+  bf16x8 rbf[2][NI][3];
+  auto ldfrag = [&](int buf, int S) __attribute__((always_inline)) {
+    const char* sb = lds + buf * cfg::STAGE;
+    const char* bb = sb + cfg::A_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int R = wm0 + i * 32 + l31, s = (R >> 2) & 3;
+      ra_lo[S][i] = *reinterpret_cast<const f32x4*>(sb + R * 64 + (((2 * h) ^ s) << 4));
+      ra_hi[S][i] = *reinterpret_cast<const f32x4*>(sb + R * 64 + (((2 * h + 1) ^ s) << 4));
+    }
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl)
+        rbf[S][j][pl] = *reinterpret_cast<const bf16x8*>(bb + (pl * 2 + h) * cfg::B_BLK + (wn0 + j * 32 + l31) * 16);
+  };
+  auto mma = [&](int S) __attribute__((always_inline)) {
+    bf16x8 af[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      u32x4 hh, mm, ll;
+      unsigned a, b, c;
+      split2(ra_lo[S][i][0], ra_lo[S][i][1], a, b, c); hh[0] = a; mm[0] = b; ll[0] = c;
+      split2(ra_lo[S][i][2], ra_lo[S][i][3], a, b, c); hh[1] = a; mm[1] = b; ll[1] = c;
+      split2(ra_hi[S][i][0], ra_hi[S][i][1], a, b, c); hh[2] = a; mm[2] = b; ll[2] = c;
+      split2(ra_hi[S][i][2], ra_hi[S][i][3], a, b, c); hh[3] = a; mm[3] = b; ll[3] = c;
+      af[i][0] = __builtin_bit_cast(bf16x8, hh);
+      af[i][1] = __builtin_bit_cast(bf16x8, mm);
+      af[i][2] = __builtin_bit_cast(bf16x8, ll);
+    }
+    constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[q]], rbf[S][j][TB[q]], acc[i][j], 0, 0, 0);
+  };
+  auto waitp = [&]() __attribute__((always_inline)) {
+    if (PERF == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  };
+  issue(0, 0);
+  issue(min(1, total - 1), 1);
+  waitp();
+  __builtin_amdgcn_s_barrier();
+  ldfrag(0, 0);
+  int ks = 0, ti = 0, buf = 0;
+  auto body = [&](int it, int S) __attribute__((always_inline)) {
+    int b1 = buf + 1; if (b1 >= 3) b1 -= 3;
+    int b2 = buf + 2; if (b2 >= 3) b2 -= 3;
+    issue(min(it + 2, total - 1), b2);
+    waitp();                                          // tile it+1 has landed (this wave's pieces)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    ldfrag(b1, S ^ 1);
+    mma(S);
+    __builtin_amdgcn_sched_barrier(0);
+    buf = b1;
+    if (++ks == KS) {
+      ks = 0;
+      const int tile = v + ti * W;
+      ++ti;
+      const int m0 = (tile / nt) * BM, n0 = (tile % nt) * BN;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          const int col = n0 + wn0 + 32 * j + l31, rbase = m0 + wm0 + 32 * i + 4 * h;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            if (col < N) C[(size_t)(rbase + (r & 3) + 8 * (r >> 2)) * ldc + col] = acc[i][j][r];
+            acc[i][j][r] = 0.f;
+          }
+        }
+    }
+  };
+  int it = 0;
+  for (; it + 1 < total; it += 2) { body(it, 0); body(it + 1, 1); }
+  if (it < total) body(it, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#elif STAGES == 2
   issue(0, 0);
   int ks = 0, ti = 0;
   for (int it = 0; it < total; ++it) {
@@ -274,7 +363,7 @@ void run(const Shape& s, int ncu, const float* dA, const float* dB, float* dC, c
   float ms;
   CHECK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / reps, tf = 2.0 * M * N * K / (us * 1e-6) / 1e12;
-  printf("R abl=%d BN=%d stages=%d wps=%d  M=%d N=%d K=%d : %8.1f us  %7.1f TFLOP/s alg (%7.1f bf16 issued)  worst err/sum|ab| %.2e\n", ABL, BN, STAGES, WPS, M, N, K, us, tf,
+  printf("R fp=%d abl=%d BN=%d stages=%d wps=%d  M=%d N=%d K=%d : %8.1f us  %7.1f TFLOP/s alg (%7.1f bf16 issued)  worst err/sum|ab| %.2e\n", FRAGPF, ABL, BN, STAGES, WPS, M, N, K, us, tf,
          tf * 6, worst);
   fflush(stdout);
 }
