@@ -29,6 +29,21 @@ PEAK_GEMM_TFLOPS = PEAK_BF16_MFMA_TFLOPS / GEMM_MFMA_TERMS
 PROF_TAGS = ['gemm_f32', 'attention_fwd', 'layernorm_fwd', 'layernorm_bwd', 'attention_bwd', 'norm_targets', 'adamw']
 
 
+def gemm_traffic_per_launch(launches_per_step):
+    """HBM-side bytes per ofb_gemm_f32 call from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes over this same bench command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; scripts/pmc_bench.sh).
+    Counters cannot be read from inside the process, so the figure is the last profiled one for configs[1]."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic_summary_v*.txt')),
+                   key=lambda f: [int(x) for x in re.findall(r'\d+', os.path.basename(f))])
+    for f in reversed(files):
+        m = re.search(r'GEMM_BYTES_PER_STEP (\d+)', open(f).read())
+        if m:
+            return int(m.group(1)) / launches_per_step, os.path.relpath(f, ROOT)
+    return None, None
+
+
 def cpu_baseline(log):
     """The CPU oracle (a parity-pinned port of the reference's engine.py search step) timed on this host's cores on a
     bounded sample of the same workload: DeiT-S, bs 8, fp32, forward + loss + backward."""
@@ -252,6 +267,13 @@ def main():
                         mfma_issued_tflops=round(ach * GEMM_MFMA_TERMS, 1),
                         launches_per_step=round(n / prof_steps, 1), avg_launch_us=round(ms / n * 1e3, 2),
                         share_of_step=round(ms / prof_steps / ms_step, 3), sampled_steps=prof_steps)
+            if args.mode == 'search' and (args.model, args.batch) == ('deit_small', 128):
+                tr, src = gemm_traffic_per_launch(n / prof_steps)
+                if tr:
+                    roof['traffic'] = round(tr)
+                    roof['traffic_unit'] = 'bytes per ofb_gemm_f32 call (FETCH_SIZE x2 + WRITE_SIZE of its kernels, PMC)'
+                    roof['traffic_source'] = src
+                    roof['algorithmic_bytes_note'] = 'operands + outputs + epilogue side inputs of the 152 calls, each moved once: 28.4 GB per step = 187 MB per call'
     step_tflops = value * gflop_img / 1e3 / world
     log(f'loss_total {loss_val:.4f}; step {ms_step:.2f} ms; whole-step {step_tflops:.1f} TFLOP/s/GPU '
         f'({step_tflops / PEAK_F32_MFMA_TFLOPS:.1%} of the f32 MFMA peak)')
