@@ -48,6 +48,9 @@ def cpu_baseline(log):
     """The CPU oracle (a parity-pinned port of the reference's engine.py search step) timed on this host's cores on a
     bounded sample of the same workload: DeiT-S, bs 8, fp32, forward + loss + backward."""
     from oracle import ofb_oracle as O
+    # 16 threads = this job's CPU share on a one-GPU box; with all 128 hardware threads the bs-8 sample spends its time in
+    # thread hand-offs (1.4-3.5 images/s, varying run to run) instead of arithmetic
+    torch.set_num_threads(min(16, os.cpu_count() or 16))
     torch.manual_seed(0)
     cfg = O.Config(**O.DEIT_SMALL, num_classes=1000, drop_path_rate=0.1)
     p = {k: v.requires_grad_(True) for k, v in O.formula_params(cfg, torch.float32).items()}
