@@ -43,7 +43,10 @@ struct Tile {
   static constexpr int LDS_BYTES = 2 * (OPER_A + OPER_B);
   static_assert(BM * BK / 4 == 2 * NT && BN * BK / 4 == 2 * NT, "the loaders stage exactly two float4 per thread and operand");
 };
-using T128 = Tile<128, 128, 2, 2, 2>;
+#ifndef OFB_GEMM_WG_PER_CU
+#define OFB_GEMM_WG_PER_CU 2
+#endif
+using T128 = Tile<128, 128, 2, 2, OFB_GEMM_WG_PER_CU>;
 using T256 = Tile<256, 256, 2, 4, 1>;
 
 struct TileRegs { f32x4 v[2]; };
