@@ -39,6 +39,11 @@ class GradAllReducer:
         # the exchange is a plain SUM, so no extra pass over the gradients is needed; prescaled=False divides afterwards.
         self.grad_scale = 1.0 / self.world
         self.prescaled = False
+        # gradient accumulation: with sync = False a backward only accumulates into the local .grad (DDP's no_sync()); the
+        # micro-step that closes the accumulation window exchanges the accumulated gradients once.  Exchanging every
+        # micro-step (as the reference does, SURVEY D-7) would SUM the already-reduced part again, because .grad is re-pointed
+        # at the reduced bucket and autograd keeps accumulating into it.
+        self.sync = True
 
     def rebuild(self, params):
         """call after compress() replaced Parameters (fixes the reference's silent de-sync, SURVEY D-6)."""
@@ -58,6 +63,8 @@ class GradAllReducer:
         self._works.append((bi, ps, flat, work))
 
     def _hook(self, p):
+        if not self.sync:
+            return
         bi = self._where[p]
         self._ready[bi] += 1
         if self._ready[bi] == len(self.buckets[bi]):
@@ -65,6 +72,8 @@ class GradAllReducer:
 
     def finalize(self):
         """wait for the exchanges of this backward and install the averaged gradients."""
+        if not self.sync:
+            return
         for bi in range(len(self.buckets)):            # buckets with frozen / unused members never filled up
             if 0 < self._ready[bi] < len(self.buckets[bi]):
                 self._launch(bi)

@@ -31,6 +31,7 @@ def search_step(model, criterion, samples, targets, target_flops, optimizers, fi
     scale = 1.0 / accum_iter
     if reducer is not None:
         reducer.prescaled = True
+        reducer.sync = do_step                           # exchange once per accumulation window, on its closing micro-step
         scale *= reducer.grad_scale                      # SUM all-reduce of (loss / world) gradients == average
     (total * scale if scale != 1.0 else total).backward()
     if reducer is not None:
@@ -122,6 +123,8 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
         if mixup_fn is not None:
             samples, targets = mixup_fn(samples, targets)
         loss = criterion(samples, model(samples), targets)
+        if reducer is not None:
+            reducer.sync = (it + 1) % accum_iter == 0    # one exchange per accumulation window
         (loss / accum_iter if accum_iter != 1 else loss).backward()
         if reducer is not None:
             reducer.finalize()

@@ -36,6 +36,21 @@ def _worker(rank, world, port, out):
             exp = sum(r + 1 + i + step for r in range(world)) / world
             assert torch.allclose(p.grad, torch.full_like(p, exp)), (rank, i, step)
         assert unused.grad is None
+    # gradient accumulation over 3 micro-steps (engine.search_step: prescaled SUM; engine.train_one_epoch: SUM then / world):
+    # only the closing micro-step exchanges, and the result is the rank-average of the accumulated gradients
+    for prescaled in (True, False):
+        red.prescaled = prescaled
+        for p in params:
+            p.grad = None
+        for micro in range(3):
+            red.sync = micro == 2
+            loss = sum((p * (rank + 1 + i + 10 * micro)).sum() for i, p in enumerate(params))
+            (loss * red.grad_scale if prescaled else loss).backward()
+            red.finalize()
+        for i, p in enumerate(params):
+            exp = sum(sum(r + 1 + i + 10 * micro for micro in range(3)) for r in range(world)) / world
+            assert torch.allclose(p.grad, torch.full_like(p, float(exp))), (rank, i, prescaled, p.grad[0].item(), exp)
+    red.sync, red.prescaled = True, False
     avg = average_scalars([torch.full((2, 3), float(rank)), torch.full((4,), 10.0 * rank)])
     assert torch.allclose(avg[0], torch.full((2, 3), 0.5)) and torch.allclose(avg[1], torch.full((4,), 5.0))
     out[rank] = 1
