@@ -283,6 +283,14 @@ int64_t ofb_crop_resize_scratch_bytes(int32_t B, int32_t out_size, int32_t max_s
 int ofb_crop_resize_norm(const uint8_t* src, const ofb_crop_param* params_dev, int32_t B, int32_t out_size, int32_t max_src_h,
                          const float* mean3, const float* std3, float* out, uint8_t* out_u8, uint8_t* scratch, void* stream);
 
+/* RandomErasing, mode 'pixel' (timm RandomErasing inside datasets.build_transform: --reprob 0.25 --remode pixel --recount 1,
+ * search.py:135-139): every element of x[b][:, top:top+h, left:left+w] becomes N(0, 1) noise (h == 0: sample untouched).
+ * Noise = Box-Muller on Philox4x32-10 words, key = seed, counter = (element index / 4, 0, b, 0); element index runs over
+ * (c, y, x) of the rectangle. */
+typedef struct ofb_erase_param { int32_t top, left, h, w; } ofb_erase_param;
+int ofb_random_erase(float* x, const ofb_erase_param* params_dev, int32_t B, int32_t C, int32_t H, int32_t W, uint64_t seed,
+                     void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -208,7 +208,59 @@ __global__ __launch_bounds__(256) void resize_v_norm_kernel(const uint8_t* __res
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// RandomErasing, mode 'pixel' (timm RandomErasing as built by datasets.build_transform: reprob 0.25, one rectangle per image,
+// every pixel of it replaced by N(0, 1) noise).  The rectangles are drawn on the host like the library does; the noise comes from
+// a counter-based generator so that no noise tensor crosses HBM: Philox4x32-10 keyed by (seed, sample), counter = element index
+// / 4, Box-Muller on the four 32-bit words.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&out)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c0, p1 = (unsigned long long)0xCD9E8D57u * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(unsigned x) { return ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f); }   // (0, 1)
+
+__global__ __launch_bounds__(256) void erase_kernel(float* __restrict__ x, const ofb_erase_param* __restrict__ params, int C, int H, int W,
+                                                    unsigned seed_lo, unsigned seed_hi) {
+  const int b = blockIdx.y;
+  const ofb_erase_param p = params[b];
+  if (p.h <= 0 || p.w <= 0) return;
+  const int n = C * p.h * p.w, groups = (n + 3) >> 2;
+  for (int gidx = blockIdx.x * 256 + threadIdx.x; gidx < groups; gidx += gridDim.x * 256) {
+    unsigned r[4];
+    philox4x32_10((unsigned)gidx, 0u, (unsigned)b, 0u, seed_lo, seed_hi, r);
+    float z[4];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const float rad = sqrtf(-2.0f * logf(u01(r[2 * k]))), ang = 6.28318530717958647692f * u01(r[2 * k + 1]);
+      z[2 * k] = rad * cosf(ang); z[2 * k + 1] = rad * sinf(ang);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int e = 4 * gidx + k;
+      if (e >= n) break;
+      const int c = e / (p.h * p.w), rem = e - c * p.h * p.w, yy = rem / p.w, xx = rem - yy * p.w;
+      x[(((size_t)b * C + c) * H + p.top + yy) * W + p.left + xx] = z[k];
+    }
+  }
+}
+
 }  // namespace
+
+extern "C" int ofb_random_erase(float* x, const ofb_erase_param* params_dev, int32_t B, int32_t C, int32_t H, int32_t W, uint64_t seed,
+                                void* stream) {
+  if (!x || !params_dev || B <= 0 || C <= 0 || H <= 0 || W <= 0) return OFB_EINVAL;
+  hipLaunchKernelGGL(erase_kernel, dim3(32, B), dim3(256), 0, (hipStream_t)stream, x, params_dev, C, H, W, (unsigned)seed,
+                     (unsigned)(seed >> 32));
+  return ofb_launch_status();
+}
 
 extern "C" int ofb_mixup_batch(float* x, const ofb_mix_param* params_dev, int32_t B, int32_t C, int32_t H, int32_t W, void* stream) {
   if (!x || !params_dev || B <= 0 || C <= 0 || H <= 0 || W <= 0) return OFB_EINVAL;

@@ -265,15 +265,64 @@ def center_crop_params(height, width, input_size=224):
     return int(round(top)), int(round(left)), int(round(side)), int(round(side))
 
 
+class RandomErasing:
+    """timm RandomErasing, mode 'pixel', on the normalized device batch (datasets.py:133-141: re_prob 0.25, re_count 1).  The
+    rectangle of every sample is drawn on the host with Python `random` in the library's order; the N(0, 1) fill is generated
+    inside the kernel (Philox4x32-10 + Box-Muller, keyed by `seed` and a per-call counter)."""
+
+    def __init__(self, probability=0.25, min_area=0.02, max_area=1 / 3, min_aspect=0.3, max_aspect=None, min_count=1, max_count=None,
+                 seed=0):
+        self.probability, self.min_area, self.max_area = probability, min_area, max_area
+        max_aspect = max_aspect or 1 / min_aspect
+        self.log_aspect_ratio = (math.log(min_aspect), math.log(max_aspect))
+        self.min_count, self.max_count = min_count, max_count or min_count
+        self.seed, self.calls = seed, 0
+        if self.min_count != 1 or self.max_count != 1:
+            raise NotImplementedError('one rectangle per image (the reference default --recount 1)')
+
+    def plan_one(self, img_h, img_w):
+        if random.random() > self.probability:
+            return (0, 0, 0, 0)
+        area = img_h * img_w
+        for _ in range(10):
+            target_area = random.uniform(self.min_area, self.max_area) * area
+            aspect_ratio = math.exp(random.uniform(*self.log_aspect_ratio))
+            h = int(round(math.sqrt(target_area * aspect_ratio)))
+            w = int(round(math.sqrt(target_area / aspect_ratio)))
+            if w < img_w and h < img_h:
+                top = random.randint(0, img_h - h)
+                left = random.randint(0, img_w - w)
+                return (top, left, h, w)
+        return (0, 0, 0, 0)
+
+    def __call__(self, x, plan=None):
+        if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() != 4:
+            raise hip.OfbError('RandomErasing expects a contiguous float32 NCHW device batch')
+        B, Cc, H, W = x.shape
+        plan = [self.plan_one(H, W) for _ in range(B)] if plan is None else plan
+        if not any(p[2] for p in plan):
+            return x
+        tab = (hip.EraseParam * B)()
+        for b, (top, left, h, w) in enumerate(plan):
+            tab[b].top, tab[b].left, tab[b].h, tab[b].w = top, left, h, w
+        dev_tab, host = hip.upload_structs(tab, x.device)
+        call_seed = (self.seed << 20) + self.calls
+        self.calls += 1
+        hip.random_erase(x, dev_tab, B, Cc, H, W, call_seed)
+        self._keep = (dev_tab, host)
+        return x
+
+
 class DeviceTransform:
     """uint8 HWC images -> normalized f32 NCHW batch on the device in two launches (resample rows, resample columns + flip +
     ToTensor + Normalize).  `images`: list of HxWx3 uint8 arrays / tensors (decoded elsewhere)."""
 
     def __init__(self, input_size=224, is_train=True, interpolation='bicubic', hflip=0.5, scale=(0.08, 1.0),
-                 ratio=(3. / 4., 4. / 3.), mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD, device='cuda'):
+                 ratio=(3. / 4., 4. / 3.), mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD, device='cuda', re_prob=0.0, seed=0):
         self.S, self.is_train, self.cubic = input_size, is_train, int(interpolation == 'bicubic')
         self.hflip, self.scale, self.ratio, self.mean, self.std = hflip, scale, ratio, tuple(mean), tuple(std)
         self.device = torch.device(device)
+        self.erase = RandomErasing(re_prob, seed=seed) if (is_train and re_prob > 0) else None
 
     def plan(self, sizes):
         out = []
@@ -313,6 +362,8 @@ class DeviceTransform:
         out = torch.empty(B, 3, self.S, self.S, device=self.device, dtype=torch.float32)
         out_u8 = torch.empty(B, 3, self.S, self.S, device=self.device, dtype=torch.uint8) if want_u8 else None
         hip.crop_resize_norm(src, dev_tab, B, self.S, max_h, self.mean, self.std, out, out_u8, scratch)
+        if self.erase is not None:
+            self.erase(out)
         self._keep = (dev_tab, host, flat, src, scratch)
         return (out, out_u8) if want_u8 else out
 

@@ -44,7 +44,7 @@ SYMBOLS = [
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets',
     'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
-    'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm',
+    'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm', 'ofb_random_erase',
 ]
 
 
@@ -368,3 +368,12 @@ def crop_resize_norm(src_u8, params_dev, B, S, max_src_h, mean, std, out, out_u8
     m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
     check(lib().ofb_crop_resize_norm(ptr(src_u8), ptr(params_dev), _i(B), _i(S), _i(max_src_h), m3, s3, ptr(out), ptr(out_u8), ptr(scratch),
                                      stream()), 'ofb_crop_resize_norm')
+
+
+class EraseParam(C.Structure):
+    _fields_ = [('top', C.c_int32), ('left', C.c_int32), ('h', C.c_int32), ('w', C.c_int32)]
+
+
+def random_erase(x, params_dev, B, Cc, H, W, seed):
+    check(lib().ofb_random_erase(ptr(_f32c(x, 'x')), ptr(params_dev), _i(B), _i(Cc), _i(H), _i(W), C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                 stream()), 'ofb_random_erase')

@@ -107,3 +107,27 @@ def test_eval_transform_and_loader():
     assert len(seen) == 3
     for (x, y), (ims, lab) in zip(seen, batches):
         assert torch.equal(x, tf2(ims).cpu()) and y.tolist() == lab
+
+
+def test_random_erasing_rectangles_and_noise():
+    import ofb_amd
+    x = torch.zeros(6, 3, 64, 48)
+    random.seed(11)
+    ref_plan = [DO.random_erasing_plan(64, 48, probability=0.7) for _ in range(6)]
+    random.seed(11)
+    er = ofb_amd.RandomErasing(probability=0.7, seed=5)
+    plan = [er.plan_one(64, 48) for _ in range(6)]
+    assert plan == ref_plan and any(p[2] for p in plan) and any(p[2] == 0 for p in plan)
+    xg = er(x.cuda().add_(7.0), plan=plan).cpu()
+    for b, (top, left, h, w) in enumerate(plan):
+        keep = torch.ones(3, 64, 48, dtype=torch.bool)
+        keep[:, top:top + h, left:left + w] = False
+        assert torch.equal(xg[b][keep], torch.full_like(xg[b][keep], 7.0)), b           # untouched outside the rectangle
+        if h:
+            got = xg[b][:, top:top + h, left:left + w].reshape(-1).double().numpy()
+            exp = DO.erase_noise(b, 3 * h * w, (5 << 20) + 0)
+            assert np.abs(got - exp).max() < 2e-5, (b, np.abs(got - exp).max())          # f32 log / sin / cos on the device
+    # the filled values are N(0, 1)
+    big = ofb_amd.RandomErasing(probability=1.0, seed=9)(torch.zeros(2, 3, 224, 224).cuda(), plan=[(0, 0, 200, 200)] * 2).cpu()
+    v = big[:, :, :200, :200].reshape(-1)
+    assert abs(float(v.mean())) < 0.01 and abs(float(v.std()) - 1.0) < 0.01

@@ -96,3 +96,16 @@ def test_data_entry_points_reject_cpu_tensors():
         ofb_amd.Mixup(0.8, 1.0, num_classes=5)(torch.zeros(4, 3, 8, 8), torch.zeros(4, dtype=torch.int64))
     with pytest.raises(hip.OfbError):
         ofb_amd.SoftTargetCrossEntropy()(torch.zeros(4, 5), torch.zeros(4, 5))
+
+
+def test_random_erasing_plan_follows_oracle_and_philox_reference():
+    import ofb_amd
+    random.seed(3)
+    a = [DO.random_erasing_plan(224, 224) for _ in range(40)]
+    random.seed(3)
+    er = ofb_amd.RandomErasing(0.25)
+    b = [er.plan_one(224, 224) for _ in range(40)]
+    assert a == b and 5 <= sum(1 for p in a if p[2]) <= 20
+    # Philox4x32-10 known-answer vectors (Random123 kat_vectors): counter 0 / key 0, and all ones
+    assert [int(v) for v in DO._philox4x32_10([0, 0, 0, 0], [0, 0])] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
+    assert [int(v) for v in DO._philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2)] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
