@@ -1,7 +1,4 @@
-"""Lab: per-phase cycle breakdown of the GEMM K-iteration from in-kernel s_memtime stamps (library built with -DOFB_GEMM_STAMPS).
-Stamps per iteration (wave 0 of workgroups 8 and 264, which share a CU only by luck): 0 top of iteration, 1 global loads issued,
-2 MFMAs issued (+ fragment reads waited), 3 prefetched tile arrived (vmcnt 0), 4 split + LDS writes done; the gap to the next
-iteration's stamp 0 is the barrier."""
+"""Lab: 3-stamp variant (top, loads issued, MFMA+staging block done) for the interleaved-staging loop."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
@@ -29,14 +26,14 @@ assert lib.ofb_diag_gemm_stamps(buf) == 0
 a = np.frombuffer(buf, dtype=np.uint64).astype(np.int64).reshape(2, 4096)
 for wg in range(2):
     s = a[wg][a[wg] > 0]
-    n = (len(s) // 5) * 5
-    s = s[:n].reshape(-1, 5)
-    d = np.diff(s, axis=1)                       # 0->1 load issue, 1->2 reads+MFMA, 2->3 vmcnt wait, 3->4 split+write
-    bar = s[1:, 0] - s[:-1, 4]                   # barrier (+ loop overhead)
+    n = (len(s) // 3) * 3
+    s = s[:n].reshape(-1, 3)
+    d = np.diff(s, axis=1)
+    bar = s[1:, 0] - s[:-1, 2]
     it = s[1:, 0] - s[:-1, 0]
-    ok = it < 20000                              # drop tile boundaries (epilogue)
-    span = int(s[-1, 4] - s[0, 0])
+    ok = it < 20000
+    span = int(s[-1, 2] - s[0, 0])
     print(f'wg {wg}: iterations {len(s)}  per-iteration cycles median {np.median(it[ok]):.0f};  first->last stamp {span} ticks = {span / wall_us / 1e3:.2f} GHz-equivalent over ~the whole launch')
-    for name, col in zip(['issue global loads', 'fragment reads + 24 MFMA', 'wait prefetched tile', 'split + ds_write'], d[:-1].T):
+    for name, col in zip(['issue global loads', 'reads + MFMA + staging'], d[:-1].T):
         print(f'   {name:28s} median {np.median(col[ok]):7.0f}   mean {col[ok].mean():7.0f}')
-    print(f'   {"barrier":28s} median {np.median(bar[ok]):7.0f}   mean {bar[ok].mean():7.0f}')
+    print(f'   {"epilogue/barrier":28s} median {np.median(bar[ok]):7.0f}   mean {bar[ok].mean():7.0f}')
