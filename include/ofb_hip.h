@@ -291,6 +291,25 @@ typedef struct ofb_erase_param { int32_t top, left, h, w; } ofb_erase_param;
 int ofb_random_erase(float* x, const ofb_erase_param* params_dev, int32_t B, int32_t C, int32_t H, int32_t W, uint64_t seed,
                      void* stream);
 
+/* RandAugment (timm rand_augment_transform('rand-m9-mstd0.5-inc1'): the reference's default --aa, search.py:123, applied by
+ * datasets.build_transform between the flip and ToTensor): ONE layer of it on uint8 CHW images [B][3][H][W], one op per image
+ * (Pillow semantics: ImageOps / ImageEnhance / Image.transform), in != out.
+ *   op 0 none, 1 AutoContrast, 2 Equalize, 3 Invert, 4 Posterize (iarg = bits), 5 Solarize (iarg = threshold), 6 SolarizeAdd (iarg = add,
+ *   threshold 128), 7 Color, 8 Contrast, 9 Brightness, 10 Sharpness (farg = factor of Image.blend(degenerate, image, factor)),
+ *   11 affine warp Image.transform(size, AFFINE, m, resample = iarg (0 nearest, 2 bilinear, 3 bicubic), fillcolor = fill): Rotate,
+ *   ShearX / ShearY, TranslateXRel / TranslateYRel.
+ * hist_scratch: B*768 int32, lsum_scratch: B uint64 (per-image channel histograms and luma sum, recomputed by every call).
+ * ofb_normalize_u8: ToTensor + Normalize, out[b][c][y][x] = ((v / 255) - mean[c]) / std[c] (mean3 / std3: HOST arrays). */
+typedef struct ofb_aug_op {
+  int32_t op, iarg;
+  float farg;
+  int32_t fill[3];
+  double m[6];
+} ofb_aug_op;
+int ofb_randaug_layer(const uint8_t* in, uint8_t* out, const ofb_aug_op* ops_dev, int32_t B, int32_t H, int32_t W, int32_t* hist_scratch,
+                      uint64_t* lsum_scratch, void* stream);
+int ofb_normalize_u8(const uint8_t* in, float* out, int32_t B, int32_t H, int32_t W, const float* mean3, const float* std3, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

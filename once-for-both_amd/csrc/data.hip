@@ -252,7 +252,189 @@ __global__ __launch_bounds__(256) void erase_kernel(float* __restrict__ x, const
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// RandAugment (timm rand_augment_transform('rand-m9-mstd0.5-inc1'), the reference's default --aa, search.py:123) on uint8 CHW images:
+// one op per image and layer, Pillow semantics (ImageOps / ImageEnhance / Image.transform), checked against Pillow in the tests.
+//   1 AutoContrast  2 Equalize  3 Invert  4 Posterize(iarg bits)  5 Solarize(iarg threshold)  6 SolarizeAdd(iarg add, threshold 128)
+//   7 Color  8 Contrast  9 Brightness  10 Sharpness (farg factor: Image.blend(degenerate, image, factor))
+//   11 Affine (m[6], iarg = resample 0 nearest / 2 bilinear / 3 bicubic; fill = fill_rgb): Rotate / ShearX / ShearY / TranslateX / Y
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int luma(int r, int g, int b) { return (r * 19595 + g * 38470 + b * 7471 + 0x8000) >> 16; }   // PIL RGB -> L
+
+// per image: histogram of every channel (int32 [3][256]) and the sum of L
+__global__ __launch_bounds__(256) void aug_stats_kernel(const uint8_t* __restrict__ img, int HW, int* __restrict__ hist, unsigned long long* __restrict__ lsum) {
+  __shared__ int h[768];
+  __shared__ unsigned long long ls[4];
+  const int b = blockIdx.x, t = threadIdx.x;
+  for (int i = t; i < 768; i += 256) h[i] = 0;
+  __syncthreads();
+  const uint8_t* p = img + (size_t)b * 3 * HW;
+  unsigned long long acc = 0;
+  for (int i = t; i < HW; i += 256) {
+    const int r = p[i], g = p[HW + i], bl = p[2 * HW + i];
+    atomicAdd(&h[r], 1); atomicAdd(&h[256 + g], 1); atomicAdd(&h[512 + bl], 1);
+    acc += (unsigned long long)luma(r, g, bl);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if ((t & 63) == 0) ls[t >> 6] = acc;
+  __syncthreads();
+  for (int i = t; i < 768; i += 256) hist[(size_t)b * 768 + i] = h[i];
+  if (t == 0) lsum[b] = ls[0] + ls[1] + ls[2] + ls[3];
+}
+
+__device__ __forceinline__ uint8_t blend8(int degenerate, int image, float alpha) {      // PIL ImagingBlend
+  const float temp = (float)degenerate + mul_rn(alpha, (float)(image - degenerate));
+  if (alpha >= 0.f && alpha <= 1.f) return (uint8_t)temp;
+  if (temp <= 0.f) return 0;
+  if (temp >= 255.f) return 255;
+  return (uint8_t)temp;
+}
+__device__ __forceinline__ int xclip(int v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+// Pillow Geometry.c BICUBIC (the transform filter, not the resize filter): v2 + d(-v1 + v3) + d^2(2(v1 - v2) + v3 - v4) + d^3(-v1 + v2 - v3 + v4)
+__device__ __forceinline__ double pil_cubic(double v1, double v2, double v3, double v4, double d) {
+  const double p1 = v2, p2 = -v1 + v3, p3 = 2 * (v1 - v2) + v3 - v4, p4 = -v1 + v2 - v3 + v4;
+  return p1 + d * (p2 + d * (p3 + d * p4));
+}
+
+__global__ __launch_bounds__(256) void aug_apply_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, const ofb_aug_op* __restrict__ ops,
+                                                        const int* __restrict__ hist, const unsigned long long* __restrict__ lsum, int H, int W) {
+  __shared__ uint8_t lut[768];
+  __shared__ int s_mean;
+  const int b = blockIdx.y, t = threadIdx.x, HW = H * W;
+  const ofb_aug_op op = ops[b];
+  const uint8_t* src = in + (size_t)b * 3 * HW;
+  uint8_t* dst = out + (size_t)b * 3 * HW;
+  const bool use_lut = op.op >= 1 && op.op <= 6;
+  if (use_lut) {
+    if (op.op == 1 || op.op == 2) {
+      if (t < 3) {
+        const int* h = hist + (size_t)b * 768 + 256 * t;
+        uint8_t* l = lut + 256 * t;
+        if (op.op == 1) {                                   // ImageOps.autocontrast, cutoff 0
+          int lo = 0, hi = 255;
+          while (lo < 256 && h[lo] == 0) ++lo;
+          while (hi >= 0 && h[hi] == 0) --hi;
+          if (hi <= lo) { for (int i = 0; i < 256; ++i) l[i] = (uint8_t)i; }
+          else {
+            const double scale = 255.0 / (double)(hi - lo), offset = -(double)lo * scale;
+            for (int i = 0; i < 256; ++i) { int v = (int)((double)i * scale + offset); l[i] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+          }
+        } else {                                            // ImageOps.equalize
+          int nz = 0, last = 0; long long total = 0;
+          for (int i = 0; i < 256; ++i) if (h[i]) { ++nz; last = h[i]; total += h[i]; }
+          const long long step = nz <= 1 ? 0 : (total - last) / 255;
+          if (step == 0) { for (int i = 0; i < 256; ++i) l[i] = (uint8_t)i; }
+          else {
+            long long n = step / 2;
+            for (int i = 0; i < 256; ++i) { const long long q = n / step; l[i] = (uint8_t)(q > 255 ? 255 : q); n += h[i]; }   // Image.point clips the table to 8 bits
+          }
+        }
+      }
+    } else {
+      for (int i = t; i < 768; i += 256) {
+        const int v = i & 255;
+        int o = v;
+        if (op.op == 3) o = 255 - v;
+        else if (op.op == 4) o = v & ~((1 << (8 - op.iarg)) - 1);
+        else if (op.op == 5) o = v < op.iarg ? v : 255 - v;
+        else if (op.op == 6) o = v < 128 ? min(255, v + op.iarg) : v;
+        lut[i] = (uint8_t)o;
+      }
+    }
+  }
+  if (op.op == 8 && t == 0) s_mean = (int)((double)lsum[b] / (double)HW + 0.5);      // int(ImageStat.Stat(L).mean[0] + 0.5)
+  __syncthreads();
+  const float k1 = 1.f / 13.f, k5 = 5.f / 13.f;              // ImageFilter.SMOOTH, kernel / 13 in float32
+  for (int i = blockIdx.x * 256 + t; i < HW; i += gridDim.x * 256) {
+    const int y = i / W, x = i - y * W;
+    int px[3] = {src[i], src[HW + i], src[2 * HW + i]};
+    int o[3];
+    if (op.op == 0) { o[0] = px[0]; o[1] = px[1]; o[2] = px[2]; }
+    else if (use_lut) { o[0] = lut[px[0]]; o[1] = lut[256 + px[1]]; o[2] = lut[512 + px[2]]; }
+    else if (op.op == 7) { const int g = luma(px[0], px[1], px[2]); for (int c = 0; c < 3; ++c) o[c] = blend8(g, px[c], op.farg); }
+    else if (op.op == 8) { for (int c = 0; c < 3; ++c) o[c] = blend8(s_mean, px[c], op.farg); }
+    else if (op.op == 9) { for (int c = 0; c < 3; ++c) o[c] = blend8(0, px[c], op.farg); }
+    else if (op.op == 10) {
+      for (int c = 0; c < 3; ++c) {
+        int d = px[c];
+        if (y > 0 && y < H - 1 && x > 0 && x < W - 1) {       // ImagingFilter3x3: rows y+1, y, y-1; borders copied
+          const uint8_t* pc = src + (size_t)c * HW;
+          float ss = 0.5f;
+          ss += mul_rn((float)pc[i + W - 1], k1) + mul_rn((float)pc[i + W], k1) + mul_rn((float)pc[i + W + 1], k1);
+          ss += mul_rn((float)pc[i - 1], k1) + mul_rn((float)pc[i], k5) + mul_rn((float)pc[i + 1], k1);
+          ss += mul_rn((float)pc[i - W - 1], k1) + mul_rn((float)pc[i - W], k1) + mul_rn((float)pc[i - W + 1], k1);
+          d = ss <= 0.f ? 0 : (ss >= 255.f ? 255 : (int)ss);
+        }
+        o[c] = blend8(d, px[c], op.farg);
+      }
+    } else {                                                 // 11: Image.transform(size, AFFINE, m, resample, fillcolor)
+      const double xin0 = op.m[0] * (x + 0.5) + op.m[1] * (y + 0.5) + op.m[2], yin0 = op.m[3] * (x + 0.5) + op.m[4] * (y + 0.5) + op.m[5];
+      const bool inside = xin0 >= 0.0 && xin0 < (double)W && yin0 >= 0.0 && yin0 < (double)H;
+      for (int c = 0; c < 3; ++c) {
+        const uint8_t* pc = src + (size_t)c * HW;
+        int v = op.fill[c];
+        if (inside) {
+          if (op.iarg == 0) {
+            v = pc[(int)yin0 * W + (int)xin0];
+          } else if (op.iarg == 2) {
+            const double xin = xin0 - 0.5, yin = yin0 - 0.5;
+            const int xf = (int)floor(xin), yf = (int)floor(yin);
+            const double dx = xin - xf, dy = yin - yf;
+            const int x0 = xclip(xf, W), x1 = xclip(xf + 1, W), y0 = xclip(yf, H), y1 = xclip(yf + 1, H);
+            const double v1 = pc[y0 * W + x0] + dx * ((double)pc[y0 * W + x1] - pc[y0 * W + x0]);
+            const double v2 = pc[y1 * W + x0] + dx * ((double)pc[y1 * W + x1] - pc[y1 * W + x0]);
+            const double r = v1 + dy * (v2 - v1);
+            v = (int)r;
+          } else {
+            const double xin = xin0 - 0.5, yin = yin0 - 0.5;
+            const int xf = (int)floor(xin), yf = (int)floor(yin);
+            const double dx = xin - xf, dy = yin - yf;
+            double rows[4];
+            for (int ky = 0; ky < 4; ++ky) {
+              const uint8_t* pr = pc + xclip(yf - 1 + ky, H) * W;
+              rows[ky] = pil_cubic(pr[xclip(xf - 1, W)], pr[xclip(xf, W)], pr[xclip(xf + 1, W)], pr[xclip(xf + 2, W)], dx);
+            }
+            const double r = pil_cubic(rows[0], rows[1], rows[2], rows[3], dy);
+            v = r <= 0.0 ? 0 : (r >= 255.0 ? 255 : (int)r);
+          }
+        }
+        o[c] = v;
+      }
+    }
+    dst[i] = (uint8_t)o[0]; dst[HW + i] = (uint8_t)o[1]; dst[2 * HW + i] = (uint8_t)o[2];
+  }
+}
+
+// ToTensor + Normalize of uint8 CHW pixels
+__global__ __launch_bounds__(256) void normalize_u8_kernel(const uint8_t* __restrict__ in, float* __restrict__ out, int64_t n_per_chan, int64_t total, float m0, float m1,
+                                                           float m2, float s0, float s1, float s2) {
+  const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)((i / n_per_chan) % 3);
+    out[i] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)in[i], 255.f), mean[c]), sd[c]);
+  }
+}
+
 }  // namespace
+
+extern "C" int ofb_randaug_layer(const uint8_t* in, uint8_t* out, const ofb_aug_op* ops_dev, int32_t B, int32_t H, int32_t W, int32_t* hist_scratch,
+                                 uint64_t* lsum_scratch, void* stream) {
+  if (!in || !out || in == out || !ops_dev || !hist_scratch || !lsum_scratch || B <= 0 || H <= 2 || W <= 2) return OFB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(aug_stats_kernel, dim3(B), dim3(256), 0, s, in, H * W, hist_scratch, (unsigned long long*)lsum_scratch);
+  hipLaunchKernelGGL(aug_apply_kernel, dim3(16, B), dim3(256), 0, s, in, out, ops_dev, (const int*)hist_scratch, (const unsigned long long*)lsum_scratch, H, W);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_normalize_u8(const uint8_t* in, float* out, int32_t B, int32_t H, int32_t W, const float* mean3, const float* std3, void* stream) {
+  if (!in || !out || !mean3 || !std3 || B <= 0 || H <= 0 || W <= 0) return OFB_EINVAL;
+  const int64_t total = (int64_t)B * 3 * H * W;
+  int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+  hipLaunchKernelGGL(normalize_u8_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, out, (int64_t)H * W, total, mean3[0], mean3[1], mean3[2], std3[0],
+                     std3[1], std3[2]);
+  return ofb_launch_status();
+}
 
 extern "C" int ofb_random_erase(float* x, const ofb_erase_param* params_dev, int32_t B, int32_t C, int32_t H, int32_t W, uint64_t seed,
                                 void* stream) {

@@ -313,16 +313,145 @@ class RandomErasing:
         return x
 
 
+# -----------------------------------------------------------------------------------------------------------------
+# RandAugment 'rand-m9-mstd0.5-inc1' (timm auto_augment.rand_augment_transform as configured by datasets.build_transform:
+# --aa default, search.py:123) - the op choice / magnitude draws on the host in timm's order, the pixels on the GPU
+# -----------------------------------------------------------------------------------------------------------------
+_MAX_LEVEL = 10.
+RAND_INCREASING_TRANSFORMS = ['AutoContrast', 'Equalize', 'Invert', 'Rotate', 'PosterizeIncreasing', 'SolarizeIncreasing', 'SolarizeAdd',
+                              'ColorIncreasing', 'ContrastIncreasing', 'BrightnessIncreasing', 'SharpnessIncreasing', 'ShearX', 'ShearY',
+                              'TranslateXRel', 'TranslateYRel']
+_OP_CODE = dict(AutoContrast=1, Equalize=2, Invert=3, PosterizeIncreasing=4, SolarizeIncreasing=5, SolarizeAdd=6, ColorIncreasing=7,
+                ContrastIncreasing=8, BrightnessIncreasing=9, SharpnessIncreasing=10)
+_PIL_RESAMPLE = dict(nearest=0, bilinear=2, bicubic=3)
+
+
+def _randomly_negate(v):
+    return -v if random.random() > 0.5 else v
+
+
+def rotate_matrix(degrees, w, h):
+    """Pillow Image.rotate(angle) -> the AFFINE matrix it hands to transform() (expand = False, centre = image centre)."""
+    angle = degrees % 360.0
+    angle = -math.radians(angle)
+    matrix = [round(math.cos(angle), 15), round(math.sin(angle), 15), 0.0, round(-math.sin(angle), 15), round(math.cos(angle), 15), 0.0]
+
+    def transform(x, y, m):
+        a, b, c, d, e, f = m
+        return a * x + b * y + c, d * x + e * y + f
+
+    cx, cy = w / 2.0, h / 2.0
+    matrix[2], matrix[5] = transform(-cx, -cy, matrix)
+    matrix[2] += cx
+    matrix[5] += cy
+    return matrix
+
+
+class RandAugment:
+    """`rand_augment_transform('rand-m{m}-mstd{s}-inc1', hparams)`: `num_layers` ops per image drawn with np.random.choice (uniform,
+    with replacement), each applied with probability 0.5 at a Gaussian-jittered magnitude.  `plan(B, H, W)` returns, per layer, the
+    list of per-image (op, iarg, farg, matrix) records; `__call__` runs them on a uint8 NCHW device batch."""
+
+    def __init__(self, magnitude=9, magnitude_std=0.5, num_layers=2, prob=0.5, img_mean=IMAGENET_DEFAULT_MEAN, interpolation='bicubic',
+                 translate_pct=0.45):
+        self.magnitude, self.magnitude_std, self.num_layers, self.prob = magnitude, magnitude_std, num_layers, prob
+        self.fill = tuple(min(255, round(255 * x)) for x in img_mean)
+        self.interpolation = interpolation                    # 'random' -> random.choice((bilinear, bicubic)) per op, like timm
+        self.translate_pct = translate_pct
+        self.names = list(RAND_INCREASING_TRANSFORMS)
+
+    def _resample(self):
+        if self.interpolation == 'random':
+            return random.choice((_PIL_RESAMPLE['bilinear'], _PIL_RESAMPLE['bicubic']))
+        return _PIL_RESAMPLE[self.interpolation]
+
+    def _one(self, name, H, W):
+        """AugmentOp.__call__ for one image: (op code, iarg, farg, matrix | None); op 0 = not applied."""
+        if self.prob < 1.0 and random.random() > self.prob:
+            return (0, 0, 0.0, None)
+        magnitude = self.magnitude
+        if self.magnitude_std > 0:
+            magnitude = random.gauss(magnitude, self.magnitude_std)
+        magnitude = min(_MAX_LEVEL, max(0, magnitude))
+        lv = magnitude / _MAX_LEVEL
+        if name in ('AutoContrast', 'Equalize', 'Invert'):
+            return (_OP_CODE[name], 0, 0.0, None)
+        if name == 'PosterizeIncreasing':
+            return (4, 4 - int(lv * 4), 0.0, None)
+        if name == 'SolarizeIncreasing':
+            return (5, 256 - int(lv * 256), 0.0, None)
+        if name == 'SolarizeAdd':
+            return (6, int(lv * 110), 0.0, None)
+        if name in ('ColorIncreasing', 'ContrastIncreasing', 'BrightnessIncreasing', 'SharpnessIncreasing'):
+            return (_OP_CODE[name], 0, 1.0 + _randomly_negate(lv * .9), None)
+        if name == 'Rotate':
+            deg = _randomly_negate(lv * 30.)
+            return (11, self._resample(), 0.0, rotate_matrix(deg, W, H))
+        if name in ('ShearX', 'ShearY'):
+            f = _randomly_negate(lv * 0.3)
+            m = [1, f, 0, 0, 1, 0] if name == 'ShearX' else [1, 0, 0, f, 1, 0]
+            return (11, self._resample(), 0.0, [float(v) for v in m])
+        if name in ('TranslateXRel', 'TranslateYRel'):
+            pct = _randomly_negate(lv * self.translate_pct)
+            m = [1, 0, pct * W, 0, 1, 0] if name == 'TranslateXRel' else [1, 0, 0, 0, 1, pct * H]
+            return (11, self._resample(), 0.0, [float(v) for v in m])
+        raise ValueError(name)
+
+    def plan(self, B, H, W):
+        per_image = []
+        for _ in range(B):
+            names = np.random.choice(self.names, self.num_layers, replace=True)
+            per_image.append([self._one(str(n), H, W) for n in names])
+        return [[per_image[b][l] for b in range(B)] for l in range(self.num_layers)]
+
+    def __call__(self, x_u8, plan=None):
+        if x_u8.dtype != torch.uint8 or not x_u8.is_contiguous() or x_u8.dim() != 4 or x_u8.shape[1] != 3:
+            raise hip.OfbError('RandAugment expects a contiguous uint8 N x 3 x H x W device batch')
+        B, _, H, W = x_u8.shape
+        plan = self.plan(B, H, W) if plan is None else plan
+        hist = torch.empty(B * 768, device=x_u8.device, dtype=torch.int32)
+        lsum = torch.empty(B, device=x_u8.device, dtype=torch.int64)
+        cur, other, keep = x_u8, torch.empty_like(x_u8), []
+        for layer in plan:
+            if not any(rec[0] for rec in layer):
+                continue
+            tab = (hip.AugOp * B)()
+            for b, (op, iarg, farg, m) in enumerate(layer):
+                t = tab[b]
+                t.op, t.iarg, t.farg = op, iarg, farg
+                t.fill[0], t.fill[1], t.fill[2] = self.fill
+                for k in range(6):
+                    t.m[k] = m[k] if m is not None else 0.0
+            dev_tab, host = hip.upload_structs(tab, x_u8.device)
+            hip.randaug_layer(cur, other, dev_tab, B, H, W, hist, lsum)
+            keep.append((dev_tab, host))
+            cur, other = other, cur
+        self._keep = (keep, hist, lsum, other)
+        return cur
+
+
 class DeviceTransform:
     """uint8 HWC images -> normalized f32 NCHW batch on the device in two launches (resample rows, resample columns + flip +
     ToTensor + Normalize).  `images`: list of HxWx3 uint8 arrays / tensors (decoded elsewhere)."""
 
     def __init__(self, input_size=224, is_train=True, interpolation='bicubic', hflip=0.5, scale=(0.08, 1.0),
-                 ratio=(3. / 4., 4. / 3.), mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD, device='cuda', re_prob=0.0, seed=0):
+                 ratio=(3. / 4., 4. / 3.), mean=IMAGENET_DEFAULT_MEAN, std=IMAGENET_DEFAULT_STD, device='cuda', re_prob=0.0, seed=0,
+                 auto_augment=None):
         self.S, self.is_train, self.cubic = input_size, is_train, int(interpolation == 'bicubic')
         self.hflip, self.scale, self.ratio, self.mean, self.std = hflip, scale, ratio, tuple(mean), tuple(std)
         self.device = torch.device(device)
         self.erase = RandomErasing(re_prob, seed=seed) if (is_train and re_prob > 0) else None
+        # auto_augment='rand-m9-mstd0.5-inc1' (the reference default): RandAugment between the flip and ToTensor, as timm orders them
+        self.randaug = None
+        if is_train and auto_augment:
+            cfg = {}
+            for part in auto_augment.split('-')[1:]:                 # timm: key = leading letters, value = the number after them
+                key = part.rstrip('0123456789.')
+                cfg[key] = part[len(key):]
+            if not auto_augment.startswith('rand') or cfg.get('inc', '0') in ('0', ''):
+                raise NotImplementedError('only the increasing RandAugment family (rand-m*-mstd*-inc1) is built')
+            self.randaug = RandAugment(magnitude=int(cfg.get('m', 10)), magnitude_std=float(cfg.get('mstd', 0)), img_mean=mean,
+                                       interpolation=interpolation)
 
     def plan(self, sizes):
         out = []
@@ -361,7 +490,14 @@ class DeviceTransform:
         scratch = torch.empty(hip.crop_resize_scratch_bytes(B, self.S, max_h), device=self.device, dtype=torch.uint8)
         out = torch.empty(B, 3, self.S, self.S, device=self.device, dtype=torch.float32)
         out_u8 = torch.empty(B, 3, self.S, self.S, device=self.device, dtype=torch.uint8) if want_u8 else None
-        hip.crop_resize_norm(src, dev_tab, B, self.S, max_h, self.mean, self.std, out, out_u8, scratch)
+        if self.randaug is not None:
+            # crop / resize / flip to uint8, RandAugment on the bytes, then ToTensor + Normalize
+            out_u8 = torch.empty(B, 3, self.S, self.S, device=self.device, dtype=torch.uint8)
+            hip.crop_resize_norm(src, dev_tab, B, self.S, max_h, self.mean, self.std, None, out_u8, scratch)
+            out_u8 = self.randaug(out_u8)
+            hip.normalize_u8(out_u8, out, B, self.S, self.S, self.mean, self.std)
+        else:
+            hip.crop_resize_norm(src, dev_tab, B, self.S, max_h, self.mean, self.std, out, out_u8, scratch)
         if self.erase is not None:
             self.erase(out)
         self._keep = (dev_tab, host, flat, src, scratch)

@@ -45,6 +45,7 @@ SYMBOLS = [
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets',
     'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
     'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm', 'ofb_random_erase',
+    'ofb_randaug_layer', 'ofb_normalize_u8',
 ]
 
 
@@ -377,3 +378,18 @@ class EraseParam(C.Structure):
 def random_erase(x, params_dev, B, Cc, H, W, seed):
     check(lib().ofb_random_erase(ptr(_f32c(x, 'x')), ptr(params_dev), _i(B), _i(Cc), _i(H), _i(W), C.c_uint64(int(seed) & (2 ** 64 - 1)),
                                  stream()), 'ofb_random_erase')
+
+
+class AugOp(C.Structure):
+    _fields_ = [('op', C.c_int32), ('iarg', C.c_int32), ('farg', C.c_float), ('fill', C.c_int32 * 3), ('m', C.c_double * 6)]
+
+
+def randaug_layer(src_u8, dst_u8, ops_dev, B, H, W, hist, lsum):
+    if src_u8.dtype != torch.uint8 or dst_u8.dtype != torch.uint8 or hist.dtype != torch.int32 or lsum.dtype != torch.int64:
+        raise OfbError('randaug_layer: uint8 images, int32 histogram scratch, int64 luma scratch')
+    check(lib().ofb_randaug_layer(ptr(src_u8), ptr(dst_u8), ptr(ops_dev), _i(B), _i(H), _i(W), ptr(hist), ptr(lsum), stream()), 'ofb_randaug_layer')
+
+
+def normalize_u8(src_u8, out, B, H, W, mean, std):
+    m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    check(lib().ofb_normalize_u8(ptr(src_u8), ptr(_f32c(out, 'out')), _i(B), _i(H), _i(W), m3, s3, stream()), 'ofb_normalize_u8')

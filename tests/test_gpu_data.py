@@ -131,3 +131,68 @@ def test_random_erasing_rectangles_and_noise():
     big = ofb_amd.RandomErasing(probability=1.0, seed=9)(torch.zeros(2, 3, 224, 224).cuda(), plan=[(0, 0, 200, 200)] * 2).cpu()
     v = big[:, :, :200, :200].reshape(-1)
     assert abs(float(v.mean())) < 0.01 and abs(float(v.std()) - 1.0) < 0.01
+
+
+def _test_images(B, H, W, seed):
+    from PIL import Image
+    rng = np.random.default_rng(seed)
+    out = []
+    for b in range(B):
+        if b % 3 == 0:
+            a = rng.integers(0, 256, size=(H, W, 3), dtype=np.uint8)                        # noise
+        elif b % 3 == 1:
+            low = rng.integers(0, 256, size=(H // 8 + 1, W // 8 + 1, 3), dtype=np.uint8)      # smooth
+            a = np.asarray(Image.fromarray(low).resize((W, H), Image.BICUBIC))
+        else:
+            yy, xx = np.mgrid[0:H, 0:W]                                                       # narrow-range gradients (autocontrast / equalize)
+            a = np.stack([40 + yy * 100 // H, 90 + xx * 60 // W, 10 + (yy + xx) * 200 // (H + W)], -1).astype(np.uint8)
+        out.append(np.ascontiguousarray(a.transpose(2, 0, 1)))
+    return np.ascontiguousarray(np.stack(out))
+
+
+@pytest.mark.parametrize('name', DO._RA_NAMES)
+def test_randaugment_each_op_matches_pillow(name):
+    """every op of the increasing RandAugment set at several magnitudes, both signs, against Pillow's own result."""
+    import ofb_amd
+    from PIL import Image
+    imgs = _test_images(6, 96, 80, 3)
+    ra = ofb_amd.RandAugment(prob=1.0, magnitude_std=0.0)
+    geometric = name in ('Rotate', 'ShearX', 'ShearY', 'TranslateXRel', 'TranslateYRel')
+    for level in (0.0, 2.5, 9.0, 10.0):
+        for sign in (1, -1):
+            for resample in ((3, 2) if geometric else (3,)):
+                ra.magnitude, ra.interpolation = level, {3: 'bicubic', 2: 'bilinear'}[resample]
+                real = random.random
+                random.random = lambda: 0.9 if sign < 0 else 0.1                              # _randomly_negate: > 0.5 negates
+                try:
+                    rec = [ra._one(name, 96, 80) for _ in range(6)]
+                finally:
+                    random.random = real
+                got = ra(torch.from_numpy(imgs).cuda(), plan=[rec]).cpu().numpy()
+                for b in range(6):
+                    pil = Image.fromarray(np.ascontiguousarray(imgs[b].transpose(1, 2, 0)))
+                    exp = np.asarray(DO.ra_apply(pil, name, level, ra.fill, resample, lambda v: -v if sign < 0 else v)).transpose(2, 0, 1)
+                    d = np.abs(got[b].astype(int) - exp.astype(int))
+                    if geometric:
+                        # Pillow walks the source coordinate incrementally in fixed point for some paths; a sample that lands within
+                        # rounding of a pixel edge may differ: allow isolated one-step differences
+                        assert d.max() <= 1 and (d > 0).mean() < 0.01, (name, level, sign, resample, b, d.max(), (d > 0).mean())
+                    else:
+                        assert d.max() == 0, (name, level, sign, b, d.max(), (d > 0).mean())
+
+
+def test_randaugment_pipeline_follows_timm_draws():
+    """whole RandAugment (op choice by np.random.choice, magnitudes / signs / skips by `random`) against the Pillow restatement."""
+    import ofb_amd
+    imgs = _test_images(12, 64, 64, 5)
+    random.seed(21); np.random.seed(21)
+    exp = DO.rand_augment(imgs)
+    random.seed(21); np.random.seed(21)
+    got = ofb_amd.RandAugment()(torch.from_numpy(imgs).cuda()).cpu().numpy()
+    d = np.abs(got.astype(int) - exp.astype(int))
+    assert d.max() <= 1 and (d > 0).mean() < 0.01, (d.max(), (d > 0).mean())
+    assert (got != imgs).any()
+    # and inside the training transform: crop / flip / RandAugment / normalize / erase run end to end
+    tf = ofb_amd.DeviceTransform(64, True, 'bicubic', auto_augment='rand-m9-mstd0.5-inc1', re_prob=0.25)
+    x = tf([np.ascontiguousarray(im.transpose(1, 2, 0)) for im in imgs])
+    assert x.shape == (12, 3, 64, 64) and bool(torch.isfinite(x).all())

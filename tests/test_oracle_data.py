@@ -109,3 +109,23 @@ def test_random_erasing_plan_follows_oracle_and_philox_reference():
     # Philox4x32-10 known-answer vectors (Random123 kat_vectors): counter 0 / key 0, and all ones
     assert [int(v) for v in DO._philox4x32_10([0, 0, 0, 0], [0, 0])] == [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]
     assert [int(v) for v in DO._philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2)] == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
+
+
+def test_randaugment_plan_consumes_draws_like_the_pillow_restatement():
+    """host logic: op choice (np.random.choice) and magnitude / sign / skip draws (`random`) leave both generators in the same state as
+    the timm restatement that runs the ops on Pillow, and the aa string of the reference parses."""
+    import ofb_amd
+    imgs = np.zeros((5, 3, 32, 32), np.uint8)
+    random.seed(8); np.random.seed(8)
+    DO.rand_augment(imgs)
+    s_py, s_np = random.getstate(), np.random.get_state()[1][:6].copy()
+    random.seed(8); np.random.seed(8)
+    plan = ofb_amd.RandAugment().plan(5, 32, 32)
+    assert random.getstate() == s_py and (np.random.get_state()[1][:6] == s_np).all()
+    assert len(plan) == 2 and all(len(layer) == 5 for layer in plan)
+    with pytest.raises(ofb_amd.hip.OfbError):
+        ofb_amd.RandAugment()(torch.zeros(2, 3, 8, 8, dtype=torch.uint8))          # CPU tensor: no fallback
+    with pytest.raises(NotImplementedError):
+        ofb_amd.DeviceTransform(224, True, auto_augment='original', device='cpu')
+    tf = ofb_amd.DeviceTransform(224, True, auto_augment='rand-m9-mstd0.5-inc1', device='cpu')
+    assert tf.randaug.magnitude == 9 and tf.randaug.magnitude_std == 0.5 and tf.randaug.fill == (124, 116, 104)
