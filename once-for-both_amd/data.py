@@ -466,20 +466,34 @@ class DeviceTransform:
         return out
 
     def __call__(self, images, plan=None, want_u8=False):
-        imgs = [torch.from_numpy(np.array(im, copy=True)) if not torch.is_tensor(im) else im.contiguous() for im in images]
-        sizes = [(int(t.shape[0]), int(t.shape[1])) for t in imgs]
+        # pack the decoded images into ONE pinned staging buffer (two of them, used alternately, so the copy of the previous batch may
+        # still be in flight) with plain numpy copies, then one asynchronous H2D transfer
+        arrs = [im.numpy() if torch.is_tensor(im) else np.asarray(im) for im in images]
+        sizes = [(int(a.shape[0]), int(a.shape[1])) for a in arrs]
         plan = self.plan(sizes) if plan is None else plan
-        B = len(imgs)
+        B = len(arrs)
         offs, total = [], 0
-        for t in imgs:
-            if t.dtype != torch.uint8 or t.dim() != 3 or t.shape[2] != 3:
+        for a in arrs:
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
                 raise hip.OfbError('DeviceTransform expects HxWx3 uint8 images')
             offs.append(total)
-            total += (t.numel() + 15) // 16 * 16
-        flat = torch.empty(total, dtype=torch.uint8).pin_memory()
-        for t, o in zip(imgs, offs):
-            flat[o:o + t.numel()] = t.reshape(-1)
-        src = flat.to(self.device, non_blocking=True)
+            total += (a.size + 15) // 16 * 16
+        if self.device.type != 'cuda':
+            raise hip.OfbError('once-for-both_amd kernels need device tensors (no CPU fallback); DeviceTransform was built for ' + str(self.device))
+        slot = getattr(self, '_slot', 0) ^ 1
+        self._slot = slot
+        pins = getattr(self, '_pins', None)
+        if pins is None:
+            pins = self._pins = [None, None]
+        if pins[slot] is None or pins[slot][0].numel() < total:
+            t = torch.empty(int(total * 1.25) + 4096, dtype=torch.uint8).pin_memory()
+            pins[slot] = (t, t.numpy(), torch.cuda.Event())
+        flat, flat_np, done = pins[slot]
+        done.synchronize()                                   # the transfer that last used this staging buffer has finished
+        for a, o in zip(arrs, offs):
+            flat_np[o:o + a.size] = a.reshape(-1)
+        src = flat[:total].to(self.device, non_blocking=True)
+        done.record()
         tab = (hip.CropParam * B)()
         for b, ((h, w), o, (top, left, ch, cw, flip)) in enumerate(zip(sizes, offs, plan)):
             t = tab[b]
