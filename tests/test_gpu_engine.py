@@ -105,3 +105,41 @@ def test_train_one_epoch_with_mixup_soft_targets():
     a = engine.train_one_epoch(m, crit, fixed[:1], opt, _Sched(), dev, 1, mixup_fn=mix, args=args, set_training_mode=False)
     b = engine.train_one_epoch(m, crit, fixed, opt, _Sched(), dev, 2, mixup_fn=mix, args=args, set_training_mode=False)
     assert b['loss'] < a['loss'], (a, b)
+
+
+def test_search_epoch_fed_by_device_loader():
+    """the whole input side in front of the engine: decoded uint8 images -> DeviceTransform (crop / flip / RandAugment / normalize /
+    erase on the GPU, prefetched on a side stream by DeviceLoader) -> search_one_epoch."""
+    import random
+    import numpy as np
+    import ofb_amd
+    from ofb_amd import engine
+    from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
+    torch.manual_seed(0); random.seed(0); np.random.seed(0)
+    dev = torch.device('cuda')
+    rng = np.random.default_rng(1)
+    batches = [([rng.integers(0, 256, size=(int(rng.integers(240, 320)), int(rng.integers(240, 320)), 3), dtype=np.uint8) for _ in range(4)],
+                rng.integers(0, 2, size=4).tolist()) for _ in range(3)]
+    loader = ofb_amd.DeviceLoader(batches, ofb_amd.DeviceTransform(224, True, 'bicubic', auto_augment='rand-m9-mstd0.5-inc1', re_prob=0.25))
+    loader.__len__ = lambda: 3
+    m = ofb_amd.create_model('deit_tiny_patch16_224_mim', method='search', num_classes=2, drop_path_rate=0.1, patch_search=False,
+                             mask_ratio=1.0).to(dev)
+    m.correct_require_grad(0.5, 0.5, 0, 0.5)
+    opt_p, opt_a, opt_d = engine.build_optimizers(m, 2.5e-4 * 4 / 256)
+    crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, 0.5, 0.5, 0.0, 0.5, 5.0)
+    args = types.SimpleNamespace(accum_iter=1, warmup_epochs=20, epochs=100)
+
+    class _Sized:
+        def __init__(self, it, n):
+            self.it, self.n = it, n
+
+        def __iter__(self):
+            return iter(self.it)
+
+        def __len__(self):
+            return self.n
+
+    stats, *_ = engine.search_one_epoch(m, crit, 1.0, _Sized(loader, 3), opt_p, opt_d, opt_a, _Sched(), _Sched(), _Sched(), dev, epoch=0,
+                                        args=args, print_freq=1)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(torch.tensor(v)) for v in stats.values()), stats
