@@ -640,13 +640,18 @@ int cu_count() {
 // count (lab: 223 vs ~165 TFLOP/s at 32768 x 2048 x 2048), but on the step's shapes it LOSES (same-box A/B, DeiT-S 35.1 vs 31.5
 // ms/step, DeiT-B 54.2 vs 53.3): K is 384..1536, so a 256x256 tile lives for only 24..96 K-steps and its prologue / epilogue are
 // not hidden by a second workgroup on the CU, its stream-K partial tiles are 256 KB each, and 594 tiles over 256 workers round
-// badly.  The default build therefore compiles T128 only; -DOFB_GEMM_TILE=256 forces T256, -DOFB_GEMM_TILE=1 enables the
-// per-shape choice below (K-contiguous-A launches that pad by at most 1/8 in 256-blocks and fill a round of workers).
+// badly.  The default build (OFB_GEMM_TILE 0) therefore uses T256 for pad-free weight gradients only (see use_t256);
+// -DOFB_GEMM_TILE=128 / 256 force one configuration, -DOFB_GEMM_TILE=1 enables the wider per-shape choice below.
 #ifndef OFB_GEMM_TILE
-#define OFB_GEMM_TILE 128
+#define OFB_GEMM_TILE 0
 #endif
 bool use_t256(const ofb_gemm_args& g) {
-#if OFB_GEMM_TILE == 128
+#if OFB_GEMM_TILE == 0
+  // default: weight gradients (dY^T X: a handful of output tiles, K = all tokens) whose output is a whole number of 256x256 tiles.
+  // Their K loop is thousands of iterations long, which is where T256's leaner main loop pays: DeiT-B bs 64 dW1 (3072 x 768 x 12608)
+  // 354 vs 397 us.  DeiT-S never qualifies (384 = 1.5 tiles).
+  return !g.a_kc && !g.b_kc && (g.M % 256 == 0) && (g.N % 256 == 0);
+#elif OFB_GEMM_TILE == 128
   return false;
 #elif OFB_GEMM_TILE == 256
   return true;
@@ -675,6 +680,9 @@ Plan plan_any(const ofb_gemm_args& g, bool& t256) {
 #endif
 }
 
+// T256 for the weight-gradient storage form only (the default build does not instantiate its other forms)
+int run_t256_wgrad(const ofb_gemm_args& g, const Plan& p, bool vec, hipStream_t s);
+
 template <class TC>
 int run(const ofb_gemm_args& g, const Plan& p, bool vec, hipStream_t s) {
   int rc;
@@ -683,6 +691,15 @@ int run(const ofb_gemm_args& g, const Plan& p, bool vec, hipStream_t s) {
   else rc = launch<TC, false, false>(g, p, vec, s);
   if (rc == 0 && p.R) {
     hipLaunchKernelGGL(gemm_fixup_kernel<TC>, dim3(p.R, TC::BM / FIX_ROWS), dim3(TC::BN), 0, s, g, p);
+    rc = ofb_launch_status();
+  }
+  return rc;
+}
+
+int run_t256_wgrad(const ofb_gemm_args& g, const Plan& p, bool vec, hipStream_t s) {
+  int rc = launch<T256, false, false>(g, p, vec, s);
+  if (rc == 0 && p.R) {
+    hipLaunchKernelGGL(gemm_fixup_kernel<T256>, dim3(p.R, T256::BM / FIX_ROWS), dim3(T256::BN), 0, s, g, p);
     rc = ofb_launch_status();
   }
   return rc;
@@ -726,6 +743,8 @@ extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream) {
   ofb_prof_pre(0, s, 2.0 * g.M * g.N * (double)g.K);
 #if OFB_GEMM_TILE == 128
   const int rc = run<T128>(g, p, vec, s);
+#elif OFB_GEMM_TILE == 0
+  const int rc = t256 ? run_t256_wgrad(g, p, vec, s) : run<T128>(g, p, vec, s);
 #else
   const int rc = t256 ? run<T256>(g, p, vec, s) : run<T128>(g, p, vec, s);
 #endif
