@@ -299,17 +299,20 @@ __global__ __launch_bounds__(TC::NT, TC::WPS) void gemm_f32_kernel(const ofb_gem
     if (B_KC) store_kc<NT, TC::BLK_B, TC::PLANE_B>(rb, Bs + buf * TC::OPER_B, t);
     else store_mc<TC::BLK_B, TC::PLANE_B>(rb, Bs + buf * TC::OPER_B, t);
   };
-  auto compute = [&](int buf) __attribute__((always_inline)) {
+  // MA x NA = the 32x32 blocks of this wave's tile that hold any valid output (guarded launches on ragged shapes: the valid region
+  // of an edge tile is a prefix of rows / columns, and multiplying padding is pure wasted energy on a power-limited chip)
+  auto mma_blocks = [&](int buf, auto MAc, auto NAc) __attribute__((always_inline)) {
+    constexpr int MA = decltype(MAc)::value, NA = decltype(NAc)::value;
     // lane (row l31, k-half h) reads its 8 bf16 of each plane with one b128; A and B share the k <-> (half, j) map.
     const char* a_s = As + buf * TC::OPER_A + h * TC::BLK_A + (wm0 + l31) * 16;
     const char* b_s = Bs + buf * TC::OPER_B + h * TC::BLK_B + (wn0 + l31) * 16;
-    ofb_bf16x8 af[MI][3], bf[NI][3];
+    ofb_bf16x8 af[MA][3], bf[NA][3];
 #pragma unroll
-    for (int i = 0; i < MI; ++i)
+    for (int i = 0; i < MA; ++i)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) af[i][pl] = *reinterpret_cast<const ofb_bf16x8*>(a_s + pl * TC::PLANE_A + i * 32 * 16);
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+    for (int j = 0; j < NA; ++j)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) bf[j][pl] = *reinterpret_cast<const ofb_bf16x8*>(b_s + pl * TC::PLANE_B + j * 32 * 16);
     // six product terms, smallest first: (mid,mid) (hi,lo) (lo,hi) (hi,mid) (mid,hi) (hi,hi)
@@ -317,10 +320,31 @@ __global__ __launch_bounds__(TC::NT, TC::WPS) void gemm_f32_kernel(const ofb_gem
 #pragma unroll
     for (int q = 0; q < 6; ++q)
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+      for (int i = 0; i < MA; ++i)
 #pragma unroll
-        for (int j = 0; j < NI; ++j)
+        for (int j = 0; j < NA; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][TA[q]], bf[j][TB[q]], acc[i][j], 0, 0, 0);
+  };
+  int ma_act = MI, na_act = NI;         // active blocks of the current unit (set per unit in guarded T128 launches)
+  auto set_active = [&](const Seg& sg) __attribute__((always_inline)) {
+    if constexpr (GUARD && MI == 2 && NI == 2) {
+      const int rows = g.M - sg.m0 - wm0, cols = g.N - sg.n0 - wn0;       // valid rows / columns from this wave's corner on
+      ma_act = rows <= 0 ? 0 : (rows <= 32 ? 1 : 2);
+      na_act = cols <= 0 ? 0 : (cols <= 32 ? 1 : 2);
+    }
+  };
+  auto compute = [&](int buf) __attribute__((always_inline)) {
+    using C1 = std::integral_constant<int, 1>;
+    using C2 = std::integral_constant<int, 2>;
+    if constexpr (GUARD && MI == 2 && NI == 2) {
+      if (ma_act == 2 && na_act == 2) mma_blocks(buf, C2{}, C2{});
+      else if (ma_act == 0 || na_act == 0) { }
+      else if (ma_act == 2) mma_blocks(buf, C2{}, C1{});
+      else if (na_act == 2) mma_blocks(buf, C1{}, C2{});
+      else mma_blocks(buf, C1{}, C1{});
+    } else {
+      mma_blocks(buf, std::integral_constant<int, MI>{}, std::integral_constant<int, NI>{});
+    }
   };
 
 #ifdef OFB_GEMM_STAMPS
@@ -331,6 +355,7 @@ __global__ __launch_bounds__(TC::NT, TC::WPS) void gemm_f32_kernel(const ofb_gem
   int sidx = 0;
   Seg cur = get_seg<TAIL>(p, v, 0);
   if (!cur.ok) return;
+  set_active(cur);
   gload(cur, cur.it0);
   lstore(0, cur.n0);
   __syncthreads();
@@ -537,6 +562,7 @@ __global__ __launch_bounds__(TC::NT, TC::WPS) void gemm_f32_kernel(const ofb_gem
     buf ^= 1;
     ++sidx;
     cur = nxt;
+    set_active(cur);
   }
 }
 
