@@ -69,6 +69,24 @@ def test_gemm_nn_and_tn(M, N, K):
     _check(db, (dy.double() * ks.double()[rows].unsqueeze(1)).sum(0), what='fused bias grad', tol=1e-5)
 
 
+@pytest.mark.parametrize('tokens,N,K', [(1000, 512, 256), (197 * 8, 768, 512), (5000, 256, 256)])
+def test_gemm_weight_gradient_on_the_256_tile(tokens, N, K):
+    """dW = dY^T @ X whose output is a whole number of 256x256 tiles takes the 8-wave T256 configuration (csrc/gemm.hip: use_t256):
+    with the per-sample K scale, the fused bias gradient and a token count that is not a multiple of the K-step."""
+    from ofb_amd import hip
+    dy, x = _mk((tokens, N), 31), _mk((tokens, K), 32)
+    ks = _mk(((tokens + 196) // 197,), 33)
+    rows = torch.arange(tokens) // 197
+    scaled = dy.double() * ks.double()[rows].unsqueeze(1)
+    dw, db = torch.empty(N, K, device='cuda'), torch.full((N,), float('nan'), device='cuda')
+    hip.gemm(dy.cuda(), x.cuda(), dw, N, K, tokens, N, K, K, 0, 0, kscale=ks.cuda(), ks_div=197, a_colsum=db)
+    _check(dw, scaled.t() @ x.double(), what=f'tn/T256 {N}x{K}x{tokens}')
+    _check(db, scaled.sum(0), what='fused bias grad', tol=1e-5)
+    dw2 = torch.empty(N, K, device='cuda')
+    hip.gemm(dy.cuda(), x.cuda(), dw2, N, K, tokens, N, K, K, 0, 0, kscale=ks.cuda(), ks_div=197)
+    assert torch.equal(dw, dw2), 'deterministic partial sums'
+
+
 def test_gemm_stream_k_tail_shapes():
     """tile counts around the workgroup count (full rounds + streamed tail, tail only, exact rounds)."""
     from ofb_amd import hip
