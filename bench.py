@@ -44,39 +44,66 @@ def gemm_traffic_per_launch(launches_per_step):
     return None, None
 
 
+def _cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or 'unknown'
+
+
 def cpu_baseline(log):
-    """The CPU oracle (a parity-pinned port of the reference's engine.py search step) timed on this host's cores on a
-    bounded sample of the same workload: DeiT-S, bs 8, fp32, forward + loss + backward."""
+    """The CPU oracle (a parity-pinned port of the reference's engine.py search step) timed on this host's cores on a bounded
+    sample of the same workload, as SURVEY.md 8(d) prescribes: FULL steps (forward + OFBSearchLOSS + backward + the three
+    AdamW instances), fp32, 3 warm-up + 5 timed, at configs[0] (DeiT-T, 2 classes, bs 8) and at a reduced-batch DeiT-S point
+    (bs 32).  `value` is the DeiT-S figure (the architecture of the metric); both cases are listed."""
     from oracle import ofb_oracle as O
-    # 16 threads = this job's CPU share on a one-GPU box; with all 128 hardware threads the bs-8 sample spends its time in
+    # 16 threads = this job's CPU share on a one-GPU box; with all 128 hardware threads the small batches spend their time in
     # thread hand-offs (1.4-3.5 images/s, varying run to run) instead of arithmetic
     torch.set_num_threads(min(16, os.cpu_count() or 16))
-    torch.manual_seed(0)
-    cfg = O.Config(**O.DEIT_SMALL, num_classes=1000, drop_path_rate=0.1)
-    p = {k: v.requires_grad_(True) for k, v in O.formula_params(cfg, torch.float32).items()}
-    p['alpha_patch'].requires_grad_(False)
-    st = O.SearchState(w_p=0.99, keep_ratio=0.95)
-    bs = 8
-    g = torch.Generator().manual_seed(1234)
-    imgs = torch.randn(bs, 3, 224, 224, generator=g)
-    labels = torch.randint(0, 1000, (bs,), generator=g)
+    warm, timed = 3, 5
 
-    def step():
-        for v in p.values():
-            v.grad = None
-        out = O.search_step_loss(cfg, p, st, imgs, labels, torch.rand(bs, 196, generator=g), torch.rand(24, bs, generator=g))
-        out['loss_total'].backward()
+    def run_case(arch, ncls, bs):
+        torch.manual_seed(0)
+        cfg = O.Config(**arch, num_classes=ncls, drop_path_rate=0.1)
+        p = {k: v.requires_grad_(k != 'alpha_patch') for k, v in O.formula_params(cfg, torch.float32).items()}
+        opt = O.OptimState(p, frozen=('alpha_patch',))
+        st = O.SearchState(w_p=0.99, keep_ratio=0.95)
+        g = torch.Generator().manual_seed(1234)
+        imgs = torch.randn(bs, 3, 224, 224, generator=g)
+        labels = torch.randint(0, ncls, (bs,), generator=g)
+        lr = 2.5e-4 * bs / 256
 
-    step()
-    t0 = time.time()
-    n = 2
-    for _ in range(n):
-        step()
-    dt = (time.time() - t0) / n
-    log(f'cpu_baseline: {dt:.2f} s/step at bs {bs} on {torch.get_num_threads()} threads')
-    return dict(value=round(bs / dt, 3), unit='images/s', cores=torch.get_num_threads(), kind='port',
-                sample=f'DeiT-S OFB search step (fwd+loss+bwd), bs {bs}, fp32, 1 warm-up + {n} timed steps of the oracle')
+        def step():
+            for v in p.values():
+                v.grad = None
+            out = O.search_step_loss(cfg, p, st, imgs, labels, torch.rand(bs, 196, generator=g), torch.rand(2 * cfg.depth, bs, generator=g))
+            out['loss_total'].backward()
+            with torch.no_grad():
+                grads = {k: v.grad for k, v in p.items()}
+                q = {k: v.detach() for k, v in p.items()}
+                opt.step(q, grads, lr)                                   # the three reference AdamW instances (optim.py:56-120)
+            for k in p:
+                p[k] = q[k].requires_grad_(k != 'alpha_patch')
 
+        for _ in range(warm):
+            step()
+        t0 = time.time()
+        for _ in range(timed):
+            step()
+        dt = (time.time() - t0) / timed
+        log(f'cpu_baseline: {arch["embed_dim"]}-wide, bs {bs}: {dt:.3f} s/step on {torch.get_num_threads()} threads')
+        return dict(s_per_step=round(dt, 4), images_per_s=round(bs / dt, 3), batch=bs)
+
+    tiny = run_case(O.DEIT_TINY, 2, 8)
+    small = run_case(O.DEIT_SMALL, 1000, 32)
+    return dict(value=small['images_per_s'], unit='images/s', cores=torch.get_num_threads(), kind='port', cpu_model=_cpu_model(),
+                sample=f'full OFB search steps (fwd + loss + bwd + 3x AdamW) of the oracle, fp32, {warm} warm-up + {timed} timed: '
+                       f'DeiT-S bs 32 (value) and configs[0] DeiT-T 2-class bs 8',
+                cases={'deit_small_bs32': small, 'configs[0]_deit_tiny_2cls_bs8': tiny})
 
 
 # configs[4] (SURVEY 8d): the released OFB-DeiT-C shapes are not available, so a subnet at the same budget (~1.7 GMAC, ~8 M
@@ -116,12 +143,60 @@ def build_finetune_subnet(ofb_amd, dev, ncls):
     return model, macs, params
 
 
+def self_launch(n):
+    """`python bench.py --gpus N` from a bare shell: start N ranks (one per GPU) under torch.distributed.run and hand their exit
+    code back.  This parent never touches the GPU (no HIP call, not even torch.cuda.is_available()): a process that has
+    initialised the GPU must not be replaced or forked on this pool, so the ranks are CHILD processes started first."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')        # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print('bench.py: launching', ' '.join(cmd), file=sys.stderr, flush=True)
+    return subprocess.call(cmd, env=env)                     # the ranks inherit stdout: rank 0 prints the one JSON line
+
+
+def rehearsal(args, rank, world, real_stdout):
+    """OFB_BENCH_REHEARSAL=gloo: the launcher, rendezvous, broadcast, bucketed exchange and JSON plumbing of the N-rank run on
+    CPU tensors over gloo (no GPU in the build container; tests/test_dp_gloo.py drives it).  Not a benchmark."""
+    import torch.distributed as dist
+    dist.init_process_group('gloo', init_method='env://')
+    import ofb_amd
+    torch.manual_seed(100 + rank)                            # deliberately different replicas: the reducer must broadcast rank 0
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (4096, 33, 70000, 512)]
+    red = ofb_amd.dp.GradAllReducer(params, bucket_bytes=64 * 1024)
+    ref = [p.detach().clone() for p in params]
+    dist.broadcast(ref[0], 0)
+    same = all(bool(torch.equal(a, b)) for a, b in zip(params[:1], ref[:1]))
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        for p in params:
+            p.grad = None
+        (sum((p * (rank + 1)).sum() for p in params) * red.grad_scale).backward()
+        red.prescaled = True
+        red.finalize()
+    dt = time.perf_counter() - t0
+    ok = same and all(torch.allclose(p.grad, torch.full_like(p, sum(range(1, world + 1)) / world)) for p in params)
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        res = dict(metric='REHEARSAL of the N-rank launch on CPU/gloo (not a benchmark)', value=0.0, unit='images/s', n_gpus=world,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=round(dt / max(args.steps, 1) * 1e3, 3), higher_is_better=True,
+                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   config=dict(workload='gradient exchange of 4 CPU tensors', parallelism=f'dp{world}',
+                               collective=dict(backend='gloo', ranks=dist.get_world_size()), exchange_ok=bool(flag.item())))
+        os.write(real_stdout, (json.dumps(res) + '\n').encode())
+    dist.destroy_process_group()
+    return 0 if flag.item() else 1
+
+
 def main():
-    # stdout carries exactly ONE line (the JSON): library banners written to fd 1 (RCCL prints its version block there when
-    # the communicator comes up) are sent to stderr instead, and the JSON goes to the saved descriptor at the end.
-    sys.stdout.flush()
-    real_stdout = os.dup(1)
-    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
@@ -135,11 +210,20 @@ def main():
     ap.add_argument('--force-dp', action='store_true', help='exercise the DP bucket path even with one rank (debug)')
     args = ap.parse_args()
 
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:     # bare `python bench.py --gpus N`: become the launcher
+        raise SystemExit(self_launch(args.gpus))
+    # stdout carries exactly ONE line (the JSON): library banners written to fd 1 (RCCL prints its version block there when
+    # the communicator comes up) are sent to stderr instead, and the JSON goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get('RANK', 0))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
     world = int(os.environ.get('WORLD_SIZE', 1))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    if os.environ.get('OFB_BENCH_REHEARSAL') == 'gloo':
+        raise SystemExit(rehearsal(args, rank, world, real_stdout))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the once-for-both_amd hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -156,7 +240,7 @@ def main():
     from ofb_amd import engine, hip
     from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
 
-    torch.manual_seed(0)                                     # identical init on every rank (DDP would broadcast rank 0)
+    torch.manual_seed(0 + rank)                              # per-rank init streams (search.py:381); the reducer broadcasts rank 0's replica
     ncls = 1000
     eff_bs = args.batch * world
     gflop_img = GFLOP_PER_IMG[args.model]
@@ -186,9 +270,11 @@ def main():
         opt_ft = AdamW(model.parameters(), None, lr=2.5e-4 * eff_bs / 512, weight_decay=0.05)
         crit_ft = DistillationLoss(ofb_amd.SoftTargetCrossEntropy(), None, 'none', 0.5, 1.0)
         mixup_fn = ofb_amd.Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=ncls)
-        ema = ModelEma(model, decay=0.99996)
         np.random.seed(1234 + rank)
+    # replaces DDP's wrap (search.py:617-620): broadcasts rank 0's replica, then exchanges gradients in persistent flat buckets
     reducer = ofb_amd.dp.GradAllReducer(list(model.parameters()), force_collective=args.force_dp) if (world > 1 or args.force_dp) else None
+    if args.mode == 'finetune':
+        ema = ModelEma(model, decay=0.99996)                 # after the broadcast: the EMA copies rank 0's weights on every rank
 
     torch.manual_seed(1234 + rank)                           # per-rank data / mask / DropPath streams (search.py:381)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)
@@ -292,7 +378,10 @@ def main():
     res = dict(metric=metric, value=round(value, 2), unit='images/s', n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=round(ms_step, 3), higher_is_better=True, scaling='weak',
                vs_baseline=None, dtype='f32', data='synthetic',
-               config=dict(workload=workload, global_batch=eff_bs, parallelism=f'dp{world}', init_steps=INIT_STEPS,
+               config=dict(workload=workload, global_batch=eff_bs, parallelism=f'dp{world}',
+                           collective=dict(backend='nccl (RCCL over xGMI)' if dist.is_initialized() else 'none',
+                                           ranks=dist.get_world_size() if dist.is_initialized() else 1,
+                                           buckets=len(reducer.buckets) if reducer is not None else 0), init_steps=INIT_STEPS,
                            step_tflops_per_gpu=round(step_tflops, 2), step_frac_of_f32_mfma_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)),
                roofline=roof)
     if ft_info:

@@ -450,12 +450,10 @@ extern "C" int ofb_attention_bwd(const float* qkv, const float* out, const float
   if (!qkv || !out || !lse || !dout || !dqkv) return OFB_EINVAL;
   if (int rc = check_shape(B, N, H, dh)) return rc;
   if (!ofb_aligned16(qkv) || !ofb_aligned16(out) || !ofb_aligned16(dout) || !ofb_aligned16(dqkv)) return OFB_EINVAL;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS) != hipSuccess)
-      return (int)hipGetLastError();
-    attr_set = true;
-  }
+  // the attribute is per device and the call is cheap: set it on every launch (a per-process flag would leave a second GPU
+  // of the same process without it, and is not thread-safe)
+  if (hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS) != hipSuccess)
+    return (int)hipGetLastError();
   hipStream_t s = (hipStream_t)stream;
   ofb_prof_pre(4, s, 10.0 * B * H * (double)N * N * dh);
   hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(ATT_THREADS), BWD_LDS, s, qkv, out, lse, dout, dqkv, B, N, H, dh, scale);

@@ -3,21 +3,94 @@ backend 'nccl' IS RCCL on ROCm) launched from post-accumulate-grad hooks so it o
 backward.  Replaces DistributedDataParallel(find_unused_parameters=True) of reference search.py:617-620
 (collective C1 of SURVEY.md 2.2).  One process per GPU; no model or sequence sharding exists on this path.
 
-Buckets are filled in reverse parameter order (gradients become ready last-block-first).  After the
-reduce, each parameter's .grad is re-pointed at its slice of the reduced bucket (no copy back).
-Parameters whose gradient never arrives in a step (frozen alphas, a finished decoder) are skipped.
+* Construction (and `rebuild()` after `compress()` replaced Parameters) broadcasts rank 0's copy of EVERY tensor
+  handed in - trainable or frozen, plus `extra_tensors` such as a finished module's plain-tensor score - exactly as
+  DDP's constructor does (search.py:619), after checking that all ranks hold the same shapes.  Ranks that were seeded
+  per rank (search.py:381) or resumed from different files therefore start from identical replicas.
+* Buckets are persistent flat fp32 buffers filled in reverse parameter order (gradients become ready
+  last-block-first).  The weight-gradient GEMMs write straight into their slice of the bucket (`grad_slot`, used by
+  ops.py) so the big tensors are never copied; small gradients (biases, LayerNorm, alpha / score) are copied in when
+  the bucket is launched.  After the reduce each parameter's .grad IS its slice of the reduced bucket.
+* Parameters whose gradient never arrives in a window (frozen alphas, a finished decoder) are skipped: their slice
+  travels as zeros and is not installed.
 """
 import torch
 import torch.distributed as dist
 
+_active = None        # the reducer whose buckets ops.py may write weight gradients into (one model per process)
+
+
+def grad_slot(param):
+    """Slice of the active reducer's flat bucket where `param`'s gradient should be written, or None (no reducer,
+    unknown tensor, or a gradient is already being accumulated in this window)."""
+    r = _active
+    if r is None or not r.sync:
+        return None
+    ent = r._slot_of.get(param.data_ptr())
+    if ent is None:
+        return None
+    p, view = ent
+    if p.grad is not None or p.numel() != param.numel():
+        return None
+    return view.view(param.shape)
+
+
+def _flat_chunks(tensors, limit=64 * 1024 * 1024):
+    """groups of tensors of at most `limit` bytes (one collective each)"""
+    cur, size = [], 0
+    for t in tensors:
+        n = t.numel() * t.element_size()
+        if cur and size + n > limit:
+            yield cur
+            cur, size = [], 0
+        cur.append(t)
+        size += n
+    if cur:
+        yield cur
+
+
+def broadcast_tensors(tensors, src=0, process_group=None):
+    """rank `src`'s values into every rank's tensors, a few coalesced collectives (DDP's constructor broadcast)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return
+    ts = [t for t in tensors if t is not None and t.numel()]
+    # replicas must agree on structure before any payload collective (a mismatch would hang or corrupt silently)
+    sig = torch.tensor([len(ts), sum(t.numel() for t in ts), sum((i + 1) * t.numel() for i, t in enumerate(ts)) % (2 ** 31)],
+                       dtype=torch.int64, device=ts[0].device if ts else 'cpu')
+    lo, hi = sig.clone(), sig.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=process_group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=process_group)
+    if not torch.equal(lo, hi):
+        raise RuntimeError('data-parallel replicas disagree on parameter count / shapes: '
+                           f'min {lo.tolist()} max {hi.tolist()} (did compress() cut different cells per rank?)')
+    by_type = {}
+    for t in ts:
+        by_type.setdefault((t.dtype, t.device), []).append(t)
+    for group in by_type.values():
+        for chunk in _flat_chunks(group):
+            flat = torch.cat([t.detach().reshape(-1) for t in chunk])
+            dist.broadcast(flat, src=src, group=process_group)
+            off = 0
+            with torch.no_grad():
+                for t in chunk:
+                    n = t.numel()
+                    t.copy_(flat[off:off + n].view_as(t))
+                    off += n
+
 
 class GradAllReducer:
-    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, force_collective=False):
+    def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, force_collective=False, broadcast=True,
+                 extra_tensors=()):
+        global _active
         self.group = process_group
         # force_collective: issue the all-reduce even in a one-rank group (rehearses the RCCL path on a single GPU)
         self.force_collective = bool(force_collective) and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.params = [p for p in params if p.requires_grad]
+        self.bucket_bytes = bucket_bytes
+        all_params = list(params)
+        if broadcast:
+            broadcast_tensors([p.data for p in all_params] + list(extra_tensors), 0, process_group)
+        self.params = [p for p in all_params if p.requires_grad]
         self.buckets, cur, size = [], [], 0
         for p in reversed(self.params):
             cur.append(p)
@@ -27,13 +100,22 @@ class GradAllReducer:
                 cur, size = [], 0
         if cur:
             self.buckets.append(cur)
-        self._where = {}
+        self._where, self._slot_of, self._flat, self._views = {}, {}, [], []
         for bi, b in enumerate(self.buckets):
+            flat = torch.zeros(sum(p.numel() for p in b), device=b[0].device, dtype=torch.float32)
+            views, off = [], 0
             for p in b:
+                n = p.numel()
+                v = flat[off:off + n].view_as(p)
+                views.append(v)
                 self._where[p] = bi
+                self._slot_of[p.data_ptr()] = (p, v)
+                off += n
+            self._flat.append(flat)
+            self._views.append(views)
         self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
         self._works = []
-        self._flat = [None] * len(self.buckets)
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         # averaging: callers scale the loss by `grad_scale` (= 1/world, exact for power-of-two worlds) before backward and
         # the exchange is a plain SUM, so no extra pass over the gradients is needed; prescaled=False divides afterwards.
@@ -44,23 +126,43 @@ class GradAllReducer:
         # micro-step (as the reference does, SURVEY D-7) would SUM the already-reduced part again, because .grad is re-pointed
         # at the reduced bucket and autograd keeps accumulating into it.
         self.sync = True
+        _active = self
 
-    def rebuild(self, params):
-        """call after compress() replaced Parameters (fixes the reference's silent de-sync, SURVEY D-6)."""
+    def close(self):
+        global _active
         for h in self._handles:
             h.remove()
-        self.__init__(params, process_group=self.group, force_collective=self.force_collective)
+        self._handles = []
+        if _active is self:
+            _active = None
+
+    def rebuild(self, params, extra_tensors=()):
+        """call after compress() replaced Parameters (fixes the reference's silent de-sync, SURVEY D-6).  Re-broadcasts rank
+        0's replica (after a shape check) and keeps the `sync` / `prescaled` settings of the running loop."""
+        sync, prescaled = self.sync, self.prescaled
+        self.close()
+        self.__init__(params, bucket_bytes=self.bucket_bytes, process_group=self.group, force_collective=self.force_collective,
+                      extra_tensors=extra_tensors)
+        self.sync, self.prescaled = sync, prescaled
 
     def _launch(self, bi):
-        ps = [p for p in self.buckets[bi] if p.grad is not None]
-        if not ps:
+        self._launched[bi] = True
+        flat, live = self._flat[bi], []
+        for p, v in zip(self.buckets[bi], self._views[bi]):
+            if p.grad is None:
+                v.zero_()                                # travels as zeros, is not installed afterwards
+                continue
+            if p.grad.data_ptr() != v.data_ptr():        # small gradients / accumulated windows: one copy into the bucket
+                v.copy_(p.grad)
+                p.grad = v
+            live.append(p)
+        if not live:
             return
-        flat = torch.cat([p.grad.reshape(-1) for p in ps])
         if self.world > 1 or self.force_collective:
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
             work = None
-        self._works.append((bi, ps, flat, work))
+        self._works.append((bi, work))
 
     def _hook(self, p):
         if not self.sync:
@@ -74,21 +176,20 @@ class GradAllReducer:
         """wait for the exchanges of this backward and install the averaged gradients."""
         if not self.sync:
             return
-        for bi in range(len(self.buckets)):            # buckets with frozen / unused members never filled up
-            if 0 < self._ready[bi] < len(self.buckets[bi]):
+        # buckets with frozen / unused members never fill up; under gradient accumulation a bucket may hold gradients from
+        # earlier micro-steps only.  Every rank sees the same set (it follows from requires_grad and the graph), so launch
+        # every bucket that holds any gradient.
+        for bi in range(len(self.buckets)):
+            if not self._launched[bi] and any(p.grad is not None for p in self.buckets[bi]):
                 self._launch(bi)
-        for bi, ps, flat, work in self._works:
+        for bi, work in self._works:
             if work is not None:
                 work.wait()
                 if not self.prescaled:
-                    flat.div_(self.world)
-            off = 0
-            for p in ps:
-                n = p.numel()
-                p.grad = flat[off:off + n].view_as(p)
-                off += n
+                    self._flat[bi].div_(self.world)
         self._works = []
         self._ready = [0] * len(self.buckets)
+        self._launched = [False] * len(self.buckets)
 
 
 def average_scalars(tensors, process_group=None):

@@ -62,6 +62,9 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
             opt.zero_grad(set_to_none=True)
     execute_pruned = False
     stats, t0 = {}, time.time()
+    # epoch statistics stay on the device (MetricLogger.global_avg of the reference, engine.py:87-90,186-199): running sums of
+    # the four losses plus a count of non-finite totals; the host reads them at print points only
+    sums = None
     for it, (samples, targets) in enumerate(data_loader):
         samples = samples.to(device, non_blocking=True)
         targets = targets.to(device, non_blocking=True)
@@ -78,6 +81,13 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
         opts = (optimizer_param, optimizer_arch if not finish_search else None, optimizer_decoder)
         base, arch, dec, total = search_step(net, criterion, samples, targets, target_flops, opts, finish_search, accum_iter,
                                              do_step=boundary, reducer=reducer)
+        with torch.no_grad():
+            tf = total.detach().float()
+            zero = torch.zeros_like(tf)
+            vals = torch.stack([tf, base.detach().float(), arch.detach().float() if arch is not None else zero,
+                                dec.detach().float() if not isinstance(dec, float) else zero])
+            row = torch.cat([torch.nan_to_num(vals, nan=0.0, posinf=0.0, neginf=0.0), (~torch.isfinite(tf)).float().reshape(1)])
+            sums = row if sums is None else sums + row
         if boundary:
             gstep = epoch * n_iter + it
             lr_scheduler_param.step_update(gstep)
@@ -89,13 +99,14 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
             model_ema.update(model)
         if it % print_freq == 0 or it == n_iter - 1:          # the only host syncs of the loop
             lv = float(total.detach())
-            if not math.isfinite(lv):
-                print('Loss is {}, stopping training'.format(lv))
+            host = sums.tolist()
+            if not math.isfinite(lv) or host[4] > 0:         # any micro-step since the last look (reference: every micro-step, engine.py:146-148)
+                print('Loss is {}, stopping training'.format(lv if not math.isfinite(lv) else 'non-finite in an earlier micro-step'))
                 sys.exit(1)
-            stats = dict(loss_total=lv, loss_param=float(base.detach()), loss_arch=float(arch.detach()) if arch is not None else 0.0,
-                         loss_decoder=float(dec.detach()) if not isinstance(dec, float) else 0.0,
-                         lr_param=optimizer_param.param_groups[0]['lr'])
-            print(f'Epoch: [{epoch}] [{it}/{n_iter}] ' + ' '.join(f'{k}: {v:.5f}' for k, v in stats.items())
+            n_seen = it + 1
+            stats = dict(loss_total=host[0] / n_seen, loss_param=host[1] / n_seen, loss_arch=host[2] / n_seen,
+                         loss_decoder=host[3] / n_seen, lr_param=optimizer_param.param_groups[0]['lr'])       # epoch global averages
+            print(f'Epoch: [{epoch}] [{it}/{n_iter}] loss_total: {lv:.5f} ' + ' '.join(f'{k}(avg): {v:.5f}' for k, v in stats.items())
                   + f' time: {(time.time() - t0) / (it + 1):.4f}')
         every = max(1, n_iter // 3 // accum_iter)
         if not finish_search and boundary and ((it + 1) // accum_iter) % every == 0 and hasattr(net, 'compress'):
@@ -104,6 +115,8 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
             execute_pruned |= execute_prune
             if reducer is not None and execute_prune:            # compress() replaced Parameters: re-bucket the exchange
                 reducer.rebuild([p for p in net.parameters()])
+            if model_ema is not None:                            # engine.py:212-213: the EMA adopts the cut shapes right away
+                model_ema.update(model)
             if finish_search:
                 optimizer_arch, lr_scheduler_arch = None, None
     return stats, finish_search, execute_pruned, optimizer_param, optimizer_decoder, optimizer_arch
@@ -118,6 +131,7 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
     accum_iter = args.accum_iter
     optimizer.zero_grad(set_to_none=True)
     n_iter, stats = len(data_loader), {}
+    sums = None                                          # device-side [sum of losses, count of non-finite losses]
     for it, (samples, targets) in enumerate(data_loader):
         samples, targets = samples.to(device, non_blocking=True), targets.to(device, non_blocking=True)
         if mixup_fn is not None:
@@ -125,6 +139,7 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
         loss = criterion(samples, model(samples), targets)
         if reducer is not None:
             reducer.sync = (it + 1) % accum_iter == 0    # one exchange per accumulation window
+            reducer.prescaled = False                    # plain SUM, divided by the world size in finalize()
         (loss / accum_iter if accum_iter != 1 else loss).backward()
         if reducer is not None:
             reducer.finalize()
@@ -134,12 +149,17 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
             lr_schedule.step_update(epoch * n_iter + it)
         if model_ema is not None:
             model_ema.update(model)
+        with torch.no_grad():
+            lf = loss.detach().float()
+            row = torch.stack([torch.nan_to_num(lf, nan=0.0, posinf=0.0, neginf=0.0), (~torch.isfinite(lf)).float()])
+            sums = row if sums is None else sums + row
         if it % print_freq == 0 or it == n_iter - 1:
             lv = float(loss.detach())
-            if not math.isfinite(lv):
-                print('Loss is {}, stopping training'.format(lv))
+            host = sums.tolist()
+            if not math.isfinite(lv) or host[1] > 0:
+                print('Loss is {}, stopping training'.format(lv if not math.isfinite(lv) else 'non-finite in an earlier micro-step'))
                 sys.exit(1)
-            stats = dict(loss=lv, lr=optimizer.param_groups[0]['lr'])
+            stats = dict(loss=host[0] / (it + 1), lr=optimizer.param_groups[0]['lr'])                    # epoch global average
     return stats
 
 

@@ -91,11 +91,14 @@ _gemm_ws = {}
 
 
 def _workspace(device, nbytes):
-    """one shared stream-K workspace per device (successive GEMMs on a stream may reuse it)."""
-    ws = _gemm_ws.get(device)
+    """one stream-K workspace per (device, stream): successive GEMMs on ONE stream may reuse it (stream order serialises the
+    partial tiles), GEMMs on different streams (an EMA / eval forward on a side stream, user code) must not share it.
+    A grown buffer replaces the old one; the caching allocator keeps the old block alive until the stream has passed it."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _gemm_ws.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
-        _gemm_ws[device] = ws
+        _gemm_ws[key] = ws
     return ws
 
 

@@ -8,6 +8,7 @@ import ctypes as C
 import torch
 
 from . import hip
+from .dp import grad_slot
 
 
 def _new(like, *shape):
@@ -62,11 +63,12 @@ def _gated_linear_bwd(dy2d, x2d, W, b, gvec, resid=None):
     """Backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None).
     Returns dx (+resid fused), dW, db, dg."""
     N, K = W.shape
+    slot = grad_slot(W)                # data-parallel runs: the weight gradient lands in its all-reduce bucket, no copy
     if gvec is None:
         dx = linear_bwd_input(dy2d, W, resid=resid)
         if b is None:
-            return dx, linear_bwd_weight(dy2d, x2d), None, None
-        dW, db = linear_bwd_weight(dy2d, x2d, want_bias=True)
+            return dx, linear_bwd_weight(dy2d, x2d, out=slot), None, None
+        dW, db = linear_bwd_weight(dy2d, x2d, want_bias=True, out=slot)
         return dx, dW, db, None
     Weff = _new(W, N, K)
     hip.scale_rows(W, gvec, Weff, N, K)
@@ -75,7 +77,8 @@ def _gated_linear_bwd(dy2d, x2d, W, b, gvec, resid=None):
         dWraw, dbraw = linear_bwd_weight(dy2d, x2d, want_bias=True)
     else:
         dWraw, dbraw = linear_bwd_weight(dy2d, x2d), None
-    dW, db, dg = Weff, (_new(W, N) if b is not None else None), _new(W, N)     # reuse Weff storage for dW
+    dW = slot if slot is not None else Weff                                    # else reuse Weff storage for dW
+    db, dg = (_new(W, N) if b is not None else None), _new(W, N)
     hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K)
     return dx, dW, db, dg
 
@@ -177,9 +180,9 @@ class AttnBranch(torch.autograd.Function):
         d2s = _droppath_scaled(d2, rowscale)          # gradient of the branch output (DropPath factor applied once)
         do = linear_bwd_input(d2s, wproj)
         if has_pb:
-            dwp, dbp = linear_bwd_weight(d2s, o, want_bias=True)
+            dwp, dbp = linear_bwd_weight(d2s, o, want_bias=True, out=grad_slot(wproj))
         else:
-            dwp, dbp = linear_bwd_weight(d2s, o), None
+            dwp, dbp = linear_bwd_weight(d2s, o, out=grad_slot(wproj)), None
         dqkv = torch.empty_like(qkv)
         hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
         dx, dwq, dbq, dg3 = _gated_linear_bwd(dqkv, x2d, wqkv, bqkv, g3, resid=d2 if self_resid else None)
@@ -217,9 +220,9 @@ class MlpBranch(torch.autograd.Function):
         d2s = _droppath_scaled(d2, rowscale)
         dhpre = linear_bwd_input(d2s, w2, act=hip.ACT_DGELU, aux=hpre)
         if has_b2:
-            dw2, db2 = linear_bwd_weight(d2s, h, want_bias=True)
+            dw2, db2 = linear_bwd_weight(d2s, h, want_bias=True, out=grad_slot(w2))
         else:
-            dw2, db2 = linear_bwd_weight(d2s, h), None
+            dw2, db2 = linear_bwd_weight(d2s, h, out=grad_slot(w2)), None
         dx, dw1, db1, dg = _gated_linear_bwd(dhpre, x2d, w1, b1, gv, resid=d2 if self_resid else None)
         dres = None if self_resid else dout
         return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None
@@ -263,7 +266,7 @@ class PatchEmbedTokens(torch.autograd.Function):
         dgm = _new(conv, 2, D)
         hip.colsum(part[1], D, chunks * (L + 1), D, dgm[0])
         hip.colsum(part[2], D, chunks * (L + 1), D, dgm[1])
-        dw, db = linear_bwd_weight(dconv, patches, want_bias=True)
+        dw, db = linear_bwd_weight(dconv, patches, want_bias=True, out=grad_slot(w2d))
         dcls = dpos[0].reshape(cshape)
         return (None, dw.view(wshape), db, None if gshape is None else dgm[0].view(gshape), dpos.view(pshape), dcls,
                 None if mshape is None else dgm[1].view(mshape), None, None)

@@ -50,6 +50,19 @@ def _worker(rank, world, port, out):
         for i, p in enumerate(params):
             exp = sum(sum(r + 1 + i + 10 * micro for micro in range(3)) for r in range(world)) / world
             assert torch.allclose(p.grad, torch.full_like(p, float(exp))), (rank, i, prescaled, p.grad[0].item(), exp)
+    # a bucket whose members received gradients only in EARLIER micro-steps of the window must still be exchanged
+    red.prescaled = False
+    for p in params:
+        p.grad = None
+    red.sync = False
+    sum((p * (rank + 1)).sum() for p in params).backward()
+    red.finalize()
+    red.sync = True
+    (params[0] * (rank + 1)).sum().backward()                  # closing micro-step touches one parameter only
+    red.finalize()
+    for i, p in enumerate(params):
+        exp = sum((r + 1) * (2 if i == 0 else 1) for r in range(world)) / world
+        assert torch.allclose(p.grad, torch.full_like(p, float(exp))), (rank, i, p.grad[0].item(), exp)
     red.sync, red.prescaled = True, False
     avg = average_scalars([torch.full((2, 3), float(rank)), torch.full((4,), 10.0 * rank)])
     assert torch.allclose(avg[0], torch.full((2, 3), 0.5)) and torch.allclose(avg[1], torch.full((4,), 5.0))
@@ -64,3 +77,99 @@ def test_bucketed_allreduce_world2():
         port = _free_port()
         ctx = mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
         assert dict(out) == {0: 1, 1: 1}
+
+
+def _worker_broadcast_rebuild(rank, world, port, out):
+    """divergent per-rank initialisation (search.py:381 seeds with seed + rank) -> construction broadcasts rank 0's replica,
+    frozen tensors and extra plain tensors included; rebuild() after Parameters were REPLACED (compress()) re-buckets the new
+    tensors, keeps the loop's flags and broadcasts again; replicas that disagree on shapes raise instead of hanging."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import ofb_amd
+    from ofb_amd import dp
+    from ofb_amd.dp import GradAllReducer
+    torch.manual_seed(1000 + rank)
+    params = [torch.nn.Parameter(torch.randn(n)) for n in (40, 3000, 17)]
+    frozen = torch.nn.Parameter(torch.randn(9), requires_grad=False)
+    extra = torch.randn(5)
+    red = GradAllReducer(params + [frozen], bucket_bytes=2048, extra_tensors=[extra])
+    everything = torch.cat([p.detach().reshape(-1) for p in params + [frozen]] + [extra])
+    ref = everything.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(everything, ref), 'construction must leave every rank with rank 0 values'
+    # gradients land in the persistent flat buckets: after finalize() every .grad is a view of its bucket (no torch.cat copy)
+    sum((p * (rank + 1)).sum() for p in params).backward()
+    red.finalize()
+    for p in params:
+        bi = red._where[p]
+        lo, hi = red._flat[bi].data_ptr(), red._flat[bi].data_ptr() + 4 * red._flat[bi].numel()
+        assert lo <= p.grad.data_ptr() < hi
+        assert torch.allclose(p.grad, torch.full_like(p, 1.5))
+    # direct-write slots (ops.py writes weight gradients straight into the bucket): only while no gradient is pending
+    assert dp.grad_slot(params[1]) is None
+    for p in params:
+        p.grad = None
+    slot = dp.grad_slot(params[1])
+    assert slot is not None and slot.shape == params[1].shape and slot.data_ptr() == red._slot_of[params[1].data_ptr()][1].data_ptr()
+    # ---- compress(): Parameters are replaced by differently-shaped ones, rank-locally perturbed
+    torch.manual_seed(2000 + rank)
+    new = [torch.nn.Parameter(torch.randn(n)) for n in (24, 1000, 17, 8)]
+    red.sync, red.prescaled = True, True
+    red.rebuild(new + [frozen])
+    assert red.sync is True and red.prescaled is True, 'rebuild must keep the loop flags'
+    cat = torch.cat([p.detach() for p in new])
+    ref = cat.clone()
+    dist.broadcast(ref, 0)
+    assert torch.equal(cat, ref)
+    for p in params:                                            # hooks of the old tensors are gone
+        p.grad = None
+    (sum((p * (rank + 1)).sum() for p in new) * red.grad_scale).backward()
+    red.finalize()
+    for p in new:
+        assert torch.allclose(p.grad, torch.full_like(p, 1.5)), (rank, p.grad[:3])
+    assert dp.grad_slot(params[1]) is None                      # stale tensors are no longer known
+    # ---- shape disagreement is an error, not a hang
+    bad = [torch.nn.Parameter(torch.randn(10 + rank))]
+    try:
+        GradAllReducer(bad)
+        raised = False
+    except RuntimeError as e:
+        raised = 'disagree' in str(e)
+    assert raised
+    out[rank] = 1
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_rebuild_world2():
+    mp.set_start_method('spawn', force=True)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_broadcast_rebuild, args=(2, _free_port(), out), nprocs=2, join=True)
+        assert dict(out) == {0: 1, 1: 1}
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` from a bare shell (no torchrun, WORLD_SIZE unset) must start two ranks that rendezvous, run the
+    reducer and print ONE JSON line with n_gpus = 2; rehearsed on CPU / gloo (OFB_BENCH_REHEARSAL), on MI355X the same launcher
+    starts the RCCL ranks."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OFB_BENCH_REHEARSAL'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 2 and res['config']['parallelism'] == 'dp2' and res['config']['collective']['ranks'] == 2
+    assert res['config']['exchange_ok'] is True
+    # without the rehearsal switch the ranks must fail loudly on a GPU-less host (no CPU fallback), and the launcher hands the
+    # failure back as a non-zero exit code
+    if torch.cuda.device_count() == 0:
+        env.pop('OFB_BENCH_REHEARSAL')
+        r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'], env=env,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0 and 'MI355X' in r.stderr
