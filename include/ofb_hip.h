@@ -29,7 +29,8 @@ extern "C" {
 #define OFB_ACT_DGELU 2     /* C <- value * gelu_erf'(aux[m][n])                              */
 
 /* ---------------------------------------------------------------------------------------------
- * Dense contraction on f32-input MFMA (v_mfma_f32_32x32x2_f32): C[M,N] = A[M,K] * B[K,N], then
+ * Dense f32 contraction on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, six terms of an exact 3-way operand split, f32
+ * accumulation: fp32-class accuracy, tests/test_gpu_accuracy_class.py): C[M,N] = A[M,K] * B[K,N], then
  *   v = alpha*acc (+bias[n]) (*colscale[n]); act; (*rowscale[m / rs_div]); (+resid[m*ldr+n]).
  * a_kc / b_kc = 1: operand stored K-contiguous (A[m*lda+k], B[n*ldb+k]); 0: stored
  * MN-contiguous (A[k*lda+m], B[k*ldb+n]).  So (1,1) is x @ W^T (nn.Linear forward,
@@ -65,6 +66,46 @@ typedef struct ofb_gemm_args {
 int64_t ofb_gemm_workspace_bytes(const ofb_gemm_args* args);
 int32_t ofb_gemm_is_streamed(const ofb_gemm_args* args);   /* 1 when every output tile goes through the stream-K tail */
 int ofb_gemm_f32(const ofb_gemm_args* args, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * The same contraction on operands that are ALREADY split into three bf16 planes ("P-format", csrc/gemm_p.hip): the exact
+ * split x = hi + mid + lo that gives the bf16 matrix pipe fp32 accuracy is done ONCE by the producer of each tensor instead
+ * of inside every GEMM tile that touches it, and the K loop is LDS-DMA + fragment reads + MFMAs only.
+ *
+ * P-format of X[R][C]: granules of 4 rows x 16 columns (384 B), stored [ceil(R/16)*4][ncb = ceil(C/16)]; a granule holds
+ * [plane hi|mid|lo][c % 16][r % 4] bf16.  Rows >= R / columns >= C inside the last granules are ZERO (the reduction axis
+ * relies on it).  A buffer needs ofb_pformat_bytes(R, C) bytes (tile-granular reads run past the matrix; that slack is never
+ * initialised and only reaches accumulators that are not stored).
+ * a_kc / b_kc = 1: the reduction runs along the columns C of that operand's P matrix (x[M][K], W[N][K]: nn.Linear forward,
+ * models/layers.py:491,515,845,863); 0: along its rows R (W[K..][N] in dY @ W; dY[tokens][N], x[tokens][K] in dY^T @ x).
+ * So the SAME P-format copy of an activation or weight feeds its forward, input-gradient and weight-gradient products.
+ * Output: f32 C (ldc) and / or P-format Cp ([R = M][C = N], c_ncb granule columns) - e.g. gelu(fc1) leaves the kernel as the
+ * P-format operand of fc2 plus the f32 pre-activation in aux.  Epilogue as ofb_gemm_f32.  Deterministic (fixed-order fix-up).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ofb_gemm_p_args {
+  const void* A; const void* B;
+  int32_t a_kc, b_kc;
+  int32_t a_ncb, b_ncb;      /* granule columns of each operand's P matrix */
+  int32_t M, N, K;
+  float* C; int32_t ldc;     /* f32 output or NULL */
+  void* Cp; int32_t c_ncb;   /* P-format output or NULL */
+  float alpha;
+  const float* bias;
+  const float* colscale;
+  const float* rowscale; int32_t rs_div;
+  const float* resid; int32_t ldr;
+  float* aux; int32_t ldaux;
+  int32_t act;
+  float* workspace; int64_t workspace_bytes;
+} ofb_gemm_p_args;
+
+int64_t ofb_pformat_bytes(int32_t R, int32_t C);
+/* X[R][C] (row-major, ld), optionally * rowscale[r / rs_div]  ->  P-format (zero padded).  Used for tensors whose producer is
+ * not one of the kernels below (weights once per optimizer step, DropPath-scaled gradients, patchified pixels). */
+int ofb_to_pformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div, void* stream);
+int ofb_from_pformat(const void* P, int32_t R, int32_t C, float* X, int32_t ld, void* stream);   /* exact: hi + mid + lo */
+int64_t ofb_gemm_p_workspace_bytes(const ofb_gemm_p_args* args);
+int ofb_gemm_p(const ofb_gemm_p_args* args, void* stream);
 
 /* out[i] = sum_s workspace[s*count + i] (+ out[i] if accumulate): sums per-chunk partial buffers (embed assembly) */
 int ofb_splitk_reduce(const float* workspace, int32_t splits, int64_t count, float* out, int32_t accumulate,

@@ -26,6 +26,7 @@
 // whatever the tile count, and weight gradients (few tiles, long K = all tokens) need no separate split-K path.  Partials are
 // summed in a fixed order: results are run-to-run deterministic.
 #include "ofb_common.h"
+#include "gemm_plan.h"
 #include <type_traits>
 
 #define BK 16
@@ -170,81 +171,7 @@ __device__ __forceinline__ void store_mc(const TileRegs& r, char* __restrict__ l
   }
 }
 
-struct Plan { int bm, bn, mt, nt, ntiles, I, W, full_rounds, R, q, S, qs; };
-
-__host__ __device__ inline Plan make_plan(int M, int N, int K, int W, int bm, int bn) {
-  Plan p;
-  p.bm = bm; p.bn = bn;
-  p.mt = (M + bm - 1) / bm;
-  p.nt = (N + bn - 1) / bn;
-  p.ntiles = p.mt * p.nt;
-  p.I = (K + BK - 1) / BK;
-  p.W = W;
-  p.full_rounds = p.ntiles / W;
-  p.R = p.ntiles - p.full_rounds * W;
-  // After >= 3 full rounds a remainder that fills at least half a round runs as one more (partly idle) data-parallel round:
-  // the idle share (< 1/8 of the launch) costs less than the partial-tile traffic and the fix-up launch of a streamed tail.
-  if (p.full_rounds >= 3 && 2 * p.R >= W) { p.full_rounds += 1; p.R = 0; }
-  p.q = p.R ? (int)(((long long)p.R * p.I + W - 1) / W) : 0;      // K-iterations per workgroup in the streamed tail (q <= I)
-  // Split-major tail: when the W workgroups divide (almost) evenly over the R tail tiles, cut every tile's K range into the
-  // same S pieces and give workgroup v piece v / R of tile v % R.  Workgroups that run side by side on one XCD then walk the
-  // SAME K rows of different tiles and share them in its L2 (weight gradients: every token row of dY / X is needed by all
-  // tiles), where the flattened runs above place neighbours on different K ranges of one tile and nothing is shared.
-  p.S = 0; p.qs = 0;
-  if (p.R > 0) {
-    const int S = W / p.R;
-    if (S >= 2 && (W - S * p.R) * 10 <= W) { p.S = S; p.qs = (p.I + S - 1) / S; }
-  }
-  return p;
-}
-
-__host__ __device__ __forceinline__ void tile_coord(const Plan& p, int tile, int& m0, int& n0) {
-  m0 = (tile / p.nt) * p.bm; n0 = (tile % p.nt) * p.bn;
-}
-
-// One unit of work: K-iterations [it0, it1) of output tile `tile`; slot < 0 -> full tile, fused epilogue to C;
-// slot >= 0 -> raw partial tile to workspace[slot].
-struct Seg { int m0, n0, it0, it1, slot; bool ok; };
-
-template <bool TAIL>
-__device__ __forceinline__ Seg get_seg(const Plan p, int v, int idx) {
-  Seg s;
-  s.m0 = s.n0 = s.it0 = s.it1 = 0; s.slot = -1; s.ok = false;
-  if (!TAIL) {
-    if (idx >= p.full_rounds) return s;
-    const int tile = v + idx * p.W;
-    if (tile >= p.ntiles) return s;
-    tile_coord(p, tile, s.m0, s.n0); s.it0 = 0; s.it1 = p.I; s.ok = true;
-    return s;
-  }
-  const int part = idx;
-  if (part > 1 || p.R == 0) return s;
-  if (p.S > 0) {                          // split-major: one piece per workgroup, slot = v
-    if (part != 0) return s;
-    const int sp = v / p.R, tl = v - sp * p.R;
-    const int i0 = sp * p.qs, i1 = min(i0 + p.qs, p.I);
-    if (sp >= p.S || i0 >= i1) return s;
-    const int tile = p.full_rounds * p.W + tl;
-    tile_coord(p, tile, s.m0, s.n0); s.it0 = i0; s.it1 = i1; s.slot = v; s.ok = true;
-    return s;
-  }
-  // R * I < W * I <= 768 * (K/16): fits 32 bits for every K the host accepts (checked in ofb_gemm_f32)
-  const int beg = v * p.q, tot = p.R * p.I;
-  const int end = min(beg + p.q, tot);
-  if (beg >= end) return s;
-  const int a = beg / p.I, it0 = beg - a * p.I;
-  const int n0 = end - beg;
-  const int first = min(p.I - it0, n0);
-  int tl, i0, i1;
-  if (part == 0) { tl = a; i0 = it0; i1 = it0 + first; }
-  else {
-    if (n0 - first <= 0) return s;
-    tl = a + 1; i0 = 0; i1 = n0 - first;
-  }
-  const int tile = p.full_rounds * p.W + tl;
-  tile_coord(p, tile, s.m0, s.n0); s.it0 = i0; s.it1 = i1; s.slot = 2 * v + part; s.ok = true;
-  return s;
-}
+using ofb_plan::Plan; using ofb_plan::make_plan; using ofb_plan::tile_coord; using ofb_plan::Seg; using ofb_plan::get_seg;
 
 // v = alpha*acc (+bias)(*colscale); act; (*rowscale); (+resid)   -- shared by the fused epilogue and the fix-up kernel
 __device__ __forceinline__ float epilogue_value(float alpha, int act, float* __restrict__ aux, int ldaux, float accv, int row,

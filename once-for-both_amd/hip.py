@@ -35,10 +35,12 @@ class GemmArgs(C.Structure):
 
 
 ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+# 'p': f32-operand GEMM calls convert to P-format and run csrc/gemm_p.hip; 'split': the in-loop split engine of csrc/gemm.hip
+ENGINE = os.environ.get('OFB_GEMM_ENGINE', 'p')
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_f32', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_from_pformat', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
@@ -106,6 +108,16 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kc, b_kc, alpha=1.0, bias=None, 
          resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, kscale=None, ks_div=1, a_colsum=None):
     """a_colsum (weight-gradient launches only): fused column sums of the stored A; falls back to a separate
     ofb_colsum launch when the GEMM is not fully streamed."""
+    if ENGINE == 'p' and not (not a_kc and b_kc):
+        # f32 operands through the P-format engine: one conversion pass per operand, then the plane GEMM.  The model path hands
+        # P-format tensors over directly (ops.py); this form serves callers that hold plain f32 matrices.
+        Ap = to_pformat(A, M, K, lda) if a_kc else to_pformat(A, K, M, lda, rowscale=kscale, rs_div=ks_div)
+        Bp = to_pformat(B, N, K, ldb) if b_kc else to_pformat(B, K, N, ldb)
+        gemm_p(Ap, Bp, a_kc, b_kc, M, N, K, C_out=C_out, ldc=ldc, alpha=alpha, bias=bias, colscale=colscale, rowscale=rowscale,
+               rs_div=rs_div, resid=resid, ldr=ldr, aux=aux, ldaux=ldaux, act=act)
+        if a_colsum is not None:
+            colsum(A, lda, K, M, a_colsum, rowscale=kscale, rs_div=ks_div)
+        return
     g = GemmArgs()
     g.A, g.B, g.C = ptr(A), ptr(B), ptr(C_out)
     g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
@@ -124,6 +136,70 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kc, b_kc, alpha=1.0, bias=None, 
     check(lib().ofb_gemm_f32(C.byref(g), stream()), 'ofb_gemm_f32')
     if a_colsum is not None and not fused:           # A stored [K][M]: column sums over its K rows
         colsum(A, lda, K, M, a_colsum, rowscale=kscale, rs_div=ks_div)
+
+
+# ---- P-format GEMM (csrc/gemm_p.hip): operands pre-split into three bf16 planes -----------------------------------------
+class GemmPArgs(C.Structure):
+    _fields_ = [
+        ('A', C.c_void_p), ('B', C.c_void_p), ('a_kc', C.c_int32), ('b_kc', C.c_int32), ('a_ncb', C.c_int32), ('b_ncb', C.c_int32),
+        ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
+        ('C', C.c_void_p), ('ldc', C.c_int32), ('Cp', C.c_void_p), ('c_ncb', C.c_int32),
+        ('alpha', C.c_float), ('bias', C.c_void_p), ('colscale', C.c_void_p), ('rowscale', C.c_void_p), ('rs_div', C.c_int32),
+        ('resid', C.c_void_p), ('ldr', C.c_int32), ('aux', C.c_void_p), ('ldaux', C.c_int32), ('act', C.c_int32),
+        ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
+    ]
+
+
+class PMat:
+    """A matrix X[R][C] in P-format (three bf16 planes in 4 x 16 granules, include/ofb_hip.h).  `buf` is a uint8 device tensor of
+    ofb_pformat_bytes(R, C) bytes."""
+    __slots__ = ('buf', 'R', 'C', 'ncb')
+
+    def __init__(self, R, C_, device, buf=None):
+        f = lib().ofb_pformat_bytes
+        f.restype = C.c_int64
+        self.R, self.C, self.ncb = int(R), int(C_), (int(C_) + 15) // 16
+        self.buf = buf if buf is not None else torch.empty(int(f(_i(R), _i(C_))), device=device, dtype=torch.uint8)
+
+    def to_f32(self):
+        out = torch.empty(self.R, self.C, device=self.buf.device, dtype=torch.float32)
+        check(lib().ofb_from_pformat(ptr(self.buf), _i(self.R), _i(self.C), ptr(out), _i(self.C), stream()), 'ofb_from_pformat')
+        return out
+
+
+def to_pformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1):
+    """f32 [R][C] (row stride ld; default: the 2-D tensor's own shape / stride) -> PMat, optionally scaled per row by
+    rowscale[r // rs_div]."""
+    if R is None:
+        R, Cc = x.shape
+    if ld is None:
+        ld = x.stride(0) if x.dim() == 2 else Cc
+    if x.dtype != torch.float32:
+        raise OfbError('to_pformat needs float32 input')
+    pm = PMat(R, Cc, x.device)
+    check(lib().ofb_to_pformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), stream()), 'ofb_to_pformat')
+    return pm
+
+
+def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
+           resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE):
+    """C[M][N] (f32 and / or P-format) = A * B on P-format operands (PMat); a_kc / b_kc: reduction along the operand's columns."""
+    g = GemmPArgs()
+    g.A, g.B, g.a_kc, g.b_kc, g.a_ncb, g.b_ncb = ptr(A.buf), ptr(B.buf), int(a_kc), int(b_kc), A.ncb, B.ncb
+    g.M, g.N, g.K = M, N, K
+    g.C, g.ldc = ptr(C_out), ldc
+    if Cp is not None:
+        if Cp.R != M or Cp.C != N:
+            raise OfbError('P-format output must be [M][N]')
+        g.Cp, g.c_ncb = ptr(Cp.buf), Cp.ncb
+    g.alpha, g.bias, g.colscale, g.rowscale, g.rs_div = alpha, ptr(bias), ptr(colscale), ptr(rowscale), rs_div
+    g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
+    lib().ofb_gemm_p_workspace_bytes.restype = C.c_int64
+    need = lib().ofb_gemm_p_workspace_bytes(C.byref(g))
+    if need > 0:
+        ws = _workspace(A.buf.device, need)
+        g.workspace, g.workspace_bytes = ptr(ws), ws.numel() * 4
+    check(lib().ofb_gemm_p(C.byref(g), stream()), 'ofb_gemm_p')
 
 
 def splitk_reduce(ws, splits, count, out, accumulate=False):

@@ -1,0 +1,123 @@
+"""P-format engine (csrc/gemm_p.hip) through the C ABI: exact f32 <-> plane conversion, the three operand-mode pairs, f32 and
+P-format outputs with the fused epilogues, ragged shapes and stream-K tails, against fp64 on the same seeded inputs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32) * scale
+
+
+def _close(got, exp, what, tol=3e-6):
+    err = (got.double().cpu() - exp).abs().max().item()
+    scale = exp.abs().max().item() + 1e-30
+    print(f'{what}: max abs err {err:.3e} (scale {scale:.3e})')
+    assert err <= tol * scale, what
+
+
+@pytest.mark.parametrize('R,C', [(4, 16), (197, 384), (130, 70), (33, 17), (1000, 264)])
+def test_pformat_round_trip_is_exact(R, C):
+    """x = hi + mid + lo with three bf16 planes carries all 24 significant bits: to_pformat -> from_pformat is the identity"""
+    from ofb_amd import hip
+    x = _mk((R, C), 1)
+    x[0, 0], x[-1, -1] = 0.0, -3.0e-20
+    x = (x * torch.pow(torch.tensor(2.0), torch.randint(-30, 30, (R, C)).float())).cuda()
+    pm = hip.to_pformat(x)
+    assert torch.equal(pm.to_f32(), x)
+    rs = _mk(((R + 6) // 7,), 2).cuda()
+    pm = hip.to_pformat(x, rowscale=rs, rs_div=7)
+    assert torch.equal(pm.to_f32(), x * rs[torch.arange(R, device='cuda') // 7].unsqueeze(1))
+
+
+SHAPES = [(256, 256, 64), (394, 384, 384), (591, 1152, 384), (130, 70, 36), (128, 1000, 384), (77, 13, 5), (591, 264, 200),
+          (2600, 520, 48), (8192, 1024, 80)]
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_gemm_p_modes_and_outputs(M, N, K):
+    from ofb_amd import hip
+    a, b = _mk((M, K), 3), _mk((N, K), 4)                       # logical A[M][K], B[N][K]
+    exact = a.double() @ b.double().t()
+    ad, bd = a.cuda(), b.cuda()
+    pa_kc, pb_kc = hip.to_pformat(ad), hip.to_pformat(bd)                                    # P matrices [rows][K]
+    pa_kr, pb_kr = hip.to_pformat(ad.t().contiguous()), hip.to_pformat(bd.t().contiguous())   # P matrices [K][rows]
+    for name, (A, B, akc, bkc) in {'kc,kc': (pa_kc, pb_kc, 1, 1), 'kc,kr': (pa_kc, pb_kr, 1, 0), 'kr,kr': (pa_kr, pb_kr, 0, 0)}.items():
+        out = torch.full((M, N), float('nan'), device='cuda')
+        outp = hip.PMat(M, N, 'cuda')
+        hip.gemm_p(A, B, akc, bkc, M, N, K, C_out=out, ldc=N, Cp=outp)
+        _close(out, exact, f'{name} {M}x{N}x{K} f32 out')
+        assert torch.equal(outp.to_f32(), out), 'the P-format output must carry exactly the f32 result'
+        out2 = torch.empty(M, N, device='cuda')
+        hip.gemm_p(A, B, akc, bkc, M, N, K, C_out=out2, ldc=N)
+        assert torch.equal(out, out2), 'deterministic (fixed-order partial sums)'
+    # the zero padding of a P-format OUTPUT must be real zeros: feed it to a product that reduces over its padded rows
+    outp = hip.PMat(M, N, 'cuda')
+    outp.buf.fill_(0x7f)                                           # poison (NaN patterns) before the kernel writes it
+    hip.gemm_p(pa_kc, pb_kc, 1, 1, M, N, K, Cp=outp)
+    y = torch.empty(N, K, device='cuda')
+    hip.gemm_p(outp, pa_kc, 0, 0, N, K, M, C_out=y, ldc=K)          # y = out^T @ a   (reduction over M, padded to 16)
+    _close(y, exact.t() @ a.double(), 'P output as KR operand (zero padding)', tol=2e-5)
+
+
+@pytest.mark.parametrize('M,N,K', [(394, 384, 384), (300, 1536, 384), (130, 70, 36)])
+def test_gemm_p_epilogues(M, N, K):
+    from ofb_amd import hip
+    x, w, b = _mk((M, K), 5), _mk((N, K), 6, 0.1), _mk((N,), 7)
+    cs, res = _mk((N,), 8), _mk((M, N), 9)
+    rs = _mk(((M + 196) // 197,), 10)
+    xp, wp = hip.to_pformat(x.cuda()), hip.to_pformat(w.cuda())
+    bd, csd, resd, rsd = b.cuda(), cs.cuda(), res.cuda(), rs.cuda()
+    ref = x.double() @ w.double().t() + b.double()
+    pre = ref * cs.double()
+    # fc1 form: bias, gate column scale, GELU; f32 pre-activation to aux, gelu output as P-format only
+    aux, hp = torch.empty(M, N, device='cuda'), hip.PMat(M, N, 'cuda')
+    hip.gemm_p(xp, wp, 1, 1, M, N, K, Cp=hp, bias=bd, colscale=csd, aux=aux, ldaux=N, act=hip.ACT_GELU)
+    _close(aux, pre, 'gelu pre-activation')
+    _close(hp.to_f32(), torch.nn.functional.gelu(pre), 'gelu out (P-format)')
+    # proj / fc2 form: residual + per-sample row scale
+    out = torch.empty(M, N, device='cuda')
+    hip.gemm_p(xp, wp, 1, 1, M, N, K, C_out=out, ldc=N, bias=bd, rowscale=rsd, rs_div=197, resid=resd, ldr=N)
+    rows = torch.arange(M) // 197
+    _close(out, ref * rs.double()[rows].unsqueeze(1) + res.double(), 'residual + rowscale')
+    # dGELU form with P-format output
+    dp = hip.PMat(M, N, 'cuda')
+    hip.gemm_p(xp, wp, 1, 1, M, N, K, Cp=dp, aux=aux, ldaux=N, act=hip.ACT_DGELU)
+    p = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(p).sum().backward()
+    _close(dp.to_f32(), (x.double() @ w.double().t()) * p.grad, 'dgelu (P-format)')
+
+
+def test_gemm_p_deit_small_layer_shapes():
+    """the bs-128 DeiT-S shapes (25216 tokens): full rounds + streamed tail; strided row sample against fp64"""
+    from ofb_amd import hip
+    M, D = 128 * 197, 384
+    x = _mk((M, D), 11)
+    xp = hip.to_pformat(x.cuda())
+    rows = torch.arange(0, M, 97)
+    for N in (1152, 384, 1536):
+        w, b = _mk((N, D), 12, 0.05), _mk((N,), 13)
+        out = torch.empty(M, N, device='cuda')
+        hip.gemm_p(xp, hip.to_pformat(w.cuda()), 1, 1, M, N, D, C_out=out, ldc=N, bias=b.cuda())
+        _close(out[rows.cuda()], x[rows].double() @ w.double().t() + b.double(), f'deit-s N {N}')
+    # weight gradient: dW[N][K] = dY^T X over all tokens (12 tiles, K = 25216: tail only)
+    dy = _mk((M, 1536), 14)
+    dw = torch.empty(1536, D, device='cuda')
+    hip.gemm_p(hip.to_pformat(dy.cuda()), xp, 0, 0, 1536, D, M, C_out=dw, ldc=D)
+    _close(dw, dy.double().t() @ x.double(), 'dW 1536x384x25216', tol=2e-5)
+
+
+def test_gemm_p_rejects_bad_arguments():
+    from ofb_amd import hip
+    a = hip.to_pformat(torch.zeros(32, 32, device='cuda'))
+    out = torch.zeros(32, 32, device='cuda')
+    with pytest.raises(hip.OfbError):
+        hip.gemm_p(a, a, 0, 1, 32, 32, 32, C_out=out, ldc=32)          # A^T B^T is not on the path
+    with pytest.raises(hip.OfbError):
+        hip.gemm_p(a, a, 1, 1, 32, 32, 32)                             # no output at all
+    with pytest.raises(hip.OfbError):
+        hip.gemm_p(a, a, 1, 1, 32, 32, 64, C_out=out, ldc=32)          # K beyond the operand's granule columns
+    with pytest.raises(hip.OfbError):
+        hip.gemm_p(a, a, 1, 1, 32, 32, 32, C_out=out, ldc=32, act=hip.ACT_DGELU)   # dGELU without aux
