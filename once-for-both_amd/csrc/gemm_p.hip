@@ -22,6 +22,7 @@
 // of gemm_plan.h (data-parallel rounds + K-split tail + deterministic fix-up).
 #include "ofb_common.h"
 #include "gemm_plan.h"
+#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -35,8 +36,27 @@ typedef short ps16x8 __attribute__((ext_vector_type(8)));
 typedef float pf32x2 __attribute__((ext_vector_type(2)));
 #define OFB_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 
-constexpr int BM = 256, BN = 256, WN = 4, MI = 4, NI = 2, NT = 512, NST = 3;
-constexpr int A_BYTES = BM * 16 * 6, B_BYTES = BN * 16 * 6, STAGE = A_BYTES + B_BYTES;       // 24 KB + 24 KB per K16 step
+// Tile configuration: WM x WN waves, wave tile (32 MI) x (32 NI), NST LDS stages, WGS workgroups per CU.  BN = 192 fits every
+// width of the DeiT family (192 | 384, 768, 1152, 1536, 2304, 3072) without padded columns.
+//   C192: 256 x 192, 8 waves, one workgroup per CU, 3 stages: the leanest main loop (fewest LDS-DMA bytes and barriers per MFMA);
+//         its epilogue is serial with its main loop, so it serves the products whose outputs are small next to their K loop.
+//   C128: 128 x 192, 4 waves, TWO workgroups per CU, 2 stages: the co-resident workgroup's MFMAs run under this one's epilogue
+//         (GELU / P-format split VALU work, output stores) - for the output-heavy products (fc1, its input gradient, qkv).
+template <int WM_, int WN_, int MI_, int NI_, int NST_, int WGS_>
+struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, NST = NST_, WGS = WGS_, NW = WM * WN;
+  static constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NT = 64 * NW;
+  static constexpr int A_BYTES = BM * 96, B_BYTES = BN * 96, STAGE = A_BYTES + B_BYTES;
+  static constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;          // 1-KB LDS-DMA pieces per stage
+  static constexpr int QA = A_PIECES / NW, QB = (B_PIECES + NW - 1) / NW;             // pieces per wave (the last B piece only for some waves)
+  static constexpr int HA = MI / 2;                                                   // row blocks per half step
+  static constexpr int HR = (NST * STAGE >= BN * 132 * 4) ? 128 : 64;                 // rows of the tile parked in LDS per epilogue pass
+  static constexpr int TROW = HR + 4, ITEMS = BN * (HR / 4) / NT;
+  static_assert(A_PIECES % NW == 0 && MI % 2 == 0 && BM % HR == 0 && (32 * MI) <= HR && HR % (32 * MI) == 0, "piece / epilogue schedule");
+  static_assert(BN * TROW * 4 <= NST * STAGE && QA == 3 && QB <= 5 && NST >= 2 && NST <= 3, "LDS budget / schedule");
+};
+using C192 = Cfg<4, 2, 2, 3, 3, 1>;
+using C128 = Cfg<2, 2, 2, 3, 2, 2>;
 constexpr int GRAN = 384;
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // v_cvt_pk_bf16_f32: a -> low half, b -> high half (RNE)
@@ -109,27 +129,57 @@ __device__ __forceinline__ float epi_value(const ofb_gemm_p_args& g, float accv,
   return v;
 }
 
-template <bool A_KC, bool B_KC, bool TAIL>
-__global__ __launch_bounds__(NT, 2) void gemm_p_kernel(const ofb_gemm_p_args g, const Plan p) {
+#ifdef OFB_P_STAMPS
+// lab only (scripts/lab/stamp_gemm_p.py): s_memtime stamps of wave 0 of every workgroup: [wg][unit][4] = unit start, K loop start,
+// K loop end, epilogue end
+__device__ unsigned long long ofb_p_stamps[1024 * 8 * 4];
+#define OFB_PSTAMP(slot) do { if (t == 0 && sidx < 8 && blockIdx.x < 1024) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ofb_p_stamps[(blockIdx.x * 8 + sidx) * 4 + slot] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define OFB_PSTAMP(slot) do { } while (0)
+#endif
+#define OFB_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+__device__ __forceinline__ void vm_wait(int n) {           // n is wave-uniform
+  switch (n) {
+    OFB_VMW(0) OFB_VMW(5) OFB_VMW(6) OFB_VMW(7) OFB_VMW(8) OFB_VMW(10) OFB_VMW(12) OFB_VMW(14) OFB_VMW(16)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// Epilogue forms are compile-time (EPI = set of E_* bits): with run-time flags hipcc has to assume that a side-input load may
+// follow an aliasing store and puts s_waitcnt vmcnt(0) between the stores of every element (measured: a 128 x 192 tile took longer
+// to store than to compute).  Each instantiation is straight-line: all loads of a pass, then arithmetic, then stores.
+enum : int { E_C = 1, E_P = 2, E_GELU = 4, E_DGELU = 8, E_RS = 16, E_RES = 32, E_ANY = 64 };
+
+template <class CF, bool A_KC, bool B_KC, bool TAIL, int EPI>
+__global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args g, const Plan p) {
+  constexpr int BM = CF::BM, BN = CF::BN, WN = CF::WN, MI = CF::MI, NI = CF::NI, HA = CF::HA, NST = CF::NST, NW = CF::NW;
+  constexpr int STAGE = CF::STAGE, A_BYTES = CF::A_BYTES, QA = CF::QA, QB = CF::QB, HR = CF::HR, TROW = CF::TROW;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, h = lane >> 5;
   const int wm0 = (w / WN) * (32 * MI), wn0 = (w % WN) * (32 * NI);
   const int a_ncb = g.a_ncb, b_ncb = g.b_ncb;
+  const bool blast = w + NW * (QB - 1) < CF::B_PIECES;   // this wave moves a QB-th B piece per stage (wave-uniform)
+  const int n_w = QA + QB - (blast ? 0 : 1);             // LDS-DMA instructions of this wave per stage
 
-  // LDS-DMA source offsets (bytes, relative to the tile / stage base) of this wave's three 1-KB pieces per operand
+  // LDS-DMA source offsets (bytes, relative to the tile / stage base) of this wave's 1-KB pieces (ids w, w + NW, ...)
   //   KC: piece = (block j of 32 rows, plane): lane -> granule tg = l>>3 of the block, 16-B chunk cp = (l&7) ^ swz(tg); the XOR on
   //       the SOURCE chunk (LDS stays lane-linear) makes the transposed fragment reads bank-conflict free
-  //   KR: the stage image is a linear copy of [4 row groups][BN/16 granules], cut into 1-KB pieces
-  unsigned a_off[3], b_off[3];
+  //   KR: the stage image is a linear copy of [4 row groups][B? / 16 granules], cut into 1-KB pieces
+  unsigned a_off[QA], b_off[QB];
+  {
+    const int tg = lane >> 3, cp = (lane & 7) ^ swz(tg);
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    const int piece = w + 8 * q;
-    const int j = piece / 3, pl = piece % 3, tg = lane >> 3, cp = (lane & 7) ^ swz(tg);
-    const int bl = piece * 1024 + lane * 16;
-    a_off[q] = A_KC ? (unsigned)(((8 * j + tg) * a_ncb) * GRAN + pl * 128 + cp * 16)
-                    : (unsigned)(((bl / (BM / 16 * GRAN)) * a_ncb) * GRAN + bl % (BM / 16 * GRAN));
-    b_off[q] = B_KC ? (unsigned)(((8 * j + tg) * b_ncb) * GRAN + pl * 128 + cp * 16)
-                    : (unsigned)(((bl / (BN / 16 * GRAN)) * b_ncb) * GRAN + bl % (BN / 16 * GRAN));
+    for (int q = 0; q < QA; ++q) {
+      const int piece = w + NW * q, j = piece / 3, pl = piece % 3, bl = piece * 1024 + lane * 16;
+      a_off[q] = A_KC ? (unsigned)(((8 * j + tg) * a_ncb) * GRAN + pl * 128 + cp * 16)
+                      : (unsigned)(((bl / (BM / 16 * GRAN)) * a_ncb) * GRAN + bl % (BM / 16 * GRAN));
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int piece = w + NW * q, j = piece / 3, pl = piece % 3, bl = piece * 1024 + lane * 16;
+      b_off[q] = B_KC ? (unsigned)(((8 * j + tg) * b_ncb) * GRAN + pl * 128 + cp * 16)
+                      : (unsigned)(((bl / (BN / 16 * GRAN)) * b_ncb) * GRAN + bl % (BN / 16 * GRAN));
+    }
   }
   // fragment read offsets (bytes inside an operand's stage image), two 8-byte reads per fragment
   int a_r0, a_r1, b_r0, b_r1;
@@ -151,36 +201,23 @@ __global__ __launch_bounds__(NT, 2) void gemm_p_kernel(const ofb_gemm_p_args g, 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // six LDS-DMA per wave and stage, invisible to hipcc's wait-count bookkeeping: counted by hand below (vmcnt(12/6/0)).
-  // Pieces of one wave sit 8 KB apart in the stage image (A: w, w+8, w+16; B follows A at +24 KB = 3 x 8 KB).
+  // LDS-DMA in inline asm (through the builtin hipcc drains every LDS-DMA with vmcnt(0) before the next ds_read): invisible to
+  // its wait-count bookkeeping, counted by hand (n_w per wave and stage).  The pieces of one wave sit NW KB apart in the stage
+  // image, A's first, then B's (A_BYTES = QA * NW KB).  M0 is written in the statement that uses it and restored afterwards.
   const unsigned lds0 = (unsigned)(size_t)OFB_LDSP(lds) + (unsigned)w * 1024u;
+  auto dma = [&](unsigned ldsaddr, unsigned voff, const char* base) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsaddr), "v"(voff), "s"(base) : "memory");
+  };
   auto issue = [&](int buf, const char* a_src, const char* b_src) __attribute__((always_inline)) {
     unsigned keep;
-    asm volatile(
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %2, %8\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %3, %8\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %4, %8\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %5, %9\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %6, %9\n\t"
-        "s_add_u32 m0, m0, 0x2000\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %7, %9\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "s"(lds0 + (unsigned)buf * (unsigned)STAGE), "v"(a_off[0]), "v"(a_off[1]), "v"(a_off[2]), "v"(b_off[0]), "v"(b_off[1]),
-          "v"(b_off[2]), "s"(a_src), "s"(b_src)
-        : "memory", "scc");
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep) :: "memory");
+    const unsigned l0 = lds0 + (unsigned)buf * (unsigned)STAGE;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) dma(l0 + q * (NW * 1024), a_off[q], a_src);
+#pragma unroll
+    for (int q = 0; q < QB - 1; ++q) dma(l0 + (QA + q) * (NW * 1024), b_off[q], b_src);
+    if (blast) dma(l0 + (QA + QB - 1) * (NW * 1024), b_off[QB - 1], b_src);
+    asm volatile("s_mov_b32 m0, %0" :: "s"(keep) : "memory");
   };
   auto frag = [&](const char* base, int r0, int r1, bool kc, int blk, int plane) __attribute__((always_inline)) -> pbf16x8 {
     ps16x4 lo4, hi4;
@@ -196,11 +233,11 @@ __global__ __launch_bounds__(NT, 2) void gemm_p_kernel(const ofb_gemm_p_args g, 
     ps16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     return __builtin_bit_cast(pbf16x8, v);
   };
-  pbf16x8 a01[2][3], a23[2][3], bb[2][NI][3];
-  auto rdA = [&](pbf16x8 (&dst)[2][3], int buf, int blk0) __attribute__((always_inline)) {
+  pbf16x8 alo[HA][3], ahi[HA][3], bb[2][NI][3];         // A fragments of the two half steps, B fragments of this / the next K step
+  auto rdA = [&](pbf16x8 (&dst)[HA][3], int buf, int blk0) __attribute__((always_inline)) {
     const char* la = lds + buf * STAGE;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < HA; ++i)
 #pragma unroll
       for (int pl = 0; pl < 3; ++pl) dst[i][pl] = frag(la, a_r0, a_r1, A_KC, (wm0 >> 5) + blk0 + i, pl);
   };
@@ -213,11 +250,12 @@ __global__ __launch_bounds__(NT, 2) void gemm_p_kernel(const ofb_gemm_p_args g, 
   };
   // six product terms, smallest first: (mid,mid) (hi,lo) (lo,hi) (hi,mid) (mid,hi) (hi,hi)
   constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
-#define OFB_MMA_HALF(AF, BF, BLK0)                                                                                                  \
-  _Pragma("unroll") for (int q = 0; q < 6; ++q) _Pragma("unroll") for (int i = 0; i < 2; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
+  constexpr int NMF = 6 * HA * NI, RD2 = 6 * HA + 6 * NI;       // MFMAs per half step; fragment reads riding in the second half
+#define OFB_MMA_HALF(AF, BF, BLK0)                                                                                                   \
+  _Pragma("unroll") for (int q = 0; q < 6; ++q) _Pragma("unroll") for (int i = 0; i < HA; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
       acc[BLK0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[i][TA[q]], BF[j][TB[q]], acc[BLK0 + i][j], 0, 0, 0);
 #define OFB_INTERLEAVE(NM, ND)                                                               \
-  _Pragma("unroll") for (int z_ = 0; z_ < NM; ++z_) {                                        \
+  _Pragma("unroll") for (int z_ = 0; z_ < (NM); ++z_) {                                      \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
     __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);                                      \
   }
@@ -226,43 +264,51 @@ __global__ __launch_bounds__(NT, 2) void gemm_p_kernel(const ofb_gemm_p_args g, 
   int sidx = 0;
   Seg cur = get_seg<TAIL>(p, v, 0);
   if (!cur.ok) return;
+  if (CF::WGS > 1 && p.stagger > 0 && (int)blockIdx.x >= p.W / 2) {
+    // de-phase the two workgroups of a CU (the later-dispatched half of the grid waits about half a tile): in lock step both sit
+    // in their epilogues together and the matrix pipe idles; out of phase one's epilogue runs under the other's MFMAs
+    for (int z = 0; z < p.stagger; ++z) __builtin_amdgcn_s_sleep(127);
+  }
   while (true) {
     const int nk = cur.it1 - cur.it0;
     const size_t a_step = A_KC ? GRAN : (size_t)4 * a_ncb * GRAN, b_step = B_KC ? GRAN : (size_t)4 * b_ncb * GRAN;
     const char* a_base = (const char*)g.A + (A_KC ? (size_t)(cur.m0 / 4) * a_ncb * GRAN : (size_t)(cur.m0 / 16) * GRAN) + cur.it0 * a_step;
     const char* b_base = (const char*)g.B + (B_KC ? (size_t)(cur.n0 / 4) * b_ncb * GRAN : (size_t)(cur.n0 / 16) * GRAN) + cur.it0 * b_step;
-    __builtin_amdgcn_s_barrier();                        // every wave is past the previous unit's LDS reads
+    OFB_PSTAMP(0);
+    __builtin_amdgcn_s_barrier();                        // every wave is past the previous unit's LDS traffic
     issue(0, a_base, b_base);
     if (nk > 1) issue(1, a_base + a_step, b_base + b_step);
-    if (nk > 2) issue(2, a_base + 2 * a_step, b_base + 2 * b_step);
-    if (nk > 2) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (NST > 2 && nk > 2) issue(2, a_base + 2 * a_step, b_base + 2 * b_step);
+    vm_wait(((nk < NST ? nk : NST) - 1) * n_w);          // stage 0 landed; the other prologue stages may be in flight
     __builtin_amdgcn_s_barrier();
-    rdA(a01, 0, 0);
+    OFB_PSTAMP(1);
+    rdA(alo, 0, 0);
     rdB(bb[0], 0);
     auto step = [&](int i, int buf, auto PAR) __attribute__((always_inline)) {
       constexpr int par = decltype(PAR)::value;
       const int nbuf = buf + 1 == NST ? 0 : buf + 1;
-      // first half: row blocks 0,1 x B(i); the reads of row blocks 2,3 ride in the MFMA gaps
+      // first half: lower row blocks x B(i); the reads of the upper row blocks ride in the MFMA gaps
       __builtin_amdgcn_sched_barrier(0);
-      rdA(a23, buf, 2);
-      OFB_MMA_HALF(a01, bb[par], 0)
-      OFB_INTERLEAVE(24, 1)
+      rdA(ahi, buf, HA);
+      OFB_MMA_HALF(alo, bb[par], 0)
+      OFB_INTERLEAVE(NMF, 1)
       __builtin_amdgcn_sched_barrier(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // this wave is done reading buf(i)
-      if (i + 2 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // own pieces of stage i+1 landed (i+2 may be in flight)
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      {                                                                      // own pieces of stage i+1 landed; later stages may fly
+        int young = nk - i - 2;
+        young = young < 0 ? 0 : (young > NST - 2 ? NST - 2 : young);
+        vm_wait(young * n_w);
+      }
       __builtin_amdgcn_s_barrier();
-      if (i + 3 < nk) issue(buf, a_base + (size_t)(i + 3) * a_step, b_base + (size_t)(i + 3) * b_step);
-      // second half: row blocks 2,3 x B(i); the reads of step i+1 (row blocks 0,1 and B) ride in the gaps (after the last step
-      // they fetch a stale buffer that nothing consumes)
+      if (i + NST < nk) issue(buf, a_base + (size_t)(i + NST) * a_step, b_base + (size_t)(i + NST) * b_step);
+      // second half: upper row blocks x B(i); the reads of step i+1 (lower row blocks and B) ride in the gaps (after the last
+      // step they fetch a stale buffer that nothing consumes)
       __builtin_amdgcn_sched_barrier(0);
-      rdA(a01, nbuf, 0);
+      rdA(alo, nbuf, 0);
       rdB(bb[par ^ 1], nbuf);
-      OFB_MMA_HALF(a23, bb[par], 2)
-      OFB_INTERLEAVE(12, 2)
-      OFB_INTERLEAVE(12, 1)
+      OFB_MMA_HALF(ahi, bb[par], HA)
+      OFB_INTERLEAVE(RD2 > NMF ? RD2 - NMF : 0, 2)
+      OFB_INTERLEAVE(RD2 > NMF ? 2 * NMF - RD2 : NMF, 1)
       __builtin_amdgcn_sched_barrier(0);
     };
     int buf = 0, i = 0;
@@ -274,20 +320,43 @@ __global__ __launch_bounds__(NT, 2) void gemm_p_kernel(const ofb_gemm_p_args g, 
     }
     if (i < nk) step(i, buf, std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the trailing (unused) fragment reads
+    OFB_PSTAMP(2);
 
     {
-      // Fused epilogue through LDS (the stage buffers are free now): the accumulators of one 128-row half of the tile are parked as
-      // T[col][128 rows (+4 pad)] f32 - a lane's four consecutive rows of a column are one ds_write_b128 - and all 8 waves finish
-      // that half together, one (4-row group, column) item per thread and trip: f32 loads / stores are coalesced along the columns,
-      // the P-format store is the item's three 8-byte plane slots.  The body exists once (a direct epilogue over 128 accumulator
-      // values per lane does not unroll and spills).
-      constexpr int TROW = 132;                                     // floats per column of T: conflict-free b128 writes and reads
+      // Epilogue through LDS (the stage buffers are free now): the accumulators of HR rows of the tile are parked as
+      // T[col][HR rows (+4 pad)] f32 - a lane's four consecutive rows of a column are one ds_write_b128 - and all waves finish
+      // those rows together, one (4-row group, column) item per thread and trip: f32 loads / stores are coalesced along the
+      // columns, the P-format store is the item's three 8-byte plane slots.  The body exists once (a direct epilogue over all
+      // accumulator values of a lane does not unroll and spills); the side inputs of EPB items are requested before any of them
+      // is finished, so the memory latency is paid once per batch.
+      // Item map: a thread keeps its lane's columns (lane + 64 c, c < BN/64) and walks the 4-row groups rg = w, w + NW, ..., so
+      // the per-column inputs (bias, gate) are loaded once per tile; the side inputs of ALL items of a pass (residual or saved
+      // pre-activation, DropPath row scales) are requested before any item is finished: one exposed memory latency per pass.
+      constexpr int NC = BN / 64, NRG = (HR / 4) / NW, ITEMS = NC * NRG;
+      static_assert(BN % 64 == 0 && (HR / 4) % NW == 0, "epilogue item map");
+      constexpr bool ANY = (EPI & E_ANY) != 0;
+      // which parts exist: known at compile time for the specialised forms, asked at run time by the generic form (E_ANY)
+      const bool has_c = ANY ? g.C != nullptr : (EPI & E_C) != 0, has_p = ANY ? g.Cp != nullptr : (EPI & E_P) != 0;
+      const bool gelu = ANY ? g.act == OFB_ACT_GELU : (EPI & E_GELU) != 0, dg = ANY ? g.act == OFB_ACT_DGELU : (EPI & E_DGELU) != 0;
+      const bool has_rs = ANY ? g.rowscale != nullptr : (EPI & E_RS) != 0, has_res = ANY ? g.resid != nullptr : (EPI & E_RES) != 0;
       float* T = reinterpret_cast<float*>(lds);
+      float* __restrict__ Cout = g.C;
+      float* __restrict__ auxw = g.aux;
+      const float* __restrict__ auxr = g.aux;
+      const float* __restrict__ resid = g.resid;
+      const float* __restrict__ rowscale = g.rowscale;
       const int rp_out = (g.M + 15) & ~15;
+      float biasv[NC], csv[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        const int col = cur.n0 + lane + 64 * c, colc = col < g.N ? col : g.N - 1;
+        biasv[c] = (!TAIL && g.bias) ? g.bias[colc] : 0.f;
+        csv[c] = (!TAIL && g.colscale) ? g.colscale[colc] : 1.f;
+      }
       __builtin_amdgcn_s_barrier();                                 // every wave has finished its fragment reads
 #pragma unroll
-      for (int half = 0; half < 2; ++half) {
-        if (w / WN == half) {
+      for (int half = 0; half < BM / HR; ++half) {
+        if (wm0 / HR == half) {
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -295,40 +364,82 @@ __global__ __launch_bounds__(NT, 2) void gemm_p_kernel(const ofb_gemm_p_args g, 
 #pragma unroll
               for (int gq = 0; gq < 4; ++gq) {
                 f32x4 q4 = {acc[mi][ni][4 * gq], acc[mi][ni][4 * gq + 1], acc[mi][ni][4 * gq + 2], acc[mi][ni][4 * gq + 3]};
-                *reinterpret_cast<f32x4*>(T + (wn0 + 32 * ni + l31) * TROW + 32 * mi + 8 * gq + 4 * h) = q4;
+                *reinterpret_cast<f32x4*>(T + (wn0 + 32 * ni + l31) * TROW + (wm0 % HR) + 32 * mi + 8 * gq + 4 * h) = q4;
                 acc[mi][ni][4 * gq] = 0.f; acc[mi][ni][4 * gq + 1] = 0.f; acc[mi][ni][4 * gq + 2] = 0.f; acc[mi][ni][4 * gq + 3] = 0.f;
               }
         }
         __syncthreads();
-        const int col = cur.n0 + (t & 255);
-        const bool colok = col < g.N;
-        const float bias = (!TAIL && g.bias && colok) ? g.bias[col] : 0.f, cs = (!TAIL && g.colscale && colok) ? g.colscale[col] : 1.f;
-        for (int it = 0; it < 16; ++it) {
-          const int rgl = 2 * it + (t >> 8);                        // 4-row group inside the half (0..31)
-          const int row0 = cur.m0 + 128 * half + 4 * rgl;
-          const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + (t & 255) * TROW + 4 * rgl);
-          if (TAIL) {                                               // raw partial tile -> workspace[slot][BM][BN]
-            float* ws = g.workspace + (size_t)cur.slot * (BM * BN) + (size_t)(128 * half + 4 * rgl) * BN + (t & 255);
+        if (TAIL) {                                                   // raw partial tile -> workspace[slot][BM][BN]
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) ws[tt * BN] = q4[tt];
-            continue;
-          }
-          if (row0 >= rp_out) break;
-          float pv[4];
+          for (int k = 0; k < NRG; ++k) {
+            const int rgl = w + NW * k;
 #pragma unroll
-          for (int tt = 0; tt < 4; ++tt) {
-            const int row = row0 + tt;
-            const bool ok = colok && row < g.M;
-            const float val = epi_value(g, q4[tt], row, col, bias, cs, ok);
-            if (g.C && ok) g.C[(size_t)row * g.ldc + col] = val;
-            pv[tt] = ok ? val : 0.f;
+            for (int c = 0; c < NC; ++c) {
+              const int lcol = lane + 64 * c;
+              const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + lcol * TROW + 4 * rgl);
+              float* __restrict__ ws = g.workspace + (size_t)cur.slot * (BM * BN) + (size_t)(HR * half + 4 * rgl) * BN + lcol;
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt) ws[tt * BN] = q4[tt];
+            }
           }
-          if (g.Cp && col < g.c_ncb * 16)
-            store_p4((char*)g.Cp + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8, pv[0], pv[1], pv[2], pv[3]);
+        } else {
+          // all side inputs of the pass first, one exposed latency.  Interior tiles (every row and column in range: all but the last
+          // row / column of tiles) take the unguarded body: with per-element guards hipcc puts each store in its own block behind
+          // s_waitcnt vmcnt(0), i.e. one memory round trip per store.
+          auto pass = [&](auto GUARDED) __attribute__((always_inline)) {
+            constexpr bool GD = decltype(GUARDED)::value;
+            f32x4 side[ITEMS], side2[ITEMS], rsv[NRG];
+#pragma unroll
+            for (int k = 0; k < NRG; ++k) {
+              const int row0 = cur.m0 + HR * half + 4 * (w + NW * k);
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt) {
+                const int row = row0 + tt, rowc = (!GD || row < g.M) ? row : g.M - 1;
+                rsv[k][tt] = has_rs ? rowscale[g.rs_div == 1 ? rowc : rowc / g.rs_div] : 1.f;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                  const int col = cur.n0 + lane + 64 * c, colc = (!GD || col < g.N) ? col : g.N - 1;
+                  side[k * NC + c][tt] = dg ? auxr[(size_t)rowc * g.ldaux + colc] : 0.f;
+                  side2[k * NC + c][tt] = has_res ? resid[(size_t)rowc * g.ldr + colc] : 0.f;
+                }
+              }
+            }
+#pragma unroll
+            for (int k = 0; k < NRG; ++k) {
+              const int rgl = w + NW * k, row0 = cur.m0 + HR * half + 4 * rgl;
+#pragma unroll
+              for (int c = 0; c < NC; ++c) {
+                const int lcol = lane + 64 * c, col = cur.n0 + lcol;
+                const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + lcol * TROW + 4 * rgl);
+                const bool colok = !GD || col < g.N;
+                float pv[4];
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                  const int row = row0 + tt;
+                  const bool ok = !GD || (colok && row < g.M);
+                  float val = (q4[tt] * g.alpha + biasv[c]) * csv[c];
+                  if (gelu) {
+                    if (auxw && ok) auxw[(size_t)row * g.ldaux + col] = val;
+                    val = ofb_gelu(val);
+                  } else if (dg) {
+                    val *= ofb_dgelu(side[k * NC + c][tt]);
+                  }
+                  val = val * rsv[k][tt] + side2[k * NC + c][tt];
+                  if (has_c && ok) Cout[(size_t)row * g.ldc + col] = val;
+                  pv[tt] = ok ? val : 0.f;
+                }
+                if (has_p && (!GD || (row0 < rp_out && col < g.c_ncb * 16)))
+                  store_p4((char*)g.Cp + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8, pv[0], pv[1], pv[2], pv[3]);
+              }
+            }
+          };
+          if (cur.m0 + BM <= g.M && cur.n0 + BN <= g.N) pass(std::false_type{});
+          else pass(std::true_type{});
         }
-        if (half == 0) __syncthreads();                             // T is rewritten by the other half (the next unit starts with a barrier)
+        if (half + 1 < BM / HR) __syncthreads();                    // T is rewritten by the next pass (the next unit starts with a barrier)
       }
     }
+    OFB_PSTAMP(3);
     const Seg nxt = get_seg<TAIL>(p, v, ++sidx);
     if (!nxt.ok) break;
     cur = nxt;
@@ -337,7 +448,9 @@ __global__ __launch_bounds__(NT, 2) void gemm_p_kernel(const ofb_gemm_p_args g, 
 
 // Sums the partial tiles of each streamed tail tile in a fixed contributor order and applies the epilogue.
 // grid (R, BM / 4), BN threads: block (r, rg) handles rows [4*rg, 4*rg+4) of tail tile r, one column per thread.
-__global__ __launch_bounds__(BN) void gemm_p_fixup_kernel(const ofb_gemm_p_args g, const Plan p) {
+template <class CF>
+__global__ __launch_bounds__(CF::BN) void gemm_p_fixup_kernel(const ofb_gemm_p_args g, const Plan p) {
+  constexpr int BM = CF::BM, BN = CF::BN;
   const int r = blockIdx.x, rgl = blockIdx.y, t = threadIdx.x;
   const int tile = p.full_rounds * p.W + r;
   int m0, n0;
@@ -346,7 +459,21 @@ __global__ __launch_bounds__(BN) void gemm_p_fixup_kernel(const ofb_gemm_p_args 
   const int v0 = p.S ? 0 : lo / p.q, v1 = p.S ? (p.I + p.qs - 1) / p.qs - 1 : (hi - 1) / p.q;
   auto slot_of = [&](int v) { return p.S ? v * p.R + r : ((v * p.q < lo) ? 2 * v + 1 : 2 * v); };
   float sum[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int v = v0; v <= v1; ++v) {
+  int v = v0;
+  for (; v + 3 <= v1; v += 4) {                       // four contributors per trip in flight, added in contributor order
+    float x[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* ws = g.workspace + (size_t)slot_of(v + u) * (BM * BN) + (size_t)(4 * rgl) * BN + t;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) x[u][tt] = ws[tt * BN];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) sum[tt] += x[u][tt];
+  }
+  for (; v <= v1; ++v) {
     const float* ws = g.workspace + (size_t)slot_of(v) * (BM * BN) + (size_t)(4 * rgl) * BN + t;
 #pragma unroll
     for (int tt = 0; tt < 4; ++tt) sum[tt] += ws[tt * BN];
@@ -379,23 +506,70 @@ int p_cu_count() {
   return n;
 }
 
-Plan plan_p(const ofb_gemm_p_args& g) {
-  int W = p_cu_count();                              // one 144-KB workgroup per CU
-  const int tiles = ofb_cdiv(g.M, BM) * ofb_cdiv(g.N, BN);
-  const long long iters = (long long)tiles * ofb_cdiv(g.K, 16);
-  if (iters < W) W = (int)iters;
-  return make_plan(g.M, g.N, g.K, W, BM, BN, 16);
+// Tile configuration: C128 (two workgroups per CU) measured equal or faster than C192 on every product of the step (same-box
+// scripts/gemm_step_shapes_p.py); C192 is compiled only into lab builds (-DOFB_GEMM_P_LAB, OFB_GEMM_P_TILE=192).
+int p_tile_choice(const ofb_gemm_p_args&) {
+#ifdef OFB_GEMM_P_LAB
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("OFB_GEMM_P_TILE"); forced = e ? atoi(e) : 0; }
+  if (forced == 192) return 192;
+#endif
+  return 128;
 }
 
-template <bool A_KC, bool B_KC>
+template <class CF>
+Plan plan_p(const ofb_gemm_p_args& g) {
+  int W = p_cu_count() * CF::WGS;
+  const int tiles = ofb_cdiv(g.M, CF::BM) * ofb_cdiv(g.N, CF::BN);
+  const long long iters = (long long)tiles * ofb_cdiv(g.K, 16);
+  if (iters < W) W = (int)iters;
+  Plan p = make_plan(g.M, g.N, g.K, W, CF::BM, CF::BN, 16);
+  // Tail policy: a streamed tail costs its share of K steps plus the partial tiles' round trip through HBM and the fix-up
+  // launch (~13 K steps' worth); when that is not cheaper than one more (partly idle) data-parallel round, run the round.
+  if (p.R > 0 && (long long)(((long long)p.R * p.I + W - 1) / W) + 13 >= p.I) {
+    p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;
+  }
+  static int stag = -1;
+  if (stag < 0) { const char* e = getenv("OFB_GEMM_P_STAGGER"); stag = e ? atoi(e) : 0; }
+  p.stagger = stag;
+  return p;
+}
+
+template <class CF, bool A_KC, bool B_KC, int EPI>
+void launch_full(const ofb_gemm_p_args& g, const Plan& p, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_p_kernel<CF, A_KC, B_KC, false, EPI>), dim3(p.W), dim3(CF::NT), 0, s, g, p);
+}
+
+template <class CF, bool A_KC, bool B_KC>
 int launch_p(const ofb_gemm_p_args& g, const Plan& p, hipStream_t s) {
-  const dim3 grid(p.W), block(NT);
-  if (p.full_rounds > 0) hipLaunchKernelGGL((gemm_p_kernel<A_KC, B_KC, false>), grid, block, 0, s, g, p);
+  if (p.full_rounds > 0) {
+    const int f = (g.C ? E_C : 0) | (g.Cp ? E_P : 0) | (g.act == OFB_ACT_GELU ? E_GELU : 0) | (g.act == OFB_ACT_DGELU ? E_DGELU : 0) |
+                  (g.rowscale ? E_RS : 0) | (g.resid ? E_RES : 0);
+    switch (f) {     // the forms the model issues; anything else takes the generic (run-time flags) instantiation
+      case E_C: launch_full<CF, A_KC, B_KC, E_C>(g, p, s); break;
+      case E_C | E_RES: launch_full<CF, A_KC, B_KC, E_C | E_RES>(g, p, s); break;
+      case E_C | E_RS | E_RES: launch_full<CF, A_KC, B_KC, E_C | E_RS | E_RES>(g, p, s); break;
+      case E_P | E_GELU: launch_full<CF, A_KC, B_KC, E_P | E_GELU>(g, p, s); break;
+      case E_P | E_DGELU: launch_full<CF, A_KC, B_KC, E_P | E_DGELU>(g, p, s); break;
+      case E_P: launch_full<CF, A_KC, B_KC, E_P>(g, p, s); break;
+      default: launch_full<CF, A_KC, B_KC, E_ANY>(g, p, s); break;
+    }
+  }
   if (p.R > 0) {
-    hipLaunchKernelGGL((gemm_p_kernel<A_KC, B_KC, true>), grid, block, 0, s, g, p);
-    hipLaunchKernelGGL(gemm_p_fixup_kernel, dim3(p.R, BM / 4), dim3(BN), 0, s, g, p);
+    hipLaunchKernelGGL((gemm_p_kernel<CF, A_KC, B_KC, true, 0>), dim3(p.W), dim3(CF::NT), 0, s, g, p);
+    hipLaunchKernelGGL(gemm_p_fixup_kernel<CF>, dim3(p.R, CF::BM / 4), dim3(CF::BN), 0, s, g, p);
   }
   return ofb_launch_status();
+}
+
+template <class CF>
+int run_p(const ofb_gemm_p_args& g, hipStream_t s) {
+  const Plan p = plan_p<CF>(g);
+  if ((long long)p.W * p.I > 0x7fffffffLL / 2) return OFB_ELIMIT;
+  if (p.R && (!g.workspace || g.workspace_bytes < (int64_t)2 * p.W * CF::BM * CF::BN * (int64_t)sizeof(float))) return OFB_EINVAL;
+  if (g.a_kc && g.b_kc) return launch_p<CF, true, true>(g, p, s);
+  if (g.a_kc) return launch_p<CF, true, false>(g, p, s);
+  return launch_p<CF, false, false>(g, p, s);
 }
 
 }  // namespace
@@ -429,8 +603,11 @@ extern "C" int ofb_from_pformat(const void* P, int32_t R, int32_t C, float* X, i
 
 extern "C" int64_t ofb_gemm_p_workspace_bytes(const ofb_gemm_p_args* args) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
-  const Plan p = plan_p(*args);
-  return p.R ? (int64_t)2 * p.W * BM * BN * (int64_t)sizeof(float) : 0;
+#ifdef OFB_GEMM_P_LAB
+  if (p_tile_choice(*args) == 192) { const Plan p = plan_p<C192>(*args); return p.R ? (int64_t)2 * p.W * C192::BM * C192::BN * (int64_t)sizeof(float) : 0; }
+#endif
+  const Plan p = plan_p<C128>(*args);
+  return p.R ? (int64_t)2 * p.W * C128::BM * C128::BN * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int ofb_gemm_p(const ofb_gemm_p_args* args, void* stream) {
@@ -445,15 +622,19 @@ extern "C" int ofb_gemm_p(const ofb_gemm_p_args* args, void* stream) {
   // granule columns of each operand's P matrix must cover its extent along that axis
   if (g.a_ncb < ((g.a_kc ? g.K : g.M) + 15) / 16 || g.b_ncb < ((g.b_kc ? g.K : g.N) + 15) / 16) return OFB_EINVAL;
   if (!ofb_aligned16(g.A) || !ofb_aligned16(g.B) || (g.Cp && !ofb_aligned16(g.Cp))) return OFB_EINVAL;
-  const Plan p = plan_p(g);
-  if ((long long)p.W * p.I > 0x7fffffffLL / 2) return OFB_ELIMIT;
-  if (p.R && (!g.workspace || g.workspace_bytes < ofb_gemm_p_workspace_bytes(args))) return OFB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   ofb_prof_pre(0, s, 2.0 * g.M * g.N * (double)g.K);
-  int rc;
-  if (g.a_kc && g.b_kc) rc = launch_p<true, true>(g, p, s);
-  else if (g.a_kc) rc = launch_p<true, false>(g, p, s);
-  else rc = launch_p<false, false>(g, p, s);
+#ifdef OFB_GEMM_P_LAB
+  const int rc = p_tile_choice(g) == 192 ? run_p<C192>(g, s) : run_p<C128>(g, s);
+#else
+  const int rc = run_p<C128>(g, s);
+#endif
   ofb_prof_post(0, s);
   return rc;
 }
+
+#ifdef OFB_P_STAMPS
+extern "C" int ofb_diag_p_stamps(unsigned long long* out_host) {      /* lab only, not part of the ABI */
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(ofb_p_stamps), sizeof(unsigned long long) * 1024 * 8 * 4);
+}
+#endif

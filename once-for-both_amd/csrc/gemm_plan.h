@@ -6,11 +6,11 @@
 
 namespace ofb_plan {
 
-struct Plan { int bm, bn, mt, nt, ntiles, I, W, full_rounds, R, q, S, qs; };
+struct Plan { int bm, bn, mt, nt, ntiles, I, W, full_rounds, R, q, S, qs, stagger; };
 
 __host__ __device__ inline Plan make_plan(int M, int N, int K, int W, int bm, int bn, int bk = 16) {
   Plan p;
-  p.bm = bm; p.bn = bn;
+  p.bm = bm; p.bn = bn; p.stagger = 0;
   p.mt = (M + bm - 1) / bm;
   p.nt = (N + bn - 1) / bn;
   p.ntiles = p.mt * p.nt;

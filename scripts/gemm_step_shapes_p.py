@@ -1,0 +1,50 @@
+"""Times every GEMM configuration of one DeiT-S bs=128 search step on the P-format engine (operands converted beforehand),
+with its real epilogue and output form (run on the GPU box).  Compare: OFB_GEMM_ENGINE=split python scripts/gemm_step_shapes.py"""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from ofb_amd import hip
+M, D, H3, HID = 128 * 197, 384, 1152, 1536
+def run(tag, fn, flops, count, iters=10):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters): fn()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print(f'{tag:44s} {ms*1e3:8.1f} us {flops/ms/1e9:7.1f} TF   x{count:2d}/step = {ms*count:6.2f} ms')
+    return ms * count
+r = lambda *s: torch.randn(*s, device='cuda')
+P = hip.to_pformat
+x, rs = r(M, D), torch.rand(128, device="cuda").repeat_interleave(197)
+xp = P(x)
+tot = 0
+w, b, g = r(H3, D), r(H3), r(H3); y = torch.empty(M, H3, device='cuda'); wp = P(w)
+tot += run('fwd qkv  KC,KC bias+gate -> f32', lambda: hip.gemm_p(xp, wp, 1, 1, M, H3, D, C_out=y, ldc=H3, bias=b, colscale=g), 2.*M*H3*D, 12)
+w2, b2 = r(D, D), r(D); y2 = torch.empty(M, D, device='cuda'); w2p = P(w2)
+tot += run('fwd proj KC,KC bias+rowscale+resid -> f32', lambda: hip.gemm_p(xp, w2p, 1, 1, M, D, D, C_out=y2, ldc=D, bias=b2, rowscale=rs, resid=x, ldr=D), 2.*M*D*D, 12)
+w3, b3, g3 = r(HID, D), r(HID), r(HID); hpre = torch.empty(M, HID, device='cuda'); hP = hip.PMat(M, HID, 'cuda'); w3p = P(w3)
+tot += run('fwd fc1  KC,KC bias+gate+GELU aux -> P', lambda: hip.gemm_p(xp, w3p, 1, 1, M, HID, D, Cp=hP, bias=b3, colscale=g3, act=hip.ACT_GELU, aux=hpre, ldaux=HID), 2.*M*HID*D, 12)
+w4 = r(D, HID); w4p = P(w4)
+tot += run('fwd fc2  KC,KC bias+rowscale+resid -> f32', lambda: hip.gemm_p(hP, w4p, 1, 1, M, D, HID, C_out=y2, ldc=D, bias=b2, rowscale=rs, resid=x, ldr=D), 2.*M*D*HID, 12)
+dq = r(M, H3); dqp = P(dq)
+tot += run('bwd dX qkv  KC,KR +resid (K=1152) -> f32', lambda: hip.gemm_p(dqp, wp, 1, 0, M, D, H3, C_out=y2, ldc=D, resid=x, ldr=D), 2.*M*H3*D, 12)
+tot += run('bwd dO proj KC,KR (K=384) -> f32', lambda: hip.gemm_p(xp, w2p, 1, 0, M, D, D, C_out=y2, ldc=D), 2.*M*D*D, 12)
+dhP = hip.PMat(M, HID, 'cuda')
+tot += run('bwd dH fc2  KC,KR dgelu -> P', lambda: hip.gemm_p(xp, w4p, 1, 0, M, HID, D, Cp=dhP, act=hip.ACT_DGELU, aux=hpre, ldaux=HID), 2.*M*HID*D, 12)
+tot += run('bwd dX fc1  KC,KR +resid (K=1536) -> f32', lambda: hip.gemm_p(dhP, w3p, 1, 0, M, D, HID, C_out=y2, ldc=D, resid=x, ldr=D), 2.*M*HID*D, 12)
+dw = torch.empty(H3, D, device='cuda')
+tot += run('bwd dW qkv  KR,KR', lambda: hip.gemm_p(dqp, xp, 0, 0, H3, D, M, C_out=dw, ldc=D), 2.*M*H3*D, 12)
+dw2 = torch.empty(D, D, device='cuda')
+tot += run('bwd dW proj KR,KR', lambda: hip.gemm_p(xp, xp, 0, 0, D, D, M, C_out=dw2, ldc=D), 2.*M*D*D, 12)
+dw3 = torch.empty(HID, D, device='cuda')
+tot += run('bwd dW fc1  KR,KR', lambda: hip.gemm_p(dhP, xp, 0, 0, HID, D, M, C_out=dw3, ldc=D), 2.*M*HID*D, 12)
+dw4 = torch.empty(D, HID, device='cuda')
+tot += run('bwd dW fc2  KR,KR', lambda: hip.gemm_p(xp, hP, 0, 0, D, HID, M, C_out=dw4, ldc=HID), 2.*M*D*HID, 12)
+print(f'sum over 12 blocks: {tot:.2f} ms')
+tot2 = 0
+tot2 += run('convert x [M][384] -> P', lambda: P(x), 0, 12 * 6)
+hh = r(M, HID)
+tot2 += run('convert h [M][1536] -> P', lambda: P(hh), 0, 12 * 2)
+print(f'conversions (if not fused into producers): {tot2:.2f} ms')
