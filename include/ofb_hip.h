@@ -104,6 +104,10 @@ int64_t ofb_pformat_bytes(int32_t R, int32_t C);
  * not one of the kernels below (weights once per optimizer step, DropPath-scaled gradients, patchified pixels). */
 int ofb_to_pformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div, void* stream);
 int ofb_from_pformat(const void* P, int32_t R, int32_t C, float* X, int32_t ld, void* stream);   /* exact: hi + mid + lo */
+/* column sums of a P-format matrix, first stage: partial[ofb_colsum_p_slabs(R)][ceil(C/16)*16] (rows of a 256-row slab added in
+ * order); sum the slabs with ofb_colsum.  Bias gradients of tensors that exist only in P-format. */
+int32_t ofb_colsum_p_slabs(int32_t R);
+int ofb_colsum_p(const void* P, int32_t R, int32_t C, float* partial, void* stream);
 int64_t ofb_gemm_p_workspace_bytes(const ofb_gemm_p_args* args);
 int ofb_gemm_p(const ofb_gemm_p_args* args, void* stream);
 

@@ -112,6 +112,31 @@ __global__ void from_pformat_kernel(const char* __restrict__ P, int ncb, float* 
     if (4 * rg + t < R) X[(size_t)(4 * rg + t) * ld + c] = v[t];
 }
 
+// out partial[slab][c] = sum over the slab's rows of X[r][c] (hi + mid + lo, rows in order): column sums of a P-format matrix (bias
+// gradients of tensors that exist only in P-format).  grid (ncb / 4, slabs), 256 threads = 4 waves x 64 columns; wave w takes the row
+// groups w, w + 4, ... of the slab, the four waves' sums are added in wave order (deterministic).
+constexpr int CS_SLAB_RG = 64;                      // row groups (256 rows) per slab
+__global__ __launch_bounds__(256) void colsum_p_kernel(const char* __restrict__ P, int ncb, int rgs, float* __restrict__ partial, int ld) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, cb = blockIdx.x * 4 + (lane >> 4), slab = blockIdx.y;
+  float s = 0.f;
+  if (cb < ncb) {
+    const int rg1 = min(rgs, (slab + 1) * CS_SLAB_RG);
+    for (int rg = slab * CS_SLAB_RG + w; rg < rg1; rg += 4) {
+      const char* slot = P + ((size_t)rg * ncb + cb) * GRAN + (lane & 15) * 8;
+      const uint2 h = *reinterpret_cast<const uint2*>(slot), m = *reinterpret_cast<const uint2*>(slot + 128),
+                  l = *reinterpret_cast<const uint2*>(slot + 256);
+      s += bf16_lo(h.x) + (bf16_lo(m.x) + bf16_lo(l.x));
+      s += bf16_hi(h.x) + (bf16_hi(m.x) + bf16_hi(l.x));
+      s += bf16_lo(h.y) + (bf16_lo(m.y) + bf16_lo(l.y));
+      s += bf16_hi(h.y) + (bf16_hi(m.y) + bf16_hi(l.y));
+    }
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && cb < ncb) partial[(size_t)slab * ld + blockIdx.x * 64 + lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 // ---- the GEMM -----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz(int tg) { return ((tg >> 1) & 3) << 1; }
 
@@ -576,10 +601,11 @@ int run_p(const ofb_gemm_p_args& g, hipStream_t s) {
 
 extern "C" int64_t ofb_pformat_bytes(int32_t R, int32_t C) {
   if (R <= 0 || C <= 0) return 0;
-  // row groups up to the next 256-row tile boundary (mode KC reads whole tiles) + 16 granules of slack behind the last row
-  // group (mode KR reads whole 256-column tiles); the slack is never initialised and only ever feeds accumulators that are
-  // not stored
-  const int64_t ncb = (C + 15) / 16, rgs = (int64_t)((R + 255) / 256) * 64;
+  // Tile-granular reads run past the matrix: mode KC reads whole 128-row (A) or 192-row (B) tiles, so the row groups are
+  // allocated up to the next 256-row boundary plus one more 256-row tile (covers any tile height <= 256 at any offset); mode KR
+  // reads whole 128- / 192-column tiles, i.e. up to 12 granules behind the last row group.  The slack is never initialised and
+  // only ever feeds accumulators that are not stored.
+  const int64_t ncb = (C + 15) / 16, rgs = (int64_t)((R + 255) / 256) * 64 + 64;
   return (rgs * ncb + 16) * GRAN;
 }
 
@@ -598,6 +624,16 @@ extern "C" int ofb_from_pformat(const void* P, int32_t R, int32_t C, float* X, i
   const int ncb = (C + 15) / 16, rgs = (R + 3) / 4;
   hipLaunchKernelGGL(from_pformat_kernel, dim3((C + 255) / 256, rgs), dim3(256), 0, (hipStream_t)stream, (const char*)P, ncb, X, R,
                      C, ld);
+  return ofb_launch_status();
+}
+
+extern "C" int32_t ofb_colsum_p_slabs(int32_t R) { return R > 0 ? (((R + 15) / 16) * 4 + CS_SLAB_RG - 1) / CS_SLAB_RG : 0; }
+
+extern "C" int ofb_colsum_p(const void* P, int32_t R, int32_t C, float* partial, void* stream) {
+  if (!P || !partial || R <= 0 || C <= 0) return OFB_EINVAL;
+  const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4, slabs = ofb_colsum_p_slabs(R);
+  hipLaunchKernelGGL(colsum_p_kernel, dim3((ncb + 3) / 4, slabs), dim3(256), 0, (hipStream_t)stream, (const char*)P, ncb, rgs, partial,
+                     ncb * 16);
   return ofb_launch_status();
 }
 

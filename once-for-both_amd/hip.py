@@ -40,7 +40,7 @@ ENGINE = os.environ.get('OFB_GEMM_ENGINE', 'p')
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_from_pformat', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
@@ -178,6 +178,43 @@ def to_pformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1):
         raise OfbError('to_pformat needs float32 input')
     pm = PMat(R, Cc, x.device)
     check(lib().ofb_to_pformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), stream()), 'ofb_to_pformat')
+    return pm
+
+
+def colsum_p(pm, out):
+    """out[C] = column sums of a P-format matrix (two deterministic stages)."""
+    slabs = int(lib().ofb_colsum_p_slabs(_i(pm.R)))
+    ld = pm.ncb * 16
+    part = torch.empty(slabs, ld, device=pm.buf.device, dtype=torch.float32)
+    check(lib().ofb_colsum_p(ptr(pm.buf), _i(pm.R), _i(pm.C), ptr(part), stream()), 'ofb_colsum_p')
+    colsum(part, ld, slabs, pm.C, out)
+
+
+# P-format copies of the weights: made once per optimizer step and kept ON the Parameter object (an attribute, so the copy
+# lives and dies with the tensor it mirrors - a table keyed by data_ptr could hand a recycled address someone else's planes).
+# The optimizers / EMA / compress() bump the epoch after they changed parameters through raw pointers; torch in-place edits show
+# up in _version.  One copy feeds the forward, input-gradient and weight-gradient products.
+_weight_epoch = 0
+
+
+def bump_weight_epoch():
+    global _weight_epoch
+    _weight_epoch += 1
+
+
+def weight_p(W, shape2d=None):
+    """P-format copy of a weight viewed as W[N][K] (shape2d: the 2-D view of a conv weight)."""
+    ent = getattr(W, '_ofb_wp', None)
+    if ent is not None and ent[0] == _weight_epoch and ent[1] == W._version and ent[3] == tuple(W.shape):
+        return ent[2]
+    if not W.is_contiguous():
+        raise OfbError('weight_p needs a contiguous weight')
+    N, K = shape2d if shape2d is not None else W.shape
+    pm = to_pformat(W, N, K, K)
+    try:
+        W._ofb_wp = (_weight_epoch, W._version, pm, tuple(W.shape))
+    except AttributeError:
+        pass
     return pm
 
 

@@ -52,6 +52,73 @@ def linear_bwd_weight(dy2d, x2d, kscale=None, ks_div=1, out=None, want_bias=Fals
     return (dW, db) if want_bias else dW
 
 
+# ---------------------------------------------------------------------------------------------------
+# P-format path (csrc/gemm_p.hip): every GEMM operand is handed over as three pre-split bf16 planes.  Producers on the path
+# (LayerNorm, the GELU epilogue of fc1, ...) attach the P-format copy of their output to the tensor object (`_ofb_p`); anything
+# that arrives without one is converted by one ofb_to_pformat pass.  Weights are converted once per optimizer step (hip.weight_p).
+# ---------------------------------------------------------------------------------------------------
+def _use_p():
+    return hip.ENGINE == 'p'
+
+
+def _P(t, M, K):
+    """P-format [M][K] copy of an activation (cached on the tensor object by its producer, else converted now)"""
+    pm = getattr(t, '_ofb_p', None)
+    if pm is not None and pm.R == M and pm.C == K:
+        return pm
+    return hip.to_pformat(t, M, K, K)
+
+
+def _pm(buf, R, C):
+    return hip.PMat(R, C, buf.device, buf=buf)
+
+
+def p_linear_fwd(xP, M, K, WP, b, colscale=None, act=hip.ACT_NONE, aux=None, rowscale=None, rs_div=1, resid=None, want_f32=True,
+                 want_p=False):
+    """y[M,N] = x[M,K] @ W[N,K]^T (+ fused epilogue), WP = hip.weight_p(W); returns (f32 y or None, P-format y or None)"""
+    N, dev = WP.R, WP.buf.device
+    y = torch.empty(M, N, device=dev, dtype=torch.float32) if want_f32 else None
+    yP = hip.PMat(M, N, dev) if want_p else None
+    hip.gemm_p(xP, WP, 1, 1, M, N, K, C_out=y, ldc=N, Cp=yP, bias=b, colscale=colscale, act=act, aux=aux, ldaux=N,
+               rowscale=rowscale, rs_div=rs_div, resid=resid, ldr=N)
+    return y, yP
+
+
+def p_linear_bwd_input(dyP, M, N, WP, K, resid=None, act=hip.ACT_NONE, aux=None, want_f32=True, want_p=False):
+    """dX[M,K] = dY[M,N] @ W[N,K]: dY reduced along its columns (KC), W along its rows (KR): the SAME P-format copy of W as forward"""
+    dx = torch.empty(M, K, device=dyP.buf.device, dtype=torch.float32) if want_f32 else None
+    dxP = hip.PMat(M, K, dyP.buf.device) if want_p else None
+    hip.gemm_p(dyP, WP, 1, 0, M, K, N, C_out=dx, ldc=K, Cp=dxP, resid=resid, ldr=K, act=act, aux=aux, ldaux=K)
+    return dx, dxP
+
+
+def p_linear_bwd_weight(dyP, xP, M, N, K, out=None):
+    """dW[N,K] = dY[M,N]^T @ X[M,K]: both reduced along their rows (the tokens)"""
+    dW = out if out is not None else torch.empty(N, K, device=dyP.buf.device, dtype=torch.float32)
+    hip.gemm_p(dyP, xP, 0, 0, N, K, M, C_out=dW, ldc=K)
+    return dW
+
+
+def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None):
+    """P-format backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None): dx (+resid fused), dW, db, dg.
+    WP: the forward's P-format copy of W; dy_colsum: callable giving colsum(dY) (the raw bias gradient)."""
+    N, K = WP.R, WP.C
+    W = W.view(N, K)
+    slot = grad_slot(W)
+    if gvec is None:
+        dx, _ = p_linear_bwd_input(dyP, M, N, WP, K, resid=resid)
+        dW = p_linear_bwd_weight(dyP, xP, M, N, K, out=slot)
+        return dx, dW, (dy_colsum() if b is not None else None), None
+    WeffP = hip.to_pformat(W, N, K, K, rowscale=gvec)                    # g[n] * W[n][:] straight into planes
+    dx, _ = p_linear_bwd_input(dyP, M, N, WeffP, K, resid=resid)
+    dWraw = p_linear_bwd_weight(dyP, xP, M, N, K)
+    dbraw = dy_colsum() if b is not None else None
+    dW = slot if slot is not None else _new(W, N, K)
+    db, dg = (_new(W, N) if b is not None else None), _new(W, N)
+    hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K)
+    return dx, dW, db, dg
+
+
 def bias_grad(dy2d, rowscale=None, rs_div=1):
     M, N = dy2d.shape
     db = _new(dy2d, N)
@@ -98,11 +165,24 @@ class Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, W, b):
         x2d, W = _c(x2d), _c(W)
+        if _use_p():
+            M, K = x2d.shape
+            xP, WP = _P(x2d, M, K), hip.weight_p(W)
+            ctx.save_for_backward(xP.buf, W, b)
+            ctx.mk, ctx.wp = (M, K), WP
+            return p_linear_fwd(xP, M, K, WP, b)[0]
         ctx.save_for_backward(x2d, W, b)
         return linear_fwd(x2d, W, b)
 
     @staticmethod
     def backward(ctx, dy):
+        if _use_p():
+            xbuf, W, b = ctx.saved_tensors
+            M, K = ctx.mk
+            dy = _c(dy)
+            dyP = hip.to_pformat(dy, M, W.shape[0], W.shape[0])
+            dx, dW, db, _ = _p_gated_linear_bwd(dyP, lambda: bias_grad(dy), _pm(xbuf, M, K), M, W, ctx.wp, b, None)
+            return dx, dW, db
         x2d, W, b = ctx.saved_tensors
         dx, dW, db, _ = _gated_linear_bwd(_c(dy), x2d, W, b, None)
         return dx, dW, db
@@ -160,12 +240,25 @@ class AttnBranch(torch.autograd.Function):
         M = B * N
         x2d = x.view(M, D)
         g3 = None if g is None else g.reshape(-1).repeat(3).contiguous()
+        r2d = x2d if resid is None else _c(resid).view(M, D)
+        if _use_p():
+            xP, wqP, wpP = _P(x, M, D), hip.weight_p(wqkv), hip.weight_p(wproj)
+            ctx.wp = (wqP, wpP)
+            qkv, _ = p_linear_fwd(xP, M, D, wqP, bqkv, colscale=g3)
+            Hd = qkv.shape[1] // 3
+            dh = Hd // heads
+            o, lse = _new(x, M, Hd), _new(x, B * heads, N)
+            hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
+            oP = hip.to_pformat(o, M, Hd, Hd)
+            out, _ = p_linear_fwd(oP, M, Hd, wpP, bproj, rowscale=rowscale, rs_div=1, resid=r2d)
+            ctx.save_for_backward(xP.buf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, oP.buf)
+            ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None)
+            return out.view(B, N, D)
         qkv = linear_fwd(x2d, wqkv, bqkv, colscale=g3)
         Hd = qkv.shape[1] // 3
         dh = Hd // heads
         o, lse = _new(x, M, Hd), _new(x, B * heads, N)
         hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
-        r2d = x2d if resid is None else _c(resid).view(M, D)
         out = linear_fwd(o, wproj, bproj, rowscale=rowscale, rs_div=1, resid=r2d)
         ctx.save_for_backward(x2d, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale)
         ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None)
@@ -173,6 +266,8 @@ class AttnBranch(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if _use_p():
+            return AttnBranch._backward_p(ctx, dout)
         x2d, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale = ctx.saved_tensors
         B, N, D, heads, dh, scale, self_resid, has_pb = ctx.meta
         M = B * N
@@ -191,6 +286,29 @@ class AttnBranch(torch.autograd.Function):
         return dx.view(B, N, D), dres, dwq, dbq, dwp, dbp, dg, None, None, None
 
 
+def _attn_backward_p(ctx, dout):
+    xbuf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, obuf = ctx.saved_tensors
+    B, N, D, heads, dh, scale, self_resid, has_pb = ctx.meta
+    M, Hd = B * N, heads * dh
+    xP, oP = _pm(xbuf, M, D), _pm(obuf, M, Hd)
+    d2 = _c(dout).view(M, D)
+    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale)     # gradient of the branch output, DropPath factor applied on the way
+    wqP, wpP = ctx.wp
+    do, _ = p_linear_bwd_input(d2sP, M, D, wpP, Hd)
+    dwp = p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=grad_slot(wproj))
+    dbp = bias_grad(d2, rowscale=rowscale) if has_pb else None
+    dqkv = torch.empty_like(qkv)
+    hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
+    dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd)
+    dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: bias_grad(dqkv), xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None)
+    dg = None if dg3 is None else dg3.view(3, heads, dh).sum(0)
+    dres = None if self_resid else dout
+    return dx.view(B, N, D), dres, dwq, dbq, dwp, dbp, dg, None, None, None
+
+
+AttnBranch._backward_p = staticmethod(_attn_backward_p)
+
+
 class MlpBranch(torch.autograd.Function):
     """out = resid + rowscale[token] * fc2(gelu(g * fc1(x)))   (layers.py:843-865 + residual/DropPath).
     rowscale is the per-sample DropPath factor expanded to one entry per token ([B*N])."""
@@ -204,8 +322,18 @@ class MlpBranch(torch.autograd.Function):
         gv = None if g is None else _c(g.reshape(-1))
         hid = w1.shape[0]
         hpre = _new(x, M, hid)
-        h = linear_fwd(x2d, w1, b1, colscale=gv, act=hip.ACT_GELU, aux=hpre)
         r2d = x2d if resid is None else _c(resid).view(M, D)
+        if _use_p():
+            xP, w1P, w2P = _P(x, M, D), hip.weight_p(w1), hip.weight_p(w2)
+            ctx.wp = (w1P, w2P)
+            # gelu(g * fc1(x)) leaves the kernel as the P-format operand of fc2 (and of the fc2 weight gradient); only the f32
+            # pre-activation is kept beside it for GELU'
+            _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU, aux=hpre, want_f32=False, want_p=True)
+            out, _ = p_linear_fwd(hP, M, hid, w2P, b2, rowscale=rowscale, rs_div=1, resid=r2d)
+            ctx.save_for_backward(xP.buf, hpre, hP.buf, w1, b1, w2, gv, rowscale)
+            ctx.meta = (B, N, D, resid is None, b2 is not None)
+            return out.view(B, N, D)
+        h = linear_fwd(x2d, w1, b1, colscale=gv, act=hip.ACT_GELU, aux=hpre)
         out = linear_fwd(h, w2, b2, rowscale=rowscale, rs_div=1, resid=r2d)
         ctx.save_for_backward(x2d, hpre, h, w1, b1, w2, gv, rowscale)
         ctx.meta = (B, N, D, resid is None, b2 is not None)
@@ -213,6 +341,8 @@ class MlpBranch(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if _use_p():
+            return MlpBranch._backward_p(ctx, dout)
         x2d, hpre, h, w1, b1, w2, gv, rowscale = ctx.saved_tensors
         B, N, D, self_resid, has_b2 = ctx.meta
         M = B * N
@@ -228,6 +358,32 @@ class MlpBranch(torch.autograd.Function):
         return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None
 
 
+def _mlp_backward_p(ctx, dout):
+    xbuf, hpre, hbuf, w1, b1, w2, gv, rowscale = ctx.saved_tensors
+    B, N, D, self_resid, has_b2 = ctx.meta
+    M, hid = B * N, w1.shape[0]
+    xP, hP = _pm(xbuf, M, D), _pm(hbuf, M, hid)
+    d2 = _c(dout).view(M, D)
+    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale)
+    # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> P-format only
+    w1P, w2P = ctx.wp
+    _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_DGELU, aux=hpre, want_f32=False, want_p=True)
+    dw2 = p_linear_bwd_weight(d2sP, hP, M, D, hid, out=grad_slot(w2))
+    db2 = bias_grad(d2, rowscale=rowscale) if has_b2 else None
+
+    def dh_colsum():
+        out = _new(hpre, hid)
+        hip.colsum_p(dhP, out)
+        return out
+
+    dx, dw1, db1, dg = _p_gated_linear_bwd(dhP, dh_colsum, xP, M, w1, w1P, b1, gv, resid=d2 if self_resid else None)
+    dres = None if self_resid else dout
+    return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None
+
+
+MlpBranch._backward_p = staticmethod(_mlp_backward_p)
+
+
 class PatchEmbedTokens(torch.autograd.Function):
     """imgs -> (B, L+1, D) token buffer: conv16/16 as a GEMM over patchified pixels (layers.py:177), embed gate
     (:191), pos-embed, patch masking + mask token, cls row (vision_transformer.py:615-651)."""
@@ -241,7 +397,12 @@ class PatchEmbedTokens(torch.autograd.Function):
         patches = imgs.reshape(B, Cin, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * L, Cin * patch * patch)
         patches = _c(patches)
         w2d = wconv.reshape(D, -1)
-        conv = linear_fwd(patches, w2d, bconv)
+        if _use_p():
+            patchesP = hip.to_pformat(patches, B * L, w2d.shape[1], w2d.shape[1])
+            conv, _ = p_linear_fwd(patchesP, B * L, w2d.shape[1], hip.weight_p(wconv, (D, w2d.shape[1])), bconv)
+            patches = patchesP.buf                       # the backward needs the patches only as a weight-gradient operand
+        else:
+            conv = linear_fwd(patches, w2d, bconv)
         tok = _new(imgs, B, L + 1, D)
         gv = None if g is None else _c(g.reshape(-1))
         posv, clsv = _c(pos.reshape(L + 1, D)), _c(cls.reshape(-1))
@@ -266,7 +427,12 @@ class PatchEmbedTokens(torch.autograd.Function):
         dgm = _new(conv, 2, D)
         hip.colsum(part[1], D, chunks * (L + 1), D, dgm[0])
         hip.colsum(part[2], D, chunks * (L + 1), D, dgm[1])
-        dw, db = linear_bwd_weight(dconv, patches, want_bias=True, out=grad_slot(w2d))
+        if _use_p():
+            Kp = w2d.shape[1]
+            dw = p_linear_bwd_weight(hip.to_pformat(dconv, B * L, D, D), _pm(patches, B * L, Kp), B * L, D, Kp, out=grad_slot(w2d))
+            db = bias_grad(dconv)
+        else:
+            dw, db = linear_bwd_weight(dconv, patches, want_bias=True, out=grad_slot(w2d))
         dcls = dpos[0].reshape(cshape)
         return (None, dw.view(wshape), db, None if gshape is None else dgm[0].view(gshape), dpos.view(pshape), dcls,
                 None if mshape is None else dgm[1].view(mshape), None, None)

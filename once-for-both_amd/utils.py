@@ -71,6 +71,7 @@ class ModelEma:
                 self._table = (*self._build_table(pairs), sig)
             dev_tab, _, n, maxn, _ = self._table
             hip.ema_update(dev_tab, n, maxn, self.decay)
+            hip.bump_weight_epoch()              # the EMA weights changed under their P-format copies
         if changed:
             self.intersect(changed)
 

@@ -508,6 +508,7 @@ class MIMVisionTransformer(MAEBaseModel):
         Rank-averaged alphas (collective C3) come from ONE fused all-reduce over every live module instead of one per
         module; decisions are taken on the host from that single copy, so all ranks cut identically."""
         from .dp import average_scalars
+        hip.bump_weight_epoch()                                  # weights are about to be cut: drop their P-format copies
         assert int(self.switch_cell_patch.sum()) == 1            # single patch cell (patch_search is off on this path)
         finish_patch, execute_patch = True, False
         self.alpha_patch.requires_grad = False
@@ -549,6 +550,7 @@ class MIMVisionTransformer(MAEBaseModel):
         """reference vision_transformer.py:747-757: fold every frozen gate into the weights / tokens it scales."""
         assert self.finish_search == True
         self.fused = True
+        hip.bump_weight_epoch()
         we = self.patch_embed.score.data.clone().unsqueeze(-2)            # (1, 1, D)
         if self.mask_token is not None:
             self.mask_token = nn.Parameter(self.mask_token.data * we)
