@@ -103,6 +103,10 @@ int64_t ofb_pformat_bytes(int32_t R, int32_t C);
 /* X[R][C] (row-major, ld), optionally * rowscale[r / rs_div]  ->  P-format (zero padded).  Used for tensors whose producer is
  * not one of the kernels below (weights once per optimizer step, DropPath-scaled gradients, patchified pixels). */
 int ofb_to_pformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div, void* stream);
+/* the same pass also leaves partial[ofb_colsum_p_slabs(R)][ceil(C/16)*16] = column sums per 256-row slab (sum them with ofb_colsum):
+ * a bias gradient db = colsum(dY) rides on the conversion of dY */
+int ofb_to_pformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
+                          float* partial, void* stream);
 int ofb_from_pformat(const void* P, int32_t R, int32_t C, float* X, int32_t ld, void* stream);   /* exact: hi + mid + lo */
 /* column sums of a P-format matrix, first stage: partial[ofb_colsum_p_slabs(R)][ceil(C/16)*16] (rows of a 256-row slab added in
  * order); sum the slabs with ofb_colsum.  Bias gradients of tensors that exist only in P-format. */

@@ -58,6 +58,7 @@ struct Cfg {
 using C192 = Cfg<4, 2, 2, 3, 3, 1>;
 using C128 = Cfg<2, 2, 2, 3, 2, 2>;
 constexpr int GRAN = 384;
+constexpr int CS_SLAB_RG = 64;                      // row groups (256 rows) per column-sum slab
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {          // v_cvt_pk_bf16_f32: a -> low half, b -> high half (RNE)
   pf32x2 v = {a, b};
@@ -98,6 +99,35 @@ __global__ void to_pformat_kernel(const float* __restrict__ X, int R, int C, int
   }
   store_p4(P + ((size_t)rg * ncb + (c >> 4)) * GRAN + (c & 15) * 8, v[0], v[1], v[2], v[3]);
 }
+// The same conversion for a gradient whose column sums are wanted as well (bias gradients: db = colsum(dY)): one pass over dY
+// writes the planes AND partial[slab][c] = sum of the slab's (scaled) rows, added in row order; the slabs are summed by ofb_colsum.
+// grid (ceil(C16 / 64), slabs of 256 rows), 256 threads: wave w converts the row groups w, w + 4, ... of the slab, lane = column.
+__global__ __launch_bounds__(256) void to_pformat_colsum_kernel(const float* __restrict__ X, int R, int C, int ld, char* __restrict__ P,
+                                                                int ncb, int rgs, const float* __restrict__ rowscale, int rs_div,
+                                                                float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + lane, slab = blockIdx.y;
+  float s = 0.f;
+  if (c < ncb * 16) {
+    const int rg1 = min(rgs, (slab + 1) * CS_SLAB_RG);
+    for (int rg = slab * CS_SLAB_RG + w; rg < rg1; rg += 4) {
+      float v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = 4 * rg + t;
+        float x = (r < R && c < C) ? X[(size_t)r * ld + c] : 0.f;
+        if (rowscale && r < R) x *= rowscale[rs_div == 1 ? r : r / rs_div];
+        v[t] = x;
+      }
+      s += (v[0] + v[1]) + (v[2] + v[3]);
+      store_p4(P + ((size_t)rg * ncb + (c >> 4)) * GRAN + (c & 15) * 8, v[0], v[1], v[2], v[3]);
+    }
+  }
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && c < ncb * 16) partial[(size_t)slab * (ncb * 16) + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
 // P -> X[R][C] (hi + mid + lo is exact)
 __global__ void from_pformat_kernel(const char* __restrict__ P, int ncb, float* __restrict__ X, int R, int C, int ld) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x, rg = blockIdx.y;
@@ -115,7 +145,6 @@ __global__ void from_pformat_kernel(const char* __restrict__ P, int ncb, float* 
 // out partial[slab][c] = sum over the slab's rows of X[r][c] (hi + mid + lo, rows in order): column sums of a P-format matrix (bias
 // gradients of tensors that exist only in P-format).  grid (ncb / 4, slabs), 256 threads = 4 waves x 64 columns; wave w takes the row
 // groups w, w + 4, ... of the slab, the four waves' sums are added in wave order (deterministic).
-constexpr int CS_SLAB_RG = 64;                      // row groups (256 rows) per slab
 __global__ __launch_bounds__(256) void colsum_p_kernel(const char* __restrict__ P, int ncb, int rgs, float* __restrict__ partial, int ld) {
   __shared__ float red[4][64];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, cb = blockIdx.x * 4 + (lane >> 4), slab = blockIdx.y;
@@ -549,10 +578,26 @@ Plan plan_p(const ofb_gemm_p_args& g) {
   const long long iters = (long long)tiles * ofb_cdiv(g.K, 16);
   if (iters < W) W = (int)iters;
   Plan p = make_plan(g.M, g.N, g.K, W, CF::BM, CF::BN, 16);
-  // Tail policy: a streamed tail costs its share of K steps plus the partial tiles' round trip through HBM and the fix-up
-  // launch (~13 K steps' worth); when that is not cheaper than one more (partly idle) data-parallel round, run the round.
-  if (p.R > 0 && (long long)(((long long)p.R * p.I + W - 1) / W) + 13 >= p.I) {
-    p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;
+  // Tail policy (costs in K steps of one workgroup, ~2.3 us): a streamed tail costs its K steps plus the partial tiles' round trip
+  // through HBM (~0.019 steps per 96-KB partial at 4.5 TB/s) plus the extra launches (~3.5 steps); one more (partly idle)
+  // data-parallel round costs I steps.  The split-major piece count S is chosen to minimise that sum (short tails: few large
+  // pieces; weight gradients: one piece per workgroup); the tail must beat the round by 10 % to be worth its HBM traffic.
+  if (p.R > 0) {
+    const double PC = 0.019, FIX = 3.5;
+    double best = 0.9 * p.I;
+    int bestS = -1;                                                  // -1: run the remainder as one more round
+    const int smax = W / p.R;
+    for (int S = 2; S <= smax; ++S) {
+      const double c = (double)((p.I + S - 1) / S) + (double)p.R * S * PC + FIX;
+      if (c < best) { best = c; bestS = S; }
+    }
+    if (smax < 2) {                                                  // flattened runs: up to two partial tiles per workgroup
+      const double c = (double)(((long long)p.R * p.I + W - 1) / W) + (double)(2 * p.R < 2 * W ? 2 * p.R : 2 * W) * PC + FIX;
+      if (c < best) { best = c; bestS = 0; }
+    }
+    if (bestS < 0) { p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0; }
+    else if (bestS > 0) { p.S = bestS; p.qs = (p.I + bestS - 1) / bestS; }
+    else { p.S = 0; p.qs = 0; }
   }
   static int stag = -1;
   if (stag < 0) { const char* e = getenv("OFB_GEMM_P_STAGGER"); stag = e ? atoi(e) : 0; }
@@ -616,6 +661,16 @@ extern "C" int ofb_to_pformat(const float* X, int32_t R, int32_t C, int32_t ld, 
   const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4;
   hipLaunchKernelGGL(to_pformat_kernel, dim3((ncb * 16 + 255) / 256, rgs), dim3(256), 0, (hipStream_t)stream, X, R, C, ld, (char*)P,
                      ncb, rowscale, rs_div);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_to_pformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
+                                     float* partial, void* stream) {
+  if (!X || !P || !partial || R <= 0 || C <= 0 || ld < C) return OFB_EINVAL;
+  if (rowscale && rs_div <= 0) return OFB_EINVAL;
+  const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4, slabs = (rgs + CS_SLAB_RG - 1) / CS_SLAB_RG;
+  hipLaunchKernelGGL(to_pformat_colsum_kernel, dim3((ncb * 16 + 63) / 64, slabs), dim3(256), 0, (hipStream_t)stream, X, R, C, ld, (char*)P,
+                     ncb, rgs, rowscale, rs_div, partial);
   return ofb_launch_status();
 }
 

@@ -40,7 +40,7 @@ ENGINE = os.environ.get('OFB_GEMM_ENGINE', 'p')
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
@@ -167,9 +167,9 @@ class PMat:
         return out
 
 
-def to_pformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1):
+def to_pformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1, colsum_out=None):
     """f32 [R][C] (row stride ld; default: the 2-D tensor's own shape / stride) -> PMat, optionally scaled per row by
-    rowscale[r // rs_div]."""
+    rowscale[r // rs_div].  colsum_out [C]: also receives the column sums of the (scaled) matrix from the same pass."""
     if R is None:
         R, Cc = x.shape
     if ld is None:
@@ -177,6 +177,13 @@ def to_pformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1):
     if x.dtype != torch.float32:
         raise OfbError('to_pformat needs float32 input')
     pm = PMat(R, Cc, x.device)
+    if colsum_out is not None:
+        slabs, ldp = int(lib().ofb_colsum_p_slabs(_i(R))), pm.ncb * 16
+        part = torch.empty(slabs, ldp, device=x.device, dtype=torch.float32)
+        check(lib().ofb_to_pformat_colsum(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(part), stream()),
+              'ofb_to_pformat_colsum')
+        colsum(part, ldp, slabs, Cc, colsum_out)
+        return pm
     check(lib().ofb_to_pformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), stream()), 'ofb_to_pformat')
     return pm
 

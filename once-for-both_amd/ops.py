@@ -180,8 +180,9 @@ class Linear(torch.autograd.Function):
             xbuf, W, b = ctx.saved_tensors
             M, K = ctx.mk
             dy = _c(dy)
-            dyP = hip.to_pformat(dy, M, W.shape[0], W.shape[0])
-            dx, dW, db, _ = _p_gated_linear_bwd(dyP, lambda: bias_grad(dy), _pm(xbuf, M, K), M, W, ctx.wp, b, None)
+            db = _new(dy, W.shape[0]) if b is not None else None
+            dyP = hip.to_pformat(dy, M, W.shape[0], W.shape[0], colsum_out=db)
+            dx, dW, db, _ = _p_gated_linear_bwd(dyP, lambda: db, _pm(xbuf, M, K), M, W, ctx.wp, b, None)
             return dx, dW, db
         x2d, W, b = ctx.saved_tensors
         dx, dW, db, _ = _gated_linear_bwd(_c(dy), x2d, W, b, None)
@@ -292,15 +293,17 @@ def _attn_backward_p(ctx, dout):
     M, Hd = B * N, heads * dh
     xP, oP = _pm(xbuf, M, D), _pm(obuf, M, Hd)
     d2 = _c(dout).view(M, D)
-    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale)     # gradient of the branch output, DropPath factor applied on the way
+    # gradient of the branch output: DropPath factor applied, planes written and the projection's bias gradient summed in ONE pass
+    dbp = _new(d2, D) if has_pb else None
+    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, colsum_out=dbp)
     wqP, wpP = ctx.wp
     do, _ = p_linear_bwd_input(d2sP, M, D, wpP, Hd)
     dwp = p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=grad_slot(wproj))
-    dbp = bias_grad(d2, rowscale=rowscale) if has_pb else None
     dqkv = torch.empty_like(qkv)
     hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
-    dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd)
-    dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: bias_grad(dqkv), xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None)
+    dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
+    dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw)
+    dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None)
     dg = None if dg3 is None else dg3.view(3, heads, dh).sum(0)
     dres = None if self_resid else dout
     return dx.view(B, N, D), dres, dwq, dbq, dwp, dbp, dg, None, None, None
@@ -364,12 +367,12 @@ def _mlp_backward_p(ctx, dout):
     M, hid = B * N, w1.shape[0]
     xP, hP = _pm(xbuf, M, D), _pm(hbuf, M, hid)
     d2 = _c(dout).view(M, D)
-    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale)
+    db2 = _new(d2, D) if has_b2 else None
+    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, colsum_out=db2)
     # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> P-format only
     w1P, w2P = ctx.wp
     _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_DGELU, aux=hpre, want_f32=False, want_p=True)
     dw2 = p_linear_bwd_weight(d2sP, hP, M, D, hid, out=grad_slot(w2))
-    db2 = bias_grad(d2, rowscale=rowscale) if has_b2 else None
 
     def dh_colsum():
         out = _new(hpre, hid)
@@ -429,8 +432,8 @@ class PatchEmbedTokens(torch.autograd.Function):
         hip.colsum(part[2], D, chunks * (L + 1), D, dgm[1])
         if _use_p():
             Kp = w2d.shape[1]
-            dw = p_linear_bwd_weight(hip.to_pformat(dconv, B * L, D, D), _pm(patches, B * L, Kp), B * L, D, Kp, out=grad_slot(w2d))
-            db = bias_grad(dconv)
+            db = _new(dconv, D)
+            dw = p_linear_bwd_weight(hip.to_pformat(dconv, B * L, D, D, colsum_out=db), _pm(patches, B * L, Kp), B * L, D, Kp, out=grad_slot(w2d))
         else:
             dw, db = linear_bwd_weight(dconv, patches, want_bias=True, out=grad_slot(w2d))
         dcls = dpos[0].reshape(cshape)

@@ -32,6 +32,22 @@ def test_pformat_round_trip_is_exact(R, C):
     assert torch.equal(pm.to_f32(), x * rs[torch.arange(R, device='cuda') // 7].unsqueeze(1))
 
 
+def test_pformat_with_column_sums():
+    """the conversion pass of a gradient also yields its column sums (bias gradient), DropPath row scale included"""
+    from ofb_amd import hip
+    R, C = 1970, 264
+    x = _mk((R, C), 5).cuda()
+    rs = _mk((10,), 6).cuda()
+    out = torch.full((C,), float('nan'), device='cuda')
+    pm = hip.to_pformat(x, rowscale=rs, rs_div=197, colsum_out=out)
+    scaled = x * rs[torch.arange(R, device='cuda') // 197].unsqueeze(1)
+    assert torch.equal(pm.to_f32(), scaled)
+    _close(out, scaled.double().sum(0).cpu(), 'column sums', tol=2e-6)
+    out2 = torch.empty(C, device='cuda')
+    hip.colsum_p(pm, out2)
+    _close(out2, scaled.double().sum(0).cpu(), 'column sums of a P-format matrix', tol=2e-6)
+
+
 SHAPES = [(256, 256, 64), (394, 384, 384), (591, 1152, 384), (130, 70, 36), (128, 1000, 384), (77, 13, 5), (591, 264, 200),
           (2600, 520, 48), (8192, 1024, 80)]
 
