@@ -147,6 +147,8 @@ class GradAllReducer:
 
     def _launch(self, bi):
         self._launched[bi] = True
+        from . import hip
+        hip.join_side()                                  # weight gradients are produced on the side stream (ops.py)
         flat, live = self._flat[bi], []
         for p, v in zip(self.buckets[bi], self._views[bi]):
             if p.grad is None:

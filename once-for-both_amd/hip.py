@@ -197,6 +197,46 @@ def colsum_p(pm, out):
     colsum(part, ld, slabs, pm.C, out)
 
 
+# ---- side stream for the weight-gradient products ------------------------------------------------------------------------
+# dW = dY^T X is needed only by the optimizer, while dX = dY W sits on the critical path of backward.  The input-gradient launches
+# leave CUs idle (394 tiles on 512 workgroup slots; HBM-bound LayerNorm / conversion kernels use no matrix pipe at all), so the
+# weight-gradient launches (stream-K over all workgroups) go to a second HIP stream and fill those holes.  join_side() makes the
+# current stream wait for them: at the end of backward (autograd callback), before the gate backward, before a gradient exchange.
+SIDE_STREAM = os.environ.get('OFB_SIDE_STREAM', '1') != '0'
+_side_streams, _side_keep, _side_dirty = {}, [], [False]
+
+
+class side_work:
+    """with side_work(dev, keep=[tensors read inside]): launches go to the side stream, ordered after everything already queued on
+    the current stream; `keep` tensors stay referenced until join_side() (the caching allocator must not recycle them earlier)."""
+
+    def __init__(self, device, keep=()):
+        self.device, self.keep = device, keep
+
+    def __enter__(self):
+        side = _side_streams.get(self.device)
+        if side is None:
+            side = _side_streams[self.device] = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        _side_keep.extend(self.keep)
+        _side_dirty[0] = True
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *a):
+        return self.ctx.__exit__(*a)
+
+
+def join_side():
+    """the current stream waits for all side-stream work issued so far"""
+    if _side_dirty[0]:
+        for dev, side in _side_streams.items():
+            torch.cuda.current_stream(dev).wait_stream(side)
+        _side_dirty[0] = False
+        _side_keep.clear()
+
+
 # P-format copies of the weights: made once per optimizer step and kept ON the Parameter object (an attribute, so the copy
 # lives and dies with the tensor it mirrors - a table keyed by data_ptr could hand a recycled address someone else's planes).
 # The optimizers / EMA / compress() bump the epoch after they changed parameters through raw pointers; torch in-place edits show

@@ -99,23 +99,51 @@ def p_linear_bwd_weight(dyP, xP, M, N, K, out=None):
     return dW
 
 
+_cb_queued = [False]
+
+
+def _side_ok(*params):
+    """weight-gradient work may go to the side stream unless a gradient is being accumulated into (AccumulateGrad would add on
+    the main stream at once) or the feature is off"""
+    if not hip.SIDE_STREAM:
+        return False
+    if any(p is not None and p.grad is not None for p in params):
+        return False
+    if not _cb_queued[0]:                                 # join at the end of this backward pass
+        def _done():
+            _cb_queued[0] = False
+            hip.join_side()
+        torch.autograd.Variable._execution_engine.queue_callback(_done)
+        _cb_queued[0] = True
+    return True
+
+
+class _nullctx:
+    def __enter__(self): return self
+    def __exit__(self, *a): return False
+
+
 def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None):
     """P-format backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None): dx (+resid fused), dW, db, dg.
     WP: the forward's P-format copy of W; dy_colsum: callable giving colsum(dY) (the raw bias gradient)."""
     N, K = WP.R, WP.C
     W = W.view(N, K)
     slot = grad_slot(W)
+    side = _side_ok(W, b)
     if gvec is None:
         dx, _ = p_linear_bwd_input(dyP, M, N, WP, K, resid=resid)
-        dW = p_linear_bwd_weight(dyP, xP, M, N, K, out=slot)
+        dW = slot if slot is not None else _new(W, N, K)
+        with (hip.side_work(W.device, keep=[dyP.buf, xP.buf]) if side else _nullctx()):
+            p_linear_bwd_weight(dyP, xP, M, N, K, out=dW)
         return dx, dW, (dy_colsum() if b is not None else None), None
     WeffP = hip.to_pformat(W, N, K, K, rowscale=gvec)                    # g[n] * W[n][:] straight into planes
     dx, _ = p_linear_bwd_input(dyP, M, N, WeffP, K, resid=resid)
-    dWraw = p_linear_bwd_weight(dyP, xP, M, N, K)
     dbraw = dy_colsum() if b is not None else None
     dW = slot if slot is not None else _new(W, N, K)
-    db, dg = (_new(W, N) if b is not None else None), _new(W, N)
-    hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K)
+    db, dg, dWraw = (_new(W, N) if b is not None else None), _new(W, N), _new(W, N, K)
+    with (hip.side_work(W.device, keep=[dyP.buf, xP.buf, dWraw, dbraw, gvec]) if side else _nullctx()):
+        p_linear_bwd_weight(dyP, xP, M, N, K, out=dWraw)
+        hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K)
     return dx, dW, db, dg
 
 
@@ -298,13 +326,19 @@ def _attn_backward_p(ctx, dout):
     d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, colsum_out=dbp)
     wqP, wpP = ctx.wp
     do, _ = p_linear_bwd_input(d2sP, M, D, wpP, Hd)
-    dwp = p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=grad_slot(wproj))
+    dwp = grad_slot(wproj)
+    dwp = dwp if dwp is not None else _new(d2, D, Hd)
+    with (hip.side_work(d2.device, keep=[d2sP.buf, oP.buf]) if _side_ok(wproj) else _nullctx()):
+        p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=dwp)
     dqkv = torch.empty_like(qkv)
     hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
     dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
     dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw)
     dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None)
-    dg = None if dg3 is None else dg3.view(3, heads, dh).sum(0)
+    dg = None
+    if dg3 is not None:                                   # dg3 may still be in flight on the side stream: add it up there
+        with (hip.side_work(d2.device, keep=[dg3]) if hip._side_dirty[0] else _nullctx()):
+            dg = dg3.view(3, heads, dh).sum(0)
     dres = None if self_resid else dout
     return dx.view(B, N, D), dres, dwq, dbq, dwp, dbp, dg, None, None, None
 
@@ -372,7 +406,10 @@ def _mlp_backward_p(ctx, dout):
     # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> P-format only
     w1P, w2P = ctx.wp
     _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_DGELU, aux=hpre, want_f32=False, want_p=True)
-    dw2 = p_linear_bwd_weight(d2sP, hP, M, D, hid, out=grad_slot(w2))
+    dw2 = grad_slot(w2)
+    dw2 = dw2 if dw2 is not None else _new(d2, D, hid)
+    with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2) else _nullctx()):
+        p_linear_bwd_weight(d2sP, hP, M, D, hid, out=dw2)
 
     def dh_colsum():
         out = _new(hpre, hid)
@@ -573,6 +610,7 @@ class BiMaskGates(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grads):
+        hip.join_side()                                   # gate gradients of the gated Linear layers come off the side stream
         descs_dev, _, buf, rank, plan = ctx.keep
         n = len(plan)
         dgs, dwrs, dwms = grads[:n], grads[n:2 * n], grads[2 * n:3 * n]

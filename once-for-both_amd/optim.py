@@ -20,6 +20,7 @@ class AdamW(Optimizer):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        hip.join_side()                          # weight gradients are produced on the side stream (ops.py)
         for group in self.param_groups:
             by_step = {}
             for p in group['params']:
