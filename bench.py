@@ -317,8 +317,13 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         if prof_steps and i == args.steps - prof_steps:
+            # the sampled steps run with the side stream off: per-launch durations of kernels that overlap on two streams are not
+            # attributable to one kernel (each stretches while the other shares the chip); `value` includes these slower steps
             hip.prof_enable(True)
+            side_was, hip.SIDE_STREAM = hip.SIDE_STREAM, False
         out = step()
+    if prof_steps:
+        hip.SIDE_STREAM = side_was
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
