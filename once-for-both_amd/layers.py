@@ -383,17 +383,27 @@ class MAESparseAttention(Attention, _Searchable):
         if attn_search:
             heads = list(range(2, H + 1, 2))
             ratios = [i / d for i in range(d // 4, d + 1, max(d // 8, 1))]
+            # restricted spaces (reference layers.py:424-448): head-only keeps ONE channel option (all of d) and a per-head
+            # score (H, 1); channel-only keeps ONE head option (all heads) and a per-channel score (1, d) shared by the
+            # heads.  The gate kernel sees them as (H, 1) / (1, d) modules; the gate is broadcast to (H, d) where q, k, v are
+            # scaled (layers.py:496-509 keeps weighted_mask as the broadcast (H, 1, d)).
+            self.space = 'head' if head_search else ('channel' if channel_search else 'joint')
             if head_search:
                 self.head_num_list = heads
-                raise NotImplementedError('head-only search space: not on the default OFB path')
+                self.alpha = nn.Parameter(torch.rand(len(heads), 1))
+                self.score = nn.Parameter(torch.rand(H, 1))
+                self.mask = _staircase_state(len(heads), 1, heads, [d], H, d)
             elif channel_search:
                 self.qkv_channel_ratio_list = ratios
-                raise NotImplementedError('channel-only search space: not on the default OFB path')
-            self.head_num_list, self.qkv_channel_ratio_list = heads, ratios
-            self.alpha = nn.Parameter(torch.rand(len(heads), len(ratios)))
+                self.alpha = nn.Parameter(torch.rand(1, len(ratios)))
+                self.score = nn.Parameter(torch.rand(1, d))
+                self.mask = _staircase_state(1, len(ratios), [H], self._chan_thr(), H, d)
+            else:
+                self.head_num_list, self.qkv_channel_ratio_list = heads, ratios
+                self.alpha = nn.Parameter(torch.rand(len(heads), len(ratios)))
+                self.score = nn.Parameter(torch.rand(H, d))
+                self.mask = _staircase_state(len(heads), len(ratios), heads, self._chan_thr(), H, d)
             self.switch_cell = self.alpha > 0
-            self.mask = _staircase_state(len(heads), len(ratios), heads, self._chan_thr(), H, d)
-            self.score = nn.Parameter(torch.rand(H, d))
             trunc_normal_(self.score, std=.2)
         else:
             self.head_num_list, self.qkv_channel_ratio_list = [H], [1.0]
@@ -408,17 +418,29 @@ class MAESparseAttention(Attention, _Searchable):
         return [int(self.head_dim * r) for r in self.qkv_channel_ratio_list]
 
     def gate_plan(self):
-        H, d = self.score.shape
+        H, d = self.score.shape                        # (H, d) joint, (H, 1) head-only, (1, d) channel-only
         A0, A1 = self.alpha.shape                      # compress() drops trailing head / channel options
-        return dict(H=H, C=d, A0=A0, A1=A1, kind=0,
-                    head_thr=list(self.head_num_list)[:A0], chan_thr=self._chan_thr()[:A1], norm_coef=4e-4, w_p=float(self.w_p),
+        space = getattr(self, 'space', 'joint')
+        head_thr = list(self.head_num_list)[:A0] if space != 'channel' else [1]
+        chan_thr = self._chan_thr()[:A1] if space != 'head' else [1]
+        return dict(H=H, C=d, A0=A0, A1=A1, kind=0, head_thr=head_thr, chan_thr=chan_thr, norm_coef=4e-4, w_p=float(self.w_p),
                     on=[int(v) for v in self.switch_cell.reshape(-1).tolist()])
 
+    def wsum_scale(self):
+        """the FLOPs model sums the BROADCAST staircase (reference layers.py:747-766 on weighted_mask (H, 1, d)): the gate
+        kernel's sum over (H, 1) / (1, d) counts each entry once, so it is scaled by the broadcast extent"""
+        space = getattr(self, 'space', 'joint')
+        return float(self.head_dim) if space == 'head' else (float(self.active_heads()) if space == 'channel' else 1.0)
+
+    def _bcast(self, t):
+        return t if getattr(self, 'space', 'joint') == 'joint' else t.expand(self.active_heads(), self.head_dim)
+
     def _shape_wm(self, wm):
-        return wm.view(wm.shape[0], 1, wm.shape[1])            # (H, 1, d) as the reference stores it
+        wm = self._bcast(wm)
+        return wm.reshape(wm.shape[0], 1, wm.shape[1])         # (H, 1, d) as the reference stores it
 
     def _wr_view(self):
-        return self._wr
+        return self._bcast(self._wr)
 
     def _prob_view(self):
         return self.score.sigmoid()
@@ -431,6 +453,11 @@ class MAESparseAttention(Attention, _Searchable):
             return self._single_gate()
         return None if self.fused else self.score.to(self.qkv.weight.device)
 
+    def _branch(self, x, resid, gate, rowscale, heads):
+        if gate is not None and gate.numel() != heads * self.head_dim and getattr(self, 'space', 'joint') != 'joint':
+            gate = gate.expand(heads, self.head_dim)             # head-only / channel-only gate broadcast over (H, d)
+        return super()._branch(x, resid, gate, rowscale, heads)
+
     def forward(self, x, mask_embed=None, weighted_embed=None):
         self.weighted_mask_embed = mask_embed
         return self._branch(x, torch.zeros_like(x), self.current_gate(), None, self.active_heads())
@@ -438,6 +465,11 @@ class MAESparseAttention(Attention, _Searchable):
     def compress(self, thresh, optimizer_params, optimizer_decoder, optimizer_archs, prefix='', alpha_reduced=None):
         """reference layers.py:559-696: cut heads (ranked by summed sigmoid(score)) and per-head q/k/v channels (ranked by
         score) down to the surviving option; proj loses the matching input columns."""
+        if getattr(self, 'space', 'joint') != 'joint' and int(self.switch_cell.sum()) != 1:
+            # the reference's own cut is inconsistent for these spaces (layers.py:612-617: channel indices are gathered from a
+            # (H, 1) score, i.e. one channel per head survives while qkv.out_features is set for d channels; with a (1, d) score
+            # the head gather indexes past its single row): there is no behaviour to reproduce
+            raise NotImplementedError('compress() of a head-only / channel-only attention space is undefined in the reference')
         cut = self._prune_cells(thresh, optimizer_archs, prefix, alpha_reduced)
         if cut is None:
             return optimizer_params, optimizer_decoder, optimizer_archs

@@ -188,8 +188,6 @@ class MIMVisionTransformer(MAEBaseModel):
         super().__init__()
         if distilled or representation_size:
             raise NotImplementedError('distilled / representation_size variants are not on the OFB path')
-        if patch_search:
-            raise NotImplementedError('patch-number search (alpha_patch cells) is off in the reference workflow (w_patch=0)')
         self.num_classes = num_classes
         self.num_features = self.embed_dim = embed_dim
         self.num_tokens = 1
@@ -215,13 +213,21 @@ class MIMVisionTransformer(MAEBaseModel):
         self.head = nn.Linear(self.num_features, num_classes) if num_classes > 0 else nn.Identity()
         self.head_dist = None
 
-        # patch-number "search space" with a single cell (reference :478-485)
+        # patch-number search space (reference :470-485): five keep ratios with a cell parameter each, or a single cell.  The cells
+        # act on the forward only through the FIRST live ratio (patch_masking, :593) and on the loss through the patch term of the
+        # adaptive one-hot loss (base_model.py:39-51); compress() prunes them like any other cell row (:789-820).
         self.mae = mae
-        self.patch_ratio_list = [mask_ratio]
-        self.alpha_patch = nn.Parameter(torch.tensor([[1.]]))
+        if patch_search:
+            import numpy as np
+            self.patch_ratio_list = np.linspace(0.5, 1.0, 5).tolist()
+            self.alpha_patch = nn.Parameter(torch.rand(1, len(self.patch_ratio_list)))
+        else:
+            self.patch_ratio_list = [mask_ratio]
+            self.alpha_patch = nn.Parameter(torch.tensor([[1.]]))
         self.switch_cell_patch = self.alpha_patch > 0
-        self.patch_search_mask = torch.zeros(1, 1, self.num_patches, 1)
-        self.patch_search_mask[0, :, :int(self.num_patches * mask_ratio), :] = 1
+        self.patch_search_mask = torch.zeros(len(self.patch_ratio_list), 1, self.num_patches, 1)
+        for i, r in enumerate(self.patch_ratio_list):
+            self.patch_search_mask[i, :, :int(self.num_patches * r), :] = 1
         if self.mae:
             self.mask_token = nn.Parameter(torch.zeros(1, 1, embed_dim))
             self.decoder = nn.Sequential(nn.Conv2d(self.num_features, patch_size ** 2 * 3, kernel_size=1), nn.PixelShuffle(patch_size))
@@ -301,7 +307,11 @@ class MIMVisionTransformer(MAEBaseModel):
         n = len(live)
         for i, m in enumerate(live):
             m._set_gate_outputs(outs[i], outs[n + i], outs[2 * n + i])
-        self._gate_out = dict(live=live, wsum=outs[3 * n], spars=outs[3 * n + 1], per_module=outs[3 * n + 2])
+        wsum = outs[3 * n]
+        scales = [m.wsum_scale() if hasattr(m, 'wsum_scale') else 1.0 for m in live]
+        if any(sc != 1.0 for sc in scales):                   # head-only / channel-only attention: the FLOPs model sums the broadcast staircase
+            wsum = wsum * torch.tensor(scales, device=wsum.device, dtype=wsum.dtype)
+        self._gate_out = dict(live=live, wsum=wsum, spars=outs[3 * n + 1], per_module=outs[3 * n + 2])
 
     def _module_gate(self, m):
         """gate tensor the fused block should apply for module m (None = no gate)."""
@@ -315,9 +325,13 @@ class MIMVisionTransformer(MAEBaseModel):
     def patch_masking_mask(self, B, device):
         """0 keep / 1 remove mask (reference :586-612) or None when every patch is kept."""
         L = self.num_patches
-        len_keep = int(L * self.patch_ratio_list[0])
-        if len_keep == L:
+        sw = self.switch_cell_patch.reshape(-1).tolist()
+        # reference :593: ratios of the live cells (index i is read from switch_cell_patch[:, i], so a ratio list that
+        # adjust_masking_ratio shortened to one entry pairs with cell 0); the FIRST live one sets the keep count
+        len_keeps = [int(L * r) for i, r in enumerate(self.patch_ratio_list) if i < len(sw) and sw[i]]
+        if len_keeps == [L]:
             return None
+        len_keep = len_keeps[0]
         forced = self._forced
         noise = forced['patch_noise'] if forced and 'patch_noise' in forced else torch.rand(B, L, device=device)
         mask = torch.empty(B, L, device=device)
@@ -471,7 +485,42 @@ class MIMVisionTransformer(MAEBaseModel):
         if self._gate_out is None:
             return zero, zero.clone(), zero.clone(), zero.clone()
         sp = self._gate_out['spars']
-        return sp[0], sp[1], zero, sp[2]
+        return sp[0], sp[1], self._patch_cell_loss(zero), sp[2]
+
+    def _patch_cell_loss(self, zero):
+        """patch term of the adaptive one-hot loss (reference base_model.py:39-51): entropy + tan term over the live patch cells
+        (no 1/n, no score term).  Five scalars: a handful of ATen ops, only when patch_search is on."""
+        sw = self.switch_cell_patch.to(self.alpha_patch.device)
+        n = int(self.switch_cell_patch.sum())
+        if n == 1:
+            return zero
+        pr = torch.softmax(self.alpha_patch[sw], dim=-1)
+        sigma = ((pr - pr.mean()) ** 2).sum() / (1.0 - 1.0 / n)
+        return -(pr * pr.log()).sum() + torch.tan(math.pi / 2 - math.pi * sigma)
+
+    def _compress_patch_cells(self, thresh):
+        """reference :789-820: prune patch cells whose probability fell to <= thresh / n_live.  Returns (finished, executed)."""
+        from .layers import plan_cell_pruning
+        from .dp import average_scalars
+        sw = self.switch_cell_patch.detach().to('cpu', torch.bool)
+        if int(sw.sum()) == 1:
+            self.alpha_patch.requires_grad = False
+            return True, False
+        a = average_scalars([self.alpha_patch.data])[0].detach().to('cpu', torch.float32)
+        thr = thresh / int(sw.sum())
+        prob = plan_cell_pruning(a, sw, thr)
+        if prob is None:
+            return False, False
+        sw = prob > thr
+        old = self.alpha_patch
+        self.switch_cell_patch = sw
+        self.alpha_patch = nn.Parameter(torch.where(sw, a, torch.zeros_like(a)).to(old.device), requires_grad=old.requires_grad)
+        alpha = torch.softmax(torch.where(sw, a, torch.full_like(a, float('-inf'))).reshape(-1), 0).reshape_as(a)
+        self.weighted_mask = sum(alpha[0, j] * self.patch_search_mask[j] for j in range(alpha.shape[1]) if bool(sw[0, j]))
+        finished = int(sw.sum()) == 1
+        if finished:
+            self.alpha_patch.requires_grad = False
+        return finished, True
 
     def _cut_embedding(self, keep, optimizer_params, optimizer_decoder):
         """every consumer of the embedding width outside the searchable modules follows a cut of the patch embedding
@@ -509,9 +558,7 @@ class MIMVisionTransformer(MAEBaseModel):
         module; decisions are taken on the host from that single copy, so all ranks cut identically."""
         from .dp import average_scalars
         hip.bump_weight_epoch()                                  # weights are about to be cut: drop their P-format copies
-        assert int(self.switch_cell_patch.sum()) == 1            # single patch cell (patch_search is off on this path)
-        finish_patch, execute_patch = True, False
-        self.alpha_patch.requires_grad = False
+        finish_patch, execute_patch = self._compress_patch_cells(thresh)
         if not self.searchable_modules:
             self.searchable_modules = [m for m in self.modules() if hasattr(m, 'alpha')]
         names = {id(m): n for n, m in self.named_modules()}

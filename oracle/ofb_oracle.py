@@ -38,6 +38,11 @@ class Config:
     in_chans: int = 3
     ln_eps: float = 1e-6            # partial(LayerNorm, eps=1e-6), models/model.py:94
     drop_path_rate: float = 0.0
+    attn_space: str = 'joint'       # 'joint' (default) | 'head' (--head_search) | 'channel' (--channel_search): layers.py:424-467
+    patch_search: bool = False      # alpha_patch cells over linspace(.5, 1, 5) keep ratios (vision_transformer.py:470-477)
+
+    def patch_ratios(self) -> List[float]:
+        return np.linspace(0.5, 1.0, 5).tolist()
 
     @property
     def head_dim(self):
@@ -84,7 +89,7 @@ def param_shapes(cfg: Config) -> Dict[str, tuple]:
     """state_dict names/shapes of the search model (probed)."""
     D, H, hid, P = cfg.embed_dim, cfg.num_heads, cfg.hidden, cfg.patch_size
     s = {
-        'cls_token': (1, 1, D), 'pos_embed': (1, cfg.num_patches + 1, D), 'alpha_patch': (1, 1),
+        'cls_token': (1, 1, D), 'pos_embed': (1, cfg.num_patches + 1, D), 'alpha_patch': (1, 5) if cfg.patch_search else (1, 1),
         'mask_token': (1, 1, D),
         'patch_embed.alpha': (1, len(cfg.embed_channels())), 'patch_embed.score': (1, D),
         'patch_embed.proj.weight': (D, cfg.in_chans, P, P), 'patch_embed.proj.bias': (D,),
@@ -93,8 +98,9 @@ def param_shapes(cfg: Config) -> Dict[str, tuple]:
         b = f'blocks.{i}.'
         s.update({
             b + 'norm1.weight': (D,), b + 'norm1.bias': (D,),
-            b + 'attn.alpha': (len(cfg.attn_heads()), len(cfg.attn_channels())),
-            b + 'attn.score': (H, cfg.head_dim),
+            b + 'attn.alpha': (len(cfg.attn_heads()) if cfg.attn_space != 'channel' else 1,
+                               len(cfg.attn_channels()) if cfg.attn_space != 'head' else 1),
+            b + 'attn.score': (H if cfg.attn_space != 'channel' else 1, cfg.head_dim if cfg.attn_space != 'head' else 1),
             b + 'attn.qkv.weight': (3 * D, D), b + 'attn.qkv.bias': (3 * D,),
             b + 'attn.proj.weight': (D, D), b + 'attn.proj.bias': (D,),
             b + 'norm2.weight': (D,), b + 'norm2.bias': (D,),
@@ -111,7 +117,7 @@ def param_shapes(cfg: Config) -> Dict[str, tuple]:
 def formula_params(cfg: Config, dtype=torch.float64) -> Dict[str, torch.Tensor]:
     out = {}
     for k, shp in param_shapes(cfg).items():
-        v = np.ones(shp, np.float32) if k == 'alpha_patch' else fill.param_value(k, shp)
+        v = np.ones(shp, np.float32) if (k == 'alpha_patch' and shp == (1, 1)) else fill.param_value(k, shp)
         out[k] = torch.from_numpy(v).to(dtype)
     return out
 
@@ -245,7 +251,8 @@ def search_space(cfg: Config, name: str):
     if name == 'patch_embed':
         return [1], cfg.embed_channels()
     if name.endswith('.attn'):
-        return cfg.attn_heads(), cfg.attn_channels()
+        # head-only: the channel axis of alpha / score has one entry; channel-only: the head axis (layers.py:424-448)
+        return (cfg.attn_heads() if cfg.attn_space != 'channel' else [1]), (cfg.attn_channels() if cfg.attn_space != 'head' else [1])
     return [1], cfg.mlp_channels()
 
 
@@ -261,7 +268,13 @@ def gates_for(cfg: Config, p: Dict[str, torch.Tensor], st: SearchState):
             continue
         a = p[n + '.alpha']
         ht, ct = search_space(cfg, n)
-        out[n] = bimask_gate(a, st.cell_mask(n, a), sc, ht[:a.shape[0]], ct[:a.shape[1]], st.w_p)
+        g, wr, wm, pr = bimask_gate(a, st.cell_mask(n, a), sc, ht[:a.shape[0]], ct[:a.shape[1]], st.w_p)
+        if n.endswith('.attn') and cfg.attn_space != 'joint':
+            # the reference keeps the staircase broadcast to (H, 1, d) (mask is ones along the axis that is not searched) and
+            # q, k, v are scaled by the broadcast gate (layers.py:496-509): FLOPs use the broadcast sum
+            H, d = st.heads.get(n, cfg.num_heads), cfg.head_dim
+            g, wr, wm = g.expand(H, d), wr.expand(H, d), wm.expand(H, d)
+        out[n] = (g, wr, wm, pr)
     return out
 
 
@@ -340,9 +353,16 @@ def search_forward(cfg: Config, p: Dict[str, torch.Tensor], st: SearchState, img
 
 
 def sparsity_losses(cfg: Config, p, st: SearchState, gates, entropy=True, var=True, norm=True):
-    """base_model.py:37-86 (patch term is 0: one patch cell).  Returns (attn, mlp, patch, embed)."""
+    """base_model.py:37-86.  Returns (attn, mlp, patch, embed)."""
     z = p['cls_token'].new_zeros(())
     acc = {'attn': z.clone(), 'mlp': z.clone(), 'embed': z.clone()}
+    l_patch = z.clone()
+    ap = p['alpha_patch']
+    on_p = st.cell_mask('patch', ap)
+    if int(on_p.sum()) != 1:                                     # :39-51: entropy + tan term (no 1/n, no score term), always on
+        pr = torch.softmax(ap[on_p], -1)
+        sigma = ((pr - pr.mean()) ** 2).sum() / (1.0 - 1.0 / int(on_p.sum()))
+        l_patch = -(pr * pr.log()).sum() + torch.tan(math.pi / 2 - math.pi * sigma)
     for name in module_names(cfg):
         alpha = p[name + '.alpha']
         on = st.cell_mask(name, alpha)
@@ -358,7 +378,7 @@ def sparsity_losses(cfg: Config, p, st: SearchState, gates, entropy=True, var=Tr
         if norm:
             loss = loss + torch.sigmoid(p[name + '.score']).sum() * (4e-4 if kind == 'attn' else 1e-4)
         acc[kind] = acc[kind] + loss
-    return acc['attn'], acc['mlp'], z.clone(), acc['embed']
+    return acc['attn'], acc['mlp'], l_patch, acc['embed']
 
 
 def flops_G(cfg: Config, gates, st: SearchState = None):

@@ -48,13 +48,14 @@ def build_reference(cfg: O.Config, drop_path: float):
     m = RVT.MIMVisionTransformer(
         patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4,
         qkv_bias=True, norm_layer=partial(RL.LayerNorm, eps=1e-6), embed_layer=RL.PatchEmbed, mae=True,
-        head_search=False, channel_search=False, num_classes=cfg.num_classes, drop_path_rate=drop_path,
-        attn_search=True, mlp_search=True, embed_search=True, patch_search=False, mask_ratio=1.0)
+        head_search=cfg.attn_space == 'head', channel_search=cfg.attn_space == 'channel', num_classes=cfg.num_classes,
+        drop_path_rate=drop_path, attn_search=True, mlp_search=True, embed_search=True, patch_search=cfg.patch_search, mask_ratio=1.0)
     m.searchable_modules = [x for x in m.modules() if hasattr(x, 'alpha')]
-    sd = {k: torch.from_numpy(np.ones(v.shape, np.float32) if k == 'alpha_patch' else fill.param_value(k, tuple(v.shape)))
+    sd = {k: torch.from_numpy(np.ones(v.shape, np.float32) if (k == 'alpha_patch' and tuple(v.shape) == (1, 1))
+                              else fill.param_value(k, tuple(v.shape)))
           for k, v in m.state_dict().items()}
     m.load_state_dict(sd, strict=True)
-    m.correct_require_grad(0.5, 0.5, 0, 0.5)
+    m.correct_require_grad(0.5, 0.5, 0.5 if cfg.patch_search else 0, 0.5)
     return m
 
 
@@ -72,7 +73,15 @@ def run_case(tag, cfg_kw, batch, w_p, keep_ratio, drop_path, switches, lr=1e-3, 
         mod.w_p = w_p
         if name in switches:
             mod.switch_cell = torch.from_numpy(switches[name])
-    model.patch_ratio_list = [keep_ratio]
+    if cfg.patch_search:
+        # the keep ratio is the first LIVE patch cell's (vision_transformer.py:593); the ratio list stays the constructor's
+        if 'patch' in switches:
+            model.switch_cell_patch = torch.from_numpy(switches['patch'])
+        live = [r for i, r in enumerate(model.patch_ratio_list) if bool(model.switch_cell_patch[0, i])]
+        assert abs(live[0] - keep_ratio) < 1e-12, (live, keep_ratio)
+    else:
+        model.patch_ratio_list = [keep_ratio]
+    patch_w = 0.5 if cfg.patch_search else 0.0
     model.train()
 
     imgs = torch.from_numpy(fill.images(batch))
@@ -96,7 +105,7 @@ def run_case(tag, cfg_kw, batch, w_p, keep_ratio, drop_path, switches, lr=1e-3, 
     DropPath.rand = staticmethod(fake_rand)
     try:
         crit = RLOSS.OFBSearchLOSS(RLOSS.DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0),
-                                    torch.device('cpu'), attn_w=0.5, mlp_w=0.5, patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+                                    torch.device('cpu'), attn_w=0.5, mlp_w=0.5, patch_w=patch_w, embedding_w=0.5, flops_w=5.0)
         wrapped = _Wrap(model)
         with contextlib.redirect_stdout(io.StringIO()):
             logits, (dec_loss, score_loss) = wrapped(imgs)
@@ -117,9 +126,11 @@ def run_case(tag, cfg_kw, batch, w_p, keep_ratio, drop_path, switches, lr=1e-3, 
                meta=np.array([batch, w_p, keep_ratio, drop_path, lr], np.float64))
     for mod, name in zip(model.searchable_modules, names):
         wr, prob = mod.get_weight()
-        out[f'gate.{name}.wr'] = wr.detach().reshape(mod.score.shape).numpy()
-        out[f'gate.{name}.wm'] = mod.weighted_mask.detach().reshape(mod.score.shape).numpy()
-        g = (1 - w_p) * wr.detach().reshape(mod.score.shape) + w_p * mod.score.detach().sigmoid()
+        # restricted attention spaces keep score as (H, 1) / (1, d) while the staircase is stored broadcast to (H, d)
+        shp = wr.shape if wr.numel() != mod.score.numel() else mod.score.shape
+        out[f'gate.{name}.wr'] = wr.detach().reshape(shp).numpy()
+        out[f'gate.{name}.wm'] = mod.weighted_mask.detach().reshape(shp).numpy()
+        g = (1 - w_p) * wr.detach().reshape(shp) + w_p * mod.score.detach().sigmoid()
         out[f'gate.{name}.g'] = g.numpy()
     for k, p in model.named_parameters():
         if p.grad is None:
@@ -369,6 +380,13 @@ if __name__ == '__main__':
         run_compress_case()
         sys.exit(0)
     micro = O.MICRO
+    if len(sys.argv) > 1 and sys.argv[1] == 'ctor':          # only the constructor-surface cases (round 2)
+        micro4 = dict(embed_dim=64, depth=2, num_heads=4, num_classes=10)
+        run_case('micro_h', dict(micro4, attn_space='head'), batch=2, w_p=0.6, keep_ratio=0.9, drop_path=0.0, switches={}, full_grads=True)
+        run_case('micro_c', dict(micro4, attn_space='channel'), batch=2, w_p=0.6, keep_ratio=0.9, drop_path=0.0, switches={}, full_grads=True)
+        sw_p = {'patch': np.array([[False, True, True, False, True]])}
+        run_case('micro_p', dict(micro, patch_search=True), batch=2, w_p=0.8, keep_ratio=0.625, drop_path=0.0, switches=sw_p, full_grads=True)
+        sys.exit(0)
     sw_b = {
         'patch_embed': np.array([[0, 0] + [1] * 15], bool),
         'blocks.0.attn': np.array([[0, 1, 1, 1, 1, 1, 1]], bool),
@@ -376,6 +394,13 @@ if __name__ == '__main__':
     }
     run_case('micro_a', micro, batch=2, w_p=0.99, keep_ratio=0.95, drop_path=0.0, switches={}, full_grads=True)
     run_case('micro_b', micro, batch=3, w_p=0.545, keep_ratio=0.85, drop_path=0.1, switches=sw_b)
+    micro4 = dict(embed_dim=64, depth=2, num_heads=4, num_classes=10)
+    # constructor surface beyond the default workflow: head-only / channel-only attention spaces (layers.py:424-448) and the
+    # patch-number search with a live patch term in the architecture loss (vision_transformer.py:470-477, base_model.py:39-51)
+    run_case('micro_h', dict(micro4, attn_space='head'), batch=2, w_p=0.6, keep_ratio=0.9, drop_path=0.0, switches={}, full_grads=True)
+    run_case('micro_c', dict(micro4, attn_space='channel'), batch=2, w_p=0.6, keep_ratio=0.9, drop_path=0.0, switches={}, full_grads=True)
+    sw_p = {'patch': np.array([[False, True, True, False, True]])}
+    run_case('micro_p', dict(micro, patch_search=True), batch=2, w_p=0.8, keep_ratio=0.625, drop_path=0.0, switches=sw_p, full_grads=True)
     run_case('tiny_a', dict(O.DEIT_TINY, num_classes=2), batch=2, w_p=0.99, keep_ratio=0.95, drop_path=0.1, switches={})
     sw_s = {'blocks.3.attn': np.array([[1, 1, 1, 1, 1, 1, 0], [1, 1, 0, 1, 1, 1, 1], [0, 1, 1, 1, 1, 1, 1]], bool)}
     run_case('small_a', dict(O.DEIT_SMALL, num_classes=1000), batch=2, w_p=0.7, keep_ratio=0.9, drop_path=0.1, switches=sw_s)

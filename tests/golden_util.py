@@ -14,6 +14,10 @@ CASES = {
     'micro_b': dict(cfg=O.MICRO),
     'tiny_a': dict(cfg=dict(O.DEIT_TINY, num_classes=2)),
     'small_a': dict(cfg=dict(O.DEIT_SMALL, num_classes=1000)),
+    # constructor surface beyond the default workflow (round 2): head-only / channel-only attention spaces, patch-number search
+    'micro_h': dict(cfg=dict(embed_dim=64, depth=2, num_heads=4, num_classes=10, attn_space='head')),
+    'micro_c': dict(cfg=dict(embed_dim=64, depth=2, num_heads=4, num_classes=10, attn_space='channel')),
+    'micro_p': dict(cfg=dict(O.MICRO, patch_search=True), patch_w=0.5),
 }
 
 

@@ -22,25 +22,30 @@ def build_product(cfg, st, inputs, dev='cuda'):
     m = ofb_amd.MIMVisionTransformer(
         patch_size=cfg.patch_size, embed_dim=cfg.embed_dim, depth=cfg.depth, num_heads=cfg.num_heads, mlp_ratio=4, qkv_bias=True,
         norm_layer=partial(LayerNorm, eps=1e-6), embed_layer=PatchEmbed, mae=True, num_classes=cfg.num_classes,
-        drop_path_rate=cfg.drop_path_rate, attn_search=True, mlp_search=True, embed_search=True, patch_search=False, mask_ratio=1.0)
+        drop_path_rate=cfg.drop_path_rate, attn_search=True, mlp_search=True, embed_search=True, patch_search=cfg.patch_search,
+        head_search=cfg.attn_space == 'head', channel_search=cfg.attn_space == 'channel', mask_ratio=1.0)
     m.searchable_modules = [x for x in m.modules() if hasattr(x, 'alpha')]
     sd = {k: v.float() for k, v in O.formula_params(cfg, torch.float32).items()}
     m.load_state_dict(sd, strict=True)
-    m.correct_require_grad(0.5, 0.5, 0, 0.5)
+    m.correct_require_grad(0.5, 0.5, 0.5 if cfg.patch_search else 0, 0.5)
     for mod, name in zip(m.searchable_modules, O.module_names(cfg)):
         mod.w_p = st.w_p
         if name in st.switch:
             mod.switch_cell = st.switch[name].clone()
-    m.patch_ratio_list = [st.keep_ratio]
+    if cfg.patch_search:
+        if 'patch' in st.switch:
+            m.switch_cell_patch = st.switch['patch'].clone()
+    else:
+        m.patch_ratio_list = [st.keep_ratio]
     m.to(dev).train()
     m._forced = dict(patch_noise=inputs['patch_noise'].to(dev), droppath_u=inputs['droppath_u'].to(dev))
     return m
 
 
-def run_step(m, inputs, dev='cuda'):
+def run_step(m, inputs, dev='cuda', patch_w=0.0):
     from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
     crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), torch.device(dev),
-                         attn_w=0.5, mlp_w=0.5, patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+                         attn_w=0.5, mlp_w=0.5, patch_w=patch_w, embedding_w=0.5, flops_w=5.0)
     imgs, labels = inputs['imgs'].to(dev), inputs['labels'].to(dev)
     logits, (dec, _) = m(imgs)
     base, arch = crit(imgs, logits, labels, m, 'arch', 1.0, False)
@@ -56,15 +61,19 @@ def _scalar_close(got, exp, what, tol=TOL):
     assert abs(got - exp) <= tol * max(1.0, abs(exp)), what
 
 
-@pytest.mark.parametrize('tag', ['micro_a', 'micro_b', 'tiny_a', 'small_a'])
+@pytest.mark.parametrize('tag', ['micro_a', 'micro_b', 'tiny_a', 'small_a', 'micro_h', 'micro_c', 'micro_p'])
 def test_search_step_matches_reference_golden(tag):
+    """micro_h / micro_c: head-only / channel-only attention spaces (reference layers.py:424-448); micro_p: patch-number search
+    with two dead cells and a live patch term in the architecture loss (vision_transformer.py:470-477, base_model.py:39-51)"""
+    from tests.golden_util import CASES
     z, cfg, st, inputs, lr = load_case(tag)
     m = build_product(cfg, st, inputs)
-    out = run_step(m, inputs)
+    out = run_step(m, inputs, patch_w=CASES[tag].get('patch_w', 0.0))
     for k in ['base', 'arch', 'decoder_loss', 'loss_total']:
         _scalar_close(out[k], z[k], k)
     la, lm, lp, le = m.get_sparsity_loss(torch.device('cuda'))
     _scalar_close(la, z['loss_attn'], 'loss_attn'); _scalar_close(lm, z['loss_mlp'], 'loss_mlp'); _scalar_close(le, z['loss_embed'], 'loss_embed')
+    _scalar_close(lp, z['loss_patch'], 'loss_patch')
     tot, sea = m.get_flops()
     _scalar_close(tot, z['flops_total'], 'flops_total', 1e-6); _scalar_close(sea, z['flops_searched'], 'flops_searched', 1e-5)
     e = rel_err(out['logits'].detach().cpu(), z['logits'])
@@ -74,7 +83,8 @@ def test_search_step_matches_reference_golden(tag):
         wr, prob = mod.get_weight()
         assert rel_err(wr.detach().cpu().reshape(-1), z[f'gate.{name}.wr'].reshape(-1)) < 1e-5, name
         assert rel_err(mod.weighted_mask.detach().cpu().reshape(-1), z[f'gate.{name}.wm'].reshape(-1)) < 1e-5, name
-        assert rel_err(mod._g.detach().cpu().reshape(-1), z[f'gate.{name}.g'].reshape(-1)) < 1e-5, name
+        g_view = mod._bcast(mod._g) if hasattr(mod, '_bcast') else mod._g      # restricted attention spaces: gate broadcast to (H, d)
+        assert rel_err(g_view.detach().cpu().reshape(-1), z[f'gate.{name}.g'].reshape(-1)) < 1e-5, name
     worst, worst_k = 0.0, ''
     for k, p in m.named_parameters():
         if f'gnorm.{k}' not in z.files:

@@ -86,9 +86,23 @@ def test_forward_without_gpu_fails_loudly():
         m(torch.zeros(1, 3, 224, 224))
 
 
+def test_constructor_surface_matches_reference_shapes():
+    """patch-number search and the head-only / channel-only attention spaces (reference vision_transformer.py:470-477,
+    layers.py:424-448): parameter shapes / state as the reference builds them (values are pinned by the micro_h/c/p goldens)"""
+    m = ofb_amd.create_model('deit_small_patch16_224_mim', method='search', patch_search=True)
+    assert tuple(m.alpha_patch.shape) == (1, 5) and m.patch_ratio_list == [0.5, 0.625, 0.75, 0.875, 1.0]
+    assert tuple(m.patch_search_mask.shape) == (5, 1, 196, 1) and int(m.patch_search_mask[1].sum()) == 122
+    m = ofb_amd.create_model('deit_small_patch16_224_mim', method='search', patch_search=False, head_search=True)
+    a = m.blocks[0].attn
+    assert tuple(a.alpha.shape) == (3, 1) and tuple(a.score.shape) == (6, 1) and tuple(a.mask.shape) == (3, 6, 1, 64)
+    m = ofb_amd.create_model('deit_small_patch16_224_mim', method='search', patch_search=False, channel_search=True)
+    a = m.blocks[0].attn
+    assert tuple(a.alpha.shape) == (1, 7) and tuple(a.score.shape) == (1, 64) and tuple(a.mask.shape) == (1, 6, 7, 64)
+    with pytest.raises(NotImplementedError):               # the reference's own cut is inconsistent for these spaces (layers.py:612-617)
+        a.compress(0.2, None, None, None, 'blocks.0.attn')
+
+
 def test_unsupported_options_are_explicit():
-    with pytest.raises(NotImplementedError):
-        ofb_amd.create_model('deit_small_patch16_224_mim', method='search', patch_search=True)
     with pytest.raises(NotImplementedError):
         ofb_amd.create_model('deit_small_patch16_224_mim', pretrained=True, method='search', patch_search=False)
 

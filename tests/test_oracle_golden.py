@@ -13,21 +13,25 @@ from tests.golden_util import load_case, sample, rel_err, GOLDEN_DIR
 
 def run_oracle(tag, dtype):
     z, cfg, st, inp, lr = load_case(tag)
+    from tests.golden_util import CASES
     p = {k: v.requires_grad_(True) for k, v in O.formula_params(cfg, dtype).items()}
-    p['alpha_patch'].requires_grad_(False)
+    patch_w = CASES[tag].get('patch_w', 0.0)
+    p['alpha_patch'].requires_grad_(patch_w != 0.0)              # correct_require_grad(w_patch) freezes it otherwise
     out = O.search_step_loss(cfg, p, st, inp['imgs'].to(dtype), inp['labels'], inp['patch_noise'].to(dtype),
-                             inp['droppath_u'].to(dtype))
+                             inp['droppath_u'].to(dtype), w=(0.5, 0.5, patch_w, 0.5, 5.0))
     out['loss_total'].backward()
     return z, cfg, st, p, out, lr
 
 
 @pytest.mark.parametrize('tag,dtype', [('micro_a', torch.float64), ('micro_a', torch.float32), ('micro_b', torch.float64),
-                                       ('tiny_a', torch.float64), ('small_a', torch.float32)])
+                                       ('tiny_a', torch.float64), ('small_a', torch.float32), ('micro_h', torch.float64),
+                                       ('micro_c', torch.float64), ('micro_p', torch.float64)])
 def test_search_step_matches_reference(tag, dtype):
     z, cfg, st, p, out, lr = run_oracle(tag, dtype)
     tol = 2e-5 if dtype == torch.float64 else 1e-4
-    for k in ['base', 'arch', 'loss_attn', 'loss_mlp', 'loss_embed', 'loss_flops' if False else 'base', 'decoder_loss',
-              'flops_total', 'flops_searched', 'loss_total']:
+    out['loss_patch'] = O.sparsity_losses(cfg, p, st, out['gates'])[2]
+    for k in ['base', 'arch', 'loss_attn', 'loss_mlp', 'loss_embed', 'decoder_loss', 'flops_total', 'flops_searched', 'loss_total'] + \
+            (['loss_patch'] if 'loss_patch' in z.files else []):
         got, exp = float(out[k]), float(z[k])
         assert abs(got - exp) <= tol * max(1.0, abs(exp)), (k, got, exp)
     assert rel_err(out['logits'].detach(), z['logits']) < tol * 5
