@@ -17,20 +17,40 @@ class LabelSmoothingCrossEntropy(nn.Module):
 
 
 class DistillationLoss(nn.Module):
-    """reference losses.py:10-64; only distillation_type='none' is on the OFB path (search.py:624-631)."""
+    """reference losses.py:10-64.  distillation_type='none' is the OFB workflow (search.py:624-631) and runs on the fused CE
+    kernel; 'soft' / 'hard' follow the reference expressions on the (B, classes) logits of a model that returns
+    (outputs, outputs_kd) - a handful of row-wise ATen ops on a tensor of a few hundred KB, off the search path (the OFB models
+    have no distillation head, so like the reference they raise ValueError there)."""
 
     def __init__(self, base_criterion, teacher_model, distillation_type, alpha, tau):
         super().__init__()
         assert distillation_type in ['none', 'soft', 'hard']
-        if distillation_type != 'none':
-            raise NotImplementedError('knowledge distillation is off in the OFB workflow')
         self.base_criterion, self.teacher_model = base_criterion, teacher_model
         self.distillation_type, self.alpha, self.tau = distillation_type, alpha, tau
 
     def forward(self, inputs, outputs, labels):
+        outputs_kd = None
         if not isinstance(outputs, torch.Tensor):
-            outputs, _ = outputs
-        return self.base_criterion(outputs, labels)
+            outputs, outputs_kd = outputs
+        base_loss = self.base_criterion(outputs, labels)
+        if self.distillation_type == 'none':
+            return base_loss
+        if outputs_kd is None:
+            raise ValueError('When knowledge distillation is enabled, the model is expected to return a Tuple[Tensor, Tensor] with the '
+                             'output of the class_token and the dist_token')
+        with torch.no_grad():                                            # no backprop through the teacher (losses.py:47-48)
+            teacher_outputs = self.teacher_model(inputs)
+            if isinstance(teacher_outputs, tuple):
+                teacher_outputs = teacher_outputs[0]
+        if self.distillation_type == 'soft':                             # losses.py:50-59
+            T = self.tau
+            log_s = torch.log_softmax(outputs_kd.float() / T, dim=1)
+            log_t = torch.log_softmax(teacher_outputs.float() / T, dim=1)
+            distillation_loss = (log_t.exp() * (log_t - log_s)).sum() * (T * T) / outputs_kd.numel()
+        else:                                                            # 'hard', losses.py:60-61
+            logp = torch.log_softmax(outputs_kd.float(), dim=1)
+            distillation_loss = -logp.gather(1, teacher_outputs.float().argmax(dim=1, keepdim=True)).mean()
+        return base_loss * (1 - self.alpha) + distillation_loss * self.alpha
 
 
 class OFBSearchLOSS(nn.Module):

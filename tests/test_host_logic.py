@@ -161,3 +161,24 @@ def test_model_deepcopy_and_pickle_roundtrip_cpu():
     buf.seek(0)
     m3 = torch.load(buf, weights_only=False)
     assert sorted(m3.state_dict()) == sorted(m.state_dict()) and m3._gate_flags == (1, 1, 1)
+
+
+def test_distillation_loss_soft_and_hard_match_reference_expressions():
+    """reference losses.py:50-64 on CPU logits (the base criterion here is a plain CE stand-in: the fused CE kernel needs a GPU)"""
+    import torch.nn.functional as F
+    from ofb_amd.losses import DistillationLoss
+    torch.manual_seed(0)
+    out, kd, labels = torch.randn(6, 10), torch.randn(6, 10, requires_grad=True), torch.randint(0, 10, (6,))
+    teacher = torch.nn.Linear(4, 10)
+    x = torch.randn(6, 4)
+    base = lambda o, y: F.cross_entropy(o, y)
+    for kind in ('soft', 'hard'):
+        got = DistillationLoss(base, teacher, kind, 0.3, 2.0)(x, (out, kd), labels)
+        t = teacher(x).detach()
+        if kind == 'soft':
+            d = F.kl_div(F.log_softmax(kd / 2.0, 1), F.log_softmax(t / 2.0, 1), reduction='sum', log_target=True) * 4.0 / kd.numel()
+        else:
+            d = F.cross_entropy(kd, t.argmax(1))
+        assert torch.allclose(got, base(out, labels) * 0.7 + d * 0.3, atol=1e-6)
+    with pytest.raises(ValueError):
+        DistillationLoss(base, teacher, 'soft', 0.3, 2.0)(x, out, labels)
