@@ -247,13 +247,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
     b_r0 = B_KC ? kc0 : kr_b0; b_r1 = B_KC ? kc1 : kr_b1;
   }
 
-  f32x16 acc[MI][NI];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  f32x16 acc[MI][NI];                                // zeroed at the start of every unit: nothing of it lives across an epilogue
 
   // LDS-DMA in inline asm (through the builtin hipcc drains every LDS-DMA with vmcnt(0) before the next ds_read): invisible to
   // its wait-count bookkeeping, counted by hand (n_w per wave and stage).  The pieces of one wave sit NW KB apart in the stage
@@ -325,6 +319,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
   }
   while (true) {
     const int nk = cur.it1 - cur.it0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const size_t a_step = A_KC ? GRAN : (size_t)4 * a_ncb * GRAN, b_step = B_KC ? GRAN : (size_t)4 * b_ncb * GRAN;
     const char* a_base = (const char*)g.A + (A_KC ? (size_t)(cur.m0 / 4) * a_ncb * GRAN : (size_t)(cur.m0 / 16) * GRAN) + cur.it0 * a_step;
     const char* b_base = (const char*)g.B + (B_KC ? (size_t)(cur.n0 / 4) * b_ncb * GRAN : (size_t)(cur.n0 / 16) * GRAN) + cur.it0 * b_step;
@@ -400,9 +400,10 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
       const float* __restrict__ resid = g.resid;
       const float* __restrict__ rowscale = g.rowscale;
       const int rp_out = (g.M + 15) & ~15;
-      float biasv[NC], csv[NC];
+      float biasv[NC], csv[NC], cacc[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) {
+        cacc[c] = 0.f;
         const int col = cur.n0 + lane + 64 * c, colc = col < g.N ? col : g.N - 1;
         biasv[c] = (!TAIL && g.bias) ? g.bias[colc] : 0.f;
         csv[c] = (!TAIL && g.colscale) ? g.colscale[colc] : 1.f;
@@ -419,7 +420,6 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
               for (int gq = 0; gq < 4; ++gq) {
                 f32x4 q4 = {acc[mi][ni][4 * gq], acc[mi][ni][4 * gq + 1], acc[mi][ni][4 * gq + 2], acc[mi][ni][4 * gq + 3]};
                 *reinterpret_cast<f32x4*>(T + (wn0 + 32 * ni + l31) * TROW + (wm0 % HR) + 32 * mi + 8 * gq + 4 * h) = q4;
-                acc[mi][ni][4 * gq] = 0.f; acc[mi][ni][4 * gq + 1] = 0.f; acc[mi][ni][4 * gq + 2] = 0.f; acc[mi][ni][4 * gq + 3] = 0.f;
               }
         }
         __syncthreads();
@@ -442,48 +442,56 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
           // s_waitcnt vmcnt(0), i.e. one memory round trip per store.
           auto pass = [&](auto GUARDED) __attribute__((always_inline)) {
             constexpr bool GD = decltype(GUARDED)::value;
-            f32x4 side[ITEMS], side2[ITEMS], rsv[NRG];
+            // two batches of row groups per pass: all side inputs of a batch are requested before any item of it is finished
+            // (one exposed latency per batch); a whole pass in one batch needs > 100 registers for side inputs and spills
+            constexpr int KB = NRG / 2, BI = KB * NC;
+            static_assert(NRG % 2 == 0, "epilogue batches");
 #pragma unroll
-            for (int k = 0; k < NRG; ++k) {
-              const int row0 = cur.m0 + HR * half + 4 * (w + NW * k);
+            for (int k0 = 0; k0 < NRG; k0 += KB) {
+              f32x4 side[BI], side2[BI], rsv[KB];
 #pragma unroll
-              for (int tt = 0; tt < 4; ++tt) {
-                const int row = row0 + tt, rowc = (!GD || row < g.M) ? row : g.M - 1;
-                rsv[k][tt] = has_rs ? rowscale[g.rs_div == 1 ? rowc : rowc / g.rs_div] : 1.f;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                  const int col = cur.n0 + lane + 64 * c, colc = (!GD || col < g.N) ? col : g.N - 1;
-                  side[k * NC + c][tt] = dg ? auxr[(size_t)rowc * g.ldaux + colc] : 0.f;
-                  side2[k * NC + c][tt] = has_res ? resid[(size_t)rowc * g.ldr + colc] : 0.f;
-                }
-              }
-            }
-#pragma unroll
-            for (int k = 0; k < NRG; ++k) {
-              const int rgl = w + NW * k, row0 = cur.m0 + HR * half + 4 * rgl;
-#pragma unroll
-              for (int c = 0; c < NC; ++c) {
-                const int lcol = lane + 64 * c, col = cur.n0 + lcol;
-                const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + lcol * TROW + 4 * rgl);
-                const bool colok = !GD || col < g.N;
-                float pv[4];
+              for (int kk = 0; kk < KB; ++kk) {
+                const int row0 = cur.m0 + HR * half + 4 * (w + NW * (k0 + kk));
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
-                  const int row = row0 + tt;
-                  const bool ok = !GD || (colok && row < g.M);
-                  float val = (q4[tt] * g.alpha + biasv[c]) * csv[c];
-                  if (gelu) {
-                    if (auxw && ok) auxw[(size_t)row * g.ldaux + col] = val;
-                    val = ofb_gelu(val);
-                  } else if (dg) {
-                    val *= ofb_dgelu(side[k * NC + c][tt]);
+                  const int row = row0 + tt, rowc = (!GD || row < g.M) ? row : g.M - 1;
+                  rsv[kk][tt] = has_rs ? rowscale[g.rs_div == 1 ? rowc : rowc / g.rs_div] : 1.f;
+#pragma unroll
+                  for (int c = 0; c < NC; ++c) {
+                    const int col = cur.n0 + lane + 64 * c, colc = (!GD || col < g.N) ? col : g.N - 1;
+                    side[kk * NC + c][tt] = dg ? auxr[(size_t)rowc * g.ldaux + colc] : 0.f;
+                    side2[kk * NC + c][tt] = has_res ? resid[(size_t)rowc * g.ldr + colc] : 0.f;
                   }
-                  val = val * rsv[k][tt] + side2[k * NC + c][tt];
-                  if (has_c && ok) Cout[(size_t)row * g.ldc + col] = val;
-                  pv[tt] = ok ? val : 0.f;
                 }
-                if (has_p && (!GD || (row0 < rp_out && col < g.c_ncb * 16)))
-                  store_p4((char*)g.Cp + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8, pv[0], pv[1], pv[2], pv[3]);
+              }
+#pragma unroll
+              for (int kk = 0; kk < KB; ++kk) {
+                const int rgl = w + NW * (k0 + kk), row0 = cur.m0 + HR * half + 4 * rgl;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                  const int lcol = lane + 64 * c, col = cur.n0 + lcol;
+                  const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + lcol * TROW + 4 * rgl);
+                  const bool colok = !GD || col < g.N;
+                  float pv[4];
+#pragma unroll
+                  for (int tt = 0; tt < 4; ++tt) {
+                    const int row = row0 + tt;
+                    const bool ok = !GD || (colok && row < g.M);
+                    float val = (q4[tt] * g.alpha + biasv[c]) * csv[c];
+                    if (gelu) {
+                      if (auxw && ok) auxw[(size_t)row * g.ldaux + col] = val;
+                      val = ofb_gelu(val);
+                    } else if (dg) {
+                      val *= ofb_dgelu(side[kk * NC + c][tt]);
+                    }
+                    val = val * rsv[kk][tt] + side2[kk * NC + c][tt];
+                    if (has_c && ok) Cout[(size_t)row * g.ldc + col] = val;
+                    pv[tt] = ok ? val : 0.f;
+                  }
+                  cacc[c] += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+                  if (has_p && (!GD || (row0 < rp_out && col < g.c_ncb * 16)))
+                    store_p4((char*)g.Cp + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8, pv[0], pv[1], pv[2], pv[3]);
+                }
               }
             }
           };
@@ -491,6 +499,19 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
           else pass(std::true_type{});
         }
         if (half + 1 < BM / HR) __syncthreads();                    // T is rewritten by the next pass (the next unit starts with a barrier)
+      }
+      if (!TAIL && g.colpart) {
+        // column sums of this tile's outputs: per-thread sums over its row groups (fixed order), then the waves in order
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) T[w * BN + lane + 64 * c] = cacc[c];
+        __syncthreads();
+        if (t < BN && cur.n0 + t < g.N) {
+          float sum = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < NW; ++ww) sum += T[ww * BN + t];
+          g.colpart[(size_t)(cur.m0 / BM) * g.N + cur.n0 + t] = sum;
+        }
       }
     }
     OFB_PSTAMP(3);
@@ -582,6 +603,9 @@ Plan plan_p(const ofb_gemm_p_args& g) {
   // through HBM (~0.019 steps per 96-KB partial at 4.5 TB/s) plus the extra launches (~3.5 steps); one more (partly idle)
   // data-parallel round costs I steps.  The split-major piece count S is chosen to minimise that sum (short tails: few large
   // pieces; weight gradients: one piece per workgroup); the tail must beat the round by 10 % to be worth its HBM traffic.
+  if (p.R > 0 && g.colpart) {                                        // per-tile column sums come from the fused epilogue only
+    p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;
+  }
   if (p.R > 0) {
     const double PC = 0.019, FIX = 3.5;
     double best = 0.9 * p.I;
@@ -706,6 +730,7 @@ extern "C" int ofb_gemm_p(const ofb_gemm_p_args* args, void* stream) {
   const ofb_gemm_p_args& g = *args;
   if (!g.A || !g.B || (!g.C && !g.Cp) || g.M <= 0 || g.N <= 0 || g.K <= 0) return OFB_EINVAL;
   if (g.a_kc == 0 && g.b_kc == 1) return OFB_ELIMIT;           // A^T * B^T is not on the path
+  if (g.colpart && C128::BM != 128) return OFB_ELIMIT;
   if (g.rowscale && g.rs_div <= 0) return OFB_EINVAL;
   if (g.act == OFB_ACT_DGELU && !g.aux) return OFB_EINVAL;
   if (g.C && g.ldc < g.N) return OFB_EINVAL;

@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libofb_hip.so')
+LIB_PATH = os.environ.get('OFB_LIB_PATH') or os.path.join(_HERE, 'csrc', 'libofb_hip.so')      # OFB_LIB_PATH: lab A/B of two builds
 _lib = None
 
 
@@ -146,7 +146,7 @@ class GemmPArgs(C.Structure):
         ('C', C.c_void_p), ('ldc', C.c_int32), ('Cp', C.c_void_p), ('c_ncb', C.c_int32),
         ('alpha', C.c_float), ('bias', C.c_void_p), ('colscale', C.c_void_p), ('rowscale', C.c_void_p), ('rs_div', C.c_int32),
         ('resid', C.c_void_p), ('ldr', C.c_int32), ('aux', C.c_void_p), ('ldaux', C.c_int32), ('act', C.c_int32),
-        ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64),
+        ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('colpart', C.c_void_p),
     ]
 
 
@@ -266,8 +266,9 @@ def weight_p(W, shape2d=None):
 
 
 def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
-           resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE):
-    """C[M][N] (f32 and / or P-format) = A * B on P-format operands (PMat); a_kc / b_kc: reduction along the operand's columns."""
+           resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, colsum_out=None):
+    """C[M][N] (f32 and / or P-format) = A * B on P-format operands (PMat); a_kc / b_kc: reduction along the operand's columns.
+    colsum_out [N]: also receives the column sums of the output (fused per-tile partial sums + one small reduction)."""
     g = GemmPArgs()
     g.A, g.B, g.a_kc, g.b_kc, g.a_ncb, g.b_ncb = ptr(A.buf), ptr(B.buf), int(a_kc), int(b_kc), A.ncb, B.ncb
     g.M, g.N, g.K = M, N, K
@@ -278,12 +279,18 @@ def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bia
         g.Cp, g.c_ncb = ptr(Cp.buf), Cp.ncb
     g.alpha, g.bias, g.colscale, g.rowscale, g.rs_div = alpha, ptr(bias), ptr(colscale), ptr(rowscale), rs_div
     g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
+    part = None
+    if colsum_out is not None:
+        part = torch.empty((M + 127) // 128, N, device=A.buf.device, dtype=torch.float32)
+        g.colpart = ptr(part)
     lib().ofb_gemm_p_workspace_bytes.restype = C.c_int64
     need = lib().ofb_gemm_p_workspace_bytes(C.byref(g))
     if need > 0:
         ws = _workspace(A.buf.device, need)
         g.workspace, g.workspace_bytes = ptr(ws), ws.numel() * 4
     check(lib().ofb_gemm_p(C.byref(g), stream()), 'ofb_gemm_p')
+    if part is not None:
+        colsum(part, N, part.shape[0], N, colsum_out)
 
 
 def splitk_reduce(ws, splits, count, out, accumulate=False):

@@ -84,11 +84,11 @@ def p_linear_fwd(xP, M, K, WP, b, colscale=None, act=hip.ACT_NONE, aux=None, row
     return y, yP
 
 
-def p_linear_bwd_input(dyP, M, N, WP, K, resid=None, act=hip.ACT_NONE, aux=None, want_f32=True, want_p=False):
+def p_linear_bwd_input(dyP, M, N, WP, K, resid=None, act=hip.ACT_NONE, aux=None, want_f32=True, want_p=False, colsum_out=None):
     """dX[M,K] = dY[M,N] @ W[N,K]: dY reduced along its columns (KC), W along its rows (KR): the SAME P-format copy of W as forward"""
     dx = torch.empty(M, K, device=dyP.buf.device, dtype=torch.float32) if want_f32 else None
     dxP = hip.PMat(M, K, dyP.buf.device) if want_p else None
-    hip.gemm_p(dyP, WP, 1, 0, M, K, N, C_out=dx, ldc=K, Cp=dxP, resid=resid, ldr=K, act=act, aux=aux, ldaux=K)
+    hip.gemm_p(dyP, WP, 1, 0, M, K, N, C_out=dx, ldc=K, Cp=dxP, resid=resid, ldr=K, act=act, aux=aux, ldaux=K, colsum_out=colsum_out)
     return dx, dxP
 
 
@@ -405,18 +405,15 @@ def _mlp_backward_p(ctx, dout):
     d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, colsum_out=db2)
     # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> P-format only
     w1P, w2P = ctx.wp
-    _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_DGELU, aux=hpre, want_f32=False, want_p=True)
+    # the fc1 bias gradient (column sums of this P-format-only result) rides on the epilogue
+    db1_raw = _new(hpre, hid) if b1 is not None else None
+    _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_DGELU, aux=hpre, want_f32=False, want_p=True, colsum_out=db1_raw)
     dw2 = grad_slot(w2)
     dw2 = dw2 if dw2 is not None else _new(d2, D, hid)
     with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2) else _nullctx()):
         p_linear_bwd_weight(d2sP, hP, M, D, hid, out=dw2)
 
-    def dh_colsum():
-        out = _new(hpre, hid)
-        hip.colsum_p(dhP, out)
-        return out
-
-    dx, dw1, db1, dg = _p_gated_linear_bwd(dhP, dh_colsum, xP, M, w1, w1P, b1, gv, resid=d2 if self_resid else None)
+    dx, dw1, db1, dg = _p_gated_linear_bwd(dhP, lambda: db1_raw, xP, M, w1, w1P, b1, gv, resid=d2 if self_resid else None)
     dres = None if self_resid else dout
     return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None
 

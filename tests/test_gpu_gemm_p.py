@@ -99,11 +99,13 @@ def test_gemm_p_epilogues(M, N, K):
     rows = torch.arange(M) // 197
     _close(out, ref * rs.double()[rows].unsqueeze(1) + res.double(), 'residual + rowscale')
     # dGELU form with P-format output
-    dp = hip.PMat(M, N, 'cuda')
-    hip.gemm_p(xp, wp, 1, 1, M, N, K, Cp=dp, aux=aux, ldaux=N, act=hip.ACT_DGELU)
+    dp, cs_out = hip.PMat(M, N, 'cuda'), torch.full((N,), float('nan'), device='cuda')
+    hip.gemm_p(xp, wp, 1, 1, M, N, K, Cp=dp, aux=aux, ldaux=N, act=hip.ACT_DGELU, colsum_out=cs_out)
     p = pre.clone().requires_grad_(True)
     torch.nn.functional.gelu(p).sum().backward()
-    _close(dp.to_f32(), (x.double() @ w.double().t()) * p.grad, 'dgelu (P-format)')
+    dref = (x.double() @ w.double().t()) * p.grad
+    _close(dp.to_f32(), dref, 'dgelu (P-format)')
+    _close(cs_out, dref.sum(0), 'column sums of the output from the fused epilogue', tol=1e-5)
 
 
 def test_gemm_p_deit_small_layer_shapes():
