@@ -354,7 +354,8 @@ def main():
         n, ms, work = prof[0]
         if n:
             ach = work / (ms * 1e-3) / 1e12
-            roof = dict(bound='mfma', kernel='gemm_f32_kernel (f32 via 6-term bf16 split on v_mfma_f32_32x32x16_bf16)',
+            roof = dict(bound='mfma', kernel='gemm_p_kernel (f32 products as six v_mfma_f32_32x32x16_bf16 terms of operands pre-split into three bf16 planes, '
+                                             'LDS-DMA staged; main + stream-K tail + fix-up launches of all ofb_gemm_p calls)',
                         achieved=round(ach, 2), peak=round(PEAK_GEMM_TFLOPS, 1), unit='TFLOP/s', frac=round(ach / PEAK_GEMM_TFLOPS, 4),
                         traffic=None, peak_basis='2500 TFLOP/s dense bf16 MFMA / 6 MFMA terms per f32 product (achieved = algorithmic '
                                                  'f32 flops; the f32-input MFMA peak would be 157.3)',
@@ -365,9 +366,10 @@ def main():
                 tr, src = gemm_traffic_per_launch(n / prof_steps)
                 if tr:
                     roof['traffic'] = round(tr)
-                    roof['traffic_unit'] = 'bytes per ofb_gemm_f32 call (FETCH_SIZE x2 + WRITE_SIZE of its kernels, PMC)'
+                    roof['traffic_unit'] = 'bytes per GEMM call (FETCH_SIZE x2 + WRITE_SIZE of its kernels, PMC)'
                     roof['traffic_source'] = src
-                    roof['algorithmic_bytes_note'] = 'operands + outputs + epilogue side inputs of the 152 calls, each moved once: 28.4 GB per step = 187 MB per call'
+                    roof['algorithmic_bytes_note'] = ('P-format operands (6 B / element) + outputs + epilogue side inputs of the 152 calls, each moved '
+                                                      'once: 37.8 GB per step = 249 MB per call')
     step_tflops = value * gflop_img / 1e3 / world
     log(f'loss_total {loss_val:.4f}; step {ms_step:.2f} ms; whole-step {step_tflops:.1f} TFLOP/s/GPU '
         f'({step_tflops / PEAK_F32_MFMA_TFLOPS:.1%} of the f32 MFMA peak)')

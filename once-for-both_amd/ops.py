@@ -178,10 +178,17 @@ def _gated_linear_bwd(dy2d, x2d, W, b, gvec, resid=None):
     return dx, dW, db, dg
 
 
+def _rs_div(rowscale, M):
+    """rowscale holds one factor per token (M entries) or per sample (B entries: every sample's N tokens share it)"""
+    return 1 if rowscale is None else M // rowscale.numel()
+
+
 def _droppath_scaled(d2, rowscale):
     """d2 * rowscale[token]: one HBM pass instead of a scale lookup inside the three GEMMs that consume it."""
     if rowscale is None:
         return d2
+    if rowscale.numel() != d2.shape[0]:
+        rowscale = rowscale.repeat_interleave(d2.shape[0] // rowscale.numel())
     out = torch.empty_like(d2)
     hip.scale_rows(d2, rowscale, out, d2.shape[0], d2.shape[1])
     return out
@@ -279,7 +286,7 @@ class AttnBranch(torch.autograd.Function):
             o, lse = _new(x, M, Hd), _new(x, B * heads, N)
             hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
             oP = hip.to_pformat(o, M, Hd, Hd)
-            out, _ = p_linear_fwd(oP, M, Hd, wpP, bproj, rowscale=rowscale, rs_div=1, resid=r2d)
+            out, _ = p_linear_fwd(oP, M, Hd, wpP, bproj, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
             ctx.save_for_backward(xP.buf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, oP.buf)
             ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None)
             return out.view(B, N, D)
@@ -288,7 +295,7 @@ class AttnBranch(torch.autograd.Function):
         dh = Hd // heads
         o, lse = _new(x, M, Hd), _new(x, B * heads, N)
         hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
-        out = linear_fwd(o, wproj, bproj, rowscale=rowscale, rs_div=1, resid=r2d)
+        out = linear_fwd(o, wproj, bproj, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
         ctx.save_for_backward(x2d, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale)
         ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None)
         return out.view(B, N, D)
@@ -323,7 +330,7 @@ def _attn_backward_p(ctx, dout):
     d2 = _c(dout).view(M, D)
     # gradient of the branch output: DropPath factor applied, planes written and the projection's bias gradient summed in ONE pass
     dbp = _new(d2, D) if has_pb else None
-    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, colsum_out=dbp)
+    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=dbp)
     wqP, wpP = ctx.wp
     do, _ = p_linear_bwd_input(d2sP, M, D, wpP, Hd)
     dwp = grad_slot(wproj)
@@ -366,12 +373,12 @@ class MlpBranch(torch.autograd.Function):
             # gelu(g * fc1(x)) leaves the kernel as the P-format operand of fc2 (and of the fc2 weight gradient); only the f32
             # pre-activation is kept beside it for GELU'
             _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU, aux=hpre, want_f32=False, want_p=True)
-            out, _ = p_linear_fwd(hP, M, hid, w2P, b2, rowscale=rowscale, rs_div=1, resid=r2d)
+            out, _ = p_linear_fwd(hP, M, hid, w2P, b2, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
             ctx.save_for_backward(xP.buf, hpre, hP.buf, w1, b1, w2, gv, rowscale)
             ctx.meta = (B, N, D, resid is None, b2 is not None)
             return out.view(B, N, D)
         h = linear_fwd(x2d, w1, b1, colscale=gv, act=hip.ACT_GELU, aux=hpre)
-        out = linear_fwd(h, w2, b2, rowscale=rowscale, rs_div=1, resid=r2d)
+        out = linear_fwd(h, w2, b2, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
         ctx.save_for_backward(x2d, hpre, h, w1, b1, w2, gv, rowscale)
         ctx.meta = (B, N, D, resid is None, b2 is not None)
         return out.view(B, N, D)
@@ -402,7 +409,7 @@ def _mlp_backward_p(ctx, dout):
     xP, hP = _pm(xbuf, M, D), _pm(hbuf, M, hid)
     d2 = _c(dout).view(M, D)
     db2 = _new(d2, D) if has_b2 else None
-    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, colsum_out=db2)
+    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=db2)
     # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> P-format only
     w1P, w2P = ctx.wp
     # the fc1 bias gradient (column sums of this P-format-only result) rides on the epilogue

@@ -250,7 +250,7 @@ class MIMVisionTransformer(MAEBaseModel):
         self._side_stream = None
 
     # ---- checkpoints: whole-object pickles (search.py:671-740) and deepcopy (ModelEma) --------------
-    _TRANSIENT = ('_gate_out', '_side_stream', '_flops_maps', '_forced', '_masked_ids')
+    _TRANSIENT = ('_gate_out', '_side_stream', '_flops_maps', '_forced', '_masked_ids', '_dp_keep')
 
     def __getstate__(self):
         d = self.__dict__.copy()
@@ -358,13 +358,20 @@ class MIMVisionTransformer(MAEBaseModel):
             forced = self._forced
             u = forced['droppath_u'] if forced and 'droppath_u' in forced else torch.rand(2 * depth, B, device=dev)
         call = 0
-        ntok = x.shape[1]
+        scales = None
+        if u is not None:
+            # timm DropPath keep / keep_prob factors of all residual branches in one shot: the uniforms are consumed in call order
+            # (attn_i, mlp_i) by the blocks whose rate is > 0; one factor per SAMPLE, the kernels index it by token // tokens
+            live = [i for i in range(depth) if rates[i] > 0]
+            key = (tuple(rates), str(dev))
+            if getattr(self, '_dp_keep', None) is None or self._dp_keep[0] != key:
+                self._dp_keep = (key, torch.tensor([1.0 - rates[i] for i in live for _ in range(2)], device=dev).unsqueeze(1))
+            keep = self._dp_keep[1]
+            scales = torch.floor(keep + u[:2 * len(live)]) / keep
         for i, blk in enumerate(self.blocks):
             rs = [None, None]
-            if u is not None and rates[i] > 0:
-                keep = 1.0 - rates[i]
-                sc = (torch.floor(keep + u[call:call + 2]) / keep).repeat_interleave(ntok, dim=1)   # one factor per token
-                rs = [sc[0], sc[1]]
+            if scales is not None and rates[i] > 0:
+                rs = [scales[call], scales[call + 1]]
                 call += 2
             x = blk.run(x, replace, self._module_gate(blk.attn), self._module_gate(blk.mlp), rs[0], rs[1])
         x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)

@@ -68,8 +68,21 @@ def _rms(e):
     return e.double().pow(2).mean().sqrt().item()
 
 
+_ref_cache = {}
+
+
+def _references(kind, M, N, K):
+    """operands and CPU references of one case, shared by the three storage forms (the k-ordered chain is a Python loop)"""
+    key = (kind, M, N, K)
+    if key not in _ref_cache:
+        a, b_t = _operands(kind, (M, K), 101), _operands(kind if kind != 'tiny' else 'normal', (N, K), 202)
+        exact = a.double() @ b_t.double().t()
+        _ref_cache[key] = (a, b_t, exact, _rms(fma_chain_reference(a, b_t).double() - exact), _rms(bf16x3_reference(a, b_t) - exact))
+    return _ref_cache[key]
+
+
 FORMS = ['nt', 'nn', 'tn']
-CASES = [(256, 384, 384), (200, 384, 1536), (256, 256, 25216)]          # (M, N, K) of the product A[M,K] * B[N,K]^T
+CASES = [(256, 384, 384), (200, 384, 1536), (128, 192, 25216)]          # (M, N, K) of the product A[M,K] * B[N,K]^T
 KINDS = ['normal', 'wide_range', 'low_planes', 'tiny', 'positive']
 
 
@@ -120,12 +133,9 @@ def test_gemm_passes_all_24_bits(form, M, N, K):
 @pytest.mark.parametrize('kind', KINDS)
 def test_gemm_is_fp32_class(form, M, N, K, kind):
     """criterion 2: RMS error <= 2x that of an fp32 fma chain"""
-    a, b_t = _operands(kind, (M, K), 101), _operands(kind if kind != 'tiny' else 'normal', (N, K), 202)
-    exact = a.double() @ b_t.double().t()
+    a, b_t, exact, r_chain, r3 = _references(kind, M, N, K)
     got = _run(form, a, b_t)
     r = _rms(got.double() - exact)
-    r_chain = _rms(fma_chain_reference(a, b_t).double() - exact)
-    r3 = _rms(bf16x3_reference(a, b_t) - exact)
     print(f'{form} {M}x{N}x{K} {kind}: rms error kernel {r:.2e}  fp32 fma chain {r_chain:.2e}  bf16x3 {r3:.2e}')
     if K <= 1536 and kind != 'positive':
         assert r3 > 4 * r_chain, 'on this data a 3-term engine must be distinguishable from fp32 (else the case proves nothing)'
