@@ -299,9 +299,29 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
   // six product terms, smallest first: (mid,mid) (hi,lo) (lo,hi) (hi,mid) (mid,hi) (hi,hi)
   constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
   constexpr int NMF = 6 * HA * NI, RD2 = 6 * HA + 6 * NI;       // MFMAs per half step; fragment reads riding in the second half
+#ifndef OFB_P_PRIO_HI
+#define OFB_P_PRIO_HI 1
+#endif
+#ifdef OFB_P_PRIO
+#define OFB_PRIO(x) __builtin_amdgcn_s_setprio(x)
+#else
+#define OFB_PRIO(x) do { } while (0)
+#endif
+#ifdef OFB_P_SHAPE16_TIMING
+  // lab, WRONG RESULTS: same operand traffic and matrix-pipe cycles on the 16x16x32 shape (clock the chip holds under this shape)
+#define OFB_MMA_HALF(AF, BF, BLK0)                                                                                                   \
+  _Pragma("unroll") for (int q = 0; q < 6; ++q) _Pragma("unroll") for (int i = 0; i < HA; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) { \
+      f32x4 lo_ = {acc[BLK0 + i][j][0], acc[BLK0 + i][j][1], acc[BLK0 + i][j][2], acc[BLK0 + i][j][3]};                                 \
+      f32x4 hi_ = {acc[BLK0 + i][j][4], acc[BLK0 + i][j][5], acc[BLK0 + i][j][6], acc[BLK0 + i][j][7]};                                 \
+      lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][TA[q]], BF[j][TB[q]], lo_, 0, 0, 0);                                        \
+      hi_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][TB[q]], BF[j][TA[q]], hi_, 0, 0, 0);                                        \
+      acc[BLK0 + i][j][0] = lo_[0]; acc[BLK0 + i][j][1] = lo_[1]; acc[BLK0 + i][j][2] = lo_[2]; acc[BLK0 + i][j][3] = lo_[3];          \
+      acc[BLK0 + i][j][4] = hi_[0]; acc[BLK0 + i][j][5] = hi_[1]; acc[BLK0 + i][j][6] = hi_[2]; acc[BLK0 + i][j][7] = hi_[3]; }
+#else
 #define OFB_MMA_HALF(AF, BF, BLK0)                                                                                                   \
   _Pragma("unroll") for (int q = 0; q < 6; ++q) _Pragma("unroll") for (int i = 0; i < HA; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
       acc[BLK0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[i][TA[q]], BF[j][TB[q]], acc[BLK0 + i][j], 0, 0, 0);
+#endif
 #define OFB_INTERLEAVE(NM, ND)                                                               \
   _Pragma("unroll") for (int z_ = 0; z_ < (NM); ++z_) {                                      \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
@@ -312,10 +332,17 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
   int sidx = 0;
   Seg cur = get_seg<TAIL>(p, v, 0);
   if (!cur.ok) return;
-  if (CF::WGS > 1 && p.stagger > 0 && (int)blockIdx.x >= p.W / 2) {
-    // de-phase the two workgroups of a CU (the later-dispatched half of the grid waits about half a tile): in lock step both sit
-    // in their epilogues together and the matrix pipe idles; out of phase one's epilogue runs under the other's MFMAs
-    for (int z = 0; z < p.stagger; ++z) __builtin_amdgcn_s_sleep(127);
+  if (CF::WGS > 1 && p.stagger > 0) {
+    // de-phase the two workgroups of a CU: in lock step both sit in their epilogues together (vector pipe and stores busy, matrix
+    // pipe idle) and then in their K loops together; out of phase one's epilogue runs under the other's MFMAs.  The workgroup in
+    // the CU's odd threadgroup slot (HW_ID.TG_ID) starts about half a unit late.
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+#ifdef OFB_P_STAMPS
+    if (t == 0 && blockIdx.x < 1024) ofb_p_stamps[(blockIdx.x * 8 + 7) * 4 + 3] = hw;
+#endif
+    if ((hw >> 16) & 1)
+      for (int z = 0; z < p.stagger; ++z) __builtin_amdgcn_s_sleep(127);
   }
   while (true) {
     const int nk = cur.it1 - cur.it0;
@@ -343,10 +370,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
       const int nbuf = buf + 1 == NST ? 0 : buf + 1;
       // first half: lower row blocks x B(i); the reads of the upper row blocks ride in the MFMA gaps
       __builtin_amdgcn_sched_barrier(0);
+      OFB_PRIO(OFB_P_PRIO_HI);
       rdA(ahi, buf, HA);
       OFB_MMA_HALF(alo, bb[par], 0)
       OFB_INTERLEAVE(NMF, 1)
       __builtin_amdgcn_sched_barrier(0);
+      OFB_PRIO(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // this wave is done reading buf(i)
       {                                                                      // own pieces of stage i+1 landed; later stages may fly
         int young = nk - i - 2;
@@ -358,12 +387,14 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
       // second half: upper row blocks x B(i); the reads of step i+1 (lower row blocks and B) ride in the gaps (after the last
       // step they fetch a stale buffer that nothing consumes)
       __builtin_amdgcn_sched_barrier(0);
+      OFB_PRIO(OFB_P_PRIO_HI);
       rdA(alo, nbuf, 0);
       rdB(bb[par ^ 1], nbuf);
       OFB_MMA_HALF(ahi, bb[par], HA)
       OFB_INTERLEAVE(RD2 > NMF ? RD2 - NMF : 0, 2)
       OFB_INTERLEAVE(RD2 > NMF ? 2 * NMF - RD2 : NMF, 1)
       __builtin_amdgcn_sched_barrier(0);
+      OFB_PRIO(0);
     };
     int buf = 0, i = 0;
     for (; i + 1 < nk; i += 2) {
@@ -595,6 +626,9 @@ int p_tile_choice(const ofb_gemm_p_args&) {
 template <class CF>
 Plan plan_p(const ofb_gemm_p_args& g) {
   int W = p_cu_count() * CF::WGS;
+#ifdef OFB_P_STAMPS
+  { const char* e = getenv("OFB_GEMM_P_WCAP"); if (e && atoi(e) > 0 && atoi(e) < W) W = atoi(e); }   // lab: fewer resident workgroups
+#endif
   const int tiles = ofb_cdiv(g.M, CF::BM) * ofb_cdiv(g.N, CF::BN);
   const long long iters = (long long)tiles * ofb_cdiv(g.K, 16);
   if (iters < W) W = (int)iters;

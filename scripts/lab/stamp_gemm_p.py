@@ -4,18 +4,21 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch, numpy as np
 from ofb_amd import hip
 hip.LIB_PATH = sys.argv[1]
-M, D, HID = 128 * 192, 384, 1536        # 1536 / 768 tiles: whole rounds for both tile configurations
+M, D, HID = 128 * 192, 384, 1536        # 1536 tiles: whole rounds at W = 512 and 256
 r = lambda *s: torch.randn(*s, device='cuda')
 x = r(M, D); xp = hip.to_pformat(x)
 w3, b3, g3 = r(HID, D), r(HID), r(HID); w3p = hip.to_pformat(w3)
 y = torch.empty(M, HID, device='cuda'); aux = torch.empty(M, HID, device='cuda'); hP = hip.PMat(M, HID, 'cuda')
-W = 512 if os.environ.get('OFB_GEMM_P_TILE') == '128' else 256
+W = int(os.environ.get('OFB_GEMM_P_WCAP', 512))
 def stamps(tag, fn, units=3):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     buf = (C.c_ulonglong * (1024 * 8 * 4))()
     assert hip.lib().ofb_diag_p_stamps(buf) == 0
     a = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8, 4).astype(np.int64)[:W, :units]
+    if os.environ.get('OFB_GEMM_P_STAGGER'):
+        hw = np.frombuffer(buf, dtype=np.uint64).reshape(1024, 8, 4)[:W, 7, 3].astype(np.int64)
+        print('   TG_ID histogram', np.bincount((hw >> 16) & 15), ' CU ids', len(set((hw >> 8) & 0xff)), ' SE', len(set((hw >> 13) & 7)))
     pro, kl, ep = a[:, :, 1] - a[:, :, 0], a[:, :, 2] - a[:, :, 1], a[:, :, 3] - a[:, :, 2]
     gap = a[:, 1:, 0] - a[:, :-1, 3]
     tot = a[:, units - 1, 3] - a[:, 0, 0]
