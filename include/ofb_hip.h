@@ -169,6 +169,13 @@ int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32
                       void* stream);
 int ofb_attention_bwd(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv, int32_t B,
                       int32_t N, int32_t H, int32_t dh, float scale, void* stream);
+/* The same gradient written as P-format planes of the [B*N][3*H*dh] matrix (ofb_pformat_bytes(B*N, 3*H*dh) bytes; the operand form
+ * of the qkv gradient GEMMs, see ofb_gemm_p) - exactly the f32 values ofb_attention_bwd writes - plus colpart[B][3*H*dh], the
+ * column sums over each image's tokens (their sum over B is the raw qkv bias gradient).  The kernel writes the
+ * B*N x 3*H*dh elements only: when B*N or 3*H*dh is not a multiple of 16 the caller zeroes the buffer beforehand (padding rows
+ * and columns of a P-format matrix are zero). */
+int ofb_attention_bwd_p(const float* qkv, const float* out, const float* lse, const float* dout, void* dqkv_p, float* colpart,
+                        int32_t B, int32_t N, int32_t H, int32_t dh, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Bi-mask gates of ALL searchable modules in one launch + adaptive one-hot (sparsity) loss + FLOPs loss.

@@ -241,24 +241,62 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   }
 }
 
+// P-format stores (csrc/gemm_p.hip: granules of 4 rows x 16 columns, [plane][c % 16][r % 4] bf16, 384 B, stored [rows/4][ncb])
+__device__ __forceinline__ char* att_p_slot(char* P, int ncb, int row, int col) {
+  return P + ((size_t)(row >> 2) * ncb + (col >> 4)) * 384 + (col & 15) * 8 + (row & 3) * 2;
+}
+// four consecutive rows row0.. (row0 % 4 == 0: one 8-byte slot per plane) of one column; only rows [rlo, rhi) belong to the caller
+__device__ __forceinline__ void att_store_p_col4(char* P, int ncb, int row0, int col, f32x4 v, int rlo, int rhi) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  att_split_pair(v[0], v[1], h0, m0, l0);
+  att_split_pair(v[2], v[3], h1, m1, l1);
+  char* q = att_p_slot(P, ncb, row0, col);
+  if (rlo == 0 && rhi == 4) {
+    *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(q + 128) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(q + 256) = make_uint2(l0, l1);
+    return;
+  }
+  const unsigned hs[2] = {h0, h1}, ms[2] = {m0, m1}, ls[2] = {l0, l1};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r >= rlo && r < rhi) {                             // rows of a neighbouring image in this slot are its workgroup's to write
+      const int sh = (r & 1) * 16;
+      *reinterpret_cast<unsigned short*>(q + 2 * r) = (unsigned short)(hs[r >> 1] >> sh);
+      *reinterpret_cast<unsigned short*>(q + 2 * r + 128) = (unsigned short)(ms[r >> 1] >> sh);
+      *reinterpret_cast<unsigned short*>(q + 2 * r + 256) = (unsigned short)(ls[r >> 1] >> sh);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // backward (one kernel: dq | dk | dv); P recomputed from lse
 // ------------------------------------------------------------------------------------------------------------------
+// PF: dq | dk | dv leave the kernel as P-format planes (the operand form of the qkv gradient GEMMs, csrc/gemm_p.hip) together with
+// their per-image column sums colpart[b][3 H dh] (the qkv bias gradient is their sum over b) instead of as f32 rows.  A lane's
+// four accumulator rows are four consecutive tokens of one channel = one 8-byte plane slot IF they start on a 4-row granule
+// boundary of the [B N] matrix: the workgroup therefore lays its 16-token tiles from position -sft (sft = b N % 4; tile position
+// p holds token p - sft, the first sft positions are padding like the ones behind token N - 1).  N + 3 <= 208 is checked by the host.
+// Only the image's first and last row group are shared with a neighbouring image; there the lane stores its own rows 2 bytes at a time.
+#define ATT_QPITCH 20       // PF: column pitch (floats) of the parked partial dQ tiles [64 ch][16 q + 4]
+template <bool PF>
 __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                                const float* __restrict__ lse, const float* __restrict__ dout,
-                                                               float* __restrict__ dqkv, int B, int N, int H, int dh, float scale) {
+                                                               float* __restrict__ dqkv, char* __restrict__ dP_out, int p_ncb,
+                                                               float* __restrict__ colpart, int B, int N, int H, int dh, float scale) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* Kt = smem;                                   // [208][68]  unscaled K, row-major (B operand of dQ = dS K)
   float* Qs = Kt + ATT_NMAX * ATT_LD;                 // [2][16][68]
   float* dOs = Qs + 2 * ATT_T * ATT_LD;               // [2][16][68]
   float* dSs = dOs + 2 * ATT_T * ATT_LD;              // [16][212]  dS of the current query tile, [q][key]
-  float* dQp = dSs + ATT_T * ATT_DSLD;                // [13][16][64] per-wave partial dQ of the current query tile
-  float* lse_s = dQp + ATT_NT * ATT_T * ATT_DMAX;     // [208]
+  float* lse_s = dSs + ATT_T * ATT_DSLD;              // [208]
   float* del_s = lse_s + ATT_NMAX;                    // [208]
+  float* dQp = del_s + ATT_NMAX;                      // per-wave partial dQ of the current query tile: [13][16][64], PF: [13][64][20]
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, head = blockIdx.x % H;
   const int ldq = 3 * H * dh, ldo = H * dh;
   const size_t tok0 = (size_t)b * N;
+  const int sft = PF ? (int)(tok0 & 3) : 0;           // tile position p <-> token p - sft
   const float* qbase = qkv + tok0 * ldq + head * dh;
   const float* kbase = qbase + H * dh;
   const float* vbase = qbase + 2 * H * dh;
@@ -267,22 +305,23 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
   float* dqbase = dqkv + tok0 * ldq + head * dh;
   float* dkbase = dqbase + H * dh;
   float* dvbase = dqbase + 2 * H * dh;
+  auto valid = [&](int pos) { return pos >= sft && pos - sft < N; };
 
-  // ---- prologue: K -> LDS; delta[q] = rowsum(dO * O) and lse -> LDS; clear the dQ accumulator; stage query tile 0 ----
+  // ---- prologue: K -> LDS; delta[q] = rowsum(dO * O) and lse -> LDS; stage query tile 0 ----
   for (int idx = t; idx < ATT_NMAX * 16; idx += ATT_THREADS) {
-    const int row = idx >> 4, c4 = (idx & 15) << 2;
+    const int row = idx >> 4, c4 = (idx & 15) << 2, tok = row - sft;
     f32x4 kv = zero4(), dv = zero4(), ov = zero4();
-    if (row < N && c4 < dh) {
-      kv = *reinterpret_cast<const f32x4*>(kbase + (size_t)row * ldq + c4);
-      dv = *reinterpret_cast<const f32x4*>(dobase + (size_t)row * ldo + c4);
-      ov = *reinterpret_cast<const f32x4*>(obase + (size_t)row * ldo + c4);
+    if (valid(row) && c4 < dh) {
+      kv = *reinterpret_cast<const f32x4*>(kbase + (size_t)tok * ldq + c4);
+      dv = *reinterpret_cast<const f32x4*>(dobase + (size_t)tok * ldo + c4);
+      ov = *reinterpret_cast<const f32x4*>(obase + (size_t)tok * ldo + c4);
     }
     *reinterpret_cast<f32x4*>(&Kt[row * ATT_LD + c4]) = kv;
     float d = dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
     d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
     if ((idx & 15) == 0) del_s[row] = d;
   }
-  for (int i = t; i < ATT_NMAX; i += ATT_THREADS) lse_s[i] = (i < N) ? lse[((size_t)b * H + head) * N + i] : 0.f;
+  for (int i = t; i < ATT_NMAX; i += ATT_THREADS) lse_s[i] = valid(i) ? lse[((size_t)b * H + head) * N + i - sft] : 0.f;
   // staging of a 16-row query tile: threads 0..255 carry Q, 256..511 carry dO (one float4 each)
   const bool stager = t < 512;
   const int srow = (t & 255) >> 4, sc4 = (t & 15) << 2;
@@ -290,9 +329,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
   auto stage_load = [&](int qt) {
     sreg = zero4();
     const int qq = qt * ATT_T + srow;
-    if (stager && qq < N && sc4 < dh)
-      sreg = (t < 256) ? *reinterpret_cast<const f32x4*>(qbase + (size_t)qq * ldq + sc4)
-                       : *reinterpret_cast<const f32x4*>(dobase + (size_t)qq * ldo + sc4);
+    if (stager && valid(qq) && sc4 < dh)
+      sreg = (t < 256) ? *reinterpret_cast<const f32x4*>(qbase + (size_t)(qq - sft) * ldq + sc4)
+                       : *reinterpret_cast<const f32x4*>(dobase + (size_t)(qq - sft) * ldo + sc4);
   };
   auto stage_store = [&](int buf) {
     if (stager) *reinterpret_cast<f32x4*>(&((t < 256) ? Qs : dOs)[buf * ATT_T * ATT_LD + srow * ATT_LD + sc4]) = sreg;
@@ -302,14 +341,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
 
   // this wave's key rows as B operands: K (scaled) for S = Q K^T, V for dP = dO V^T
   const int key = w * ATT_T + c;
+  const bool kvalid = valid(key);
   float kr[16], vr[16];
 #pragma unroll
   for (int u = 0; u < 4; ++u) {
     const int cc = 16 * g + 4 * u;
     f32x4 kv = zero4(), vv = zero4();
-    if (key < N && cc < dh) {
-      kv = *reinterpret_cast<const f32x4*>(kbase + (size_t)key * ldq + cc);
-      vv = *reinterpret_cast<const f32x4*>(vbase + (size_t)key * ldq + cc);
+    if (kvalid && cc < dh) {
+      kv = *reinterpret_cast<const f32x4*>(kbase + (size_t)(key - sft) * ldq + cc);
+      vv = *reinterpret_cast<const f32x4*>(vbase + (size_t)(key - sft) * ldq + cc);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { kr[4 * u + j] = kv[j] * scale; vr[4 * u + j] = vv[j]; }
@@ -319,7 +359,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
   for (int dt = 0; dt < 4; ++dt) { dK[dt] = zero4(); dV[dt] = zero4(); }
   __syncthreads();
 
-  const int nqt = (N + ATT_T - 1) / ATT_T;
+  const int nqt = (N + sft + ATT_T - 1) / ATT_T;
+  float dq_sum = 0.f;                                      // PF: column sum of this thread's dQ column (4-row quad rq) over the query tiles
   for (int qt = 0; qt < nqt; ++qt) {
     const int buf = qt & 1;
     const float* Qb = Qs + buf * ATT_T * ATT_LD;
@@ -349,7 +390,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qrow = qt * ATT_T + 4 * g + r;
-      const float pv = (key < N) ? __expf(S[r] - lse_s[qrow]) : 0.f;
+      const float pv = kvalid ? __expf(S[r] - lse_s[qrow]) : 0.f;
       P[r] = pv;
       dS[r] = pv * (dP[r] - del_s[qrow]);
     }
@@ -382,8 +423,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
       }
     }
     // dq[dt][r] = partial dQ[query 4g + r][channel 16 dt + c]: each wave parks its partial tile in its own LDS slot and
-    // 256 threads sum the 13 slots after the barrier (LDS float atomics cost ~180 cycles per wave-instruction here)
-    {
+    // 256 threads sum the 13 slots after the barrier (LDS float atomics cost ~180 cycles per wave-instruction here).
+    // f32 output: slot [16 q][64 ch], a thread sums 4 channels of one query.  PF: slot [64 ch][16 q (+4)], a thread sums the 4
+    // queries of one row group for one channel = one plane slot.
+    if (PF) {
+      float* mine = dQp + w * (ATT_DMAX * ATT_QPITCH);
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&mine[(16 * dt + c) * ATT_QPITCH + 4 * g]) = dq[dt];
+    } else {
       float* mine = dQp + w * ATT_T * ATT_DMAX;
 #pragma unroll
       for (int dt = 0; dt < 4; ++dt)
@@ -393,33 +440,91 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __re
     if (qt + 1 < nqt) stage_store(buf ^ 1);
     __syncthreads();                                                                   // (B) partial dQ tiles parked, next Q/dO staged
     if (t < 256) {
-      const int qq = qt * ATT_T + srow;
-      f32x4 v = zero4();
+      if (PF) {
+        const int ch = t & 63, rq = t >> 6, p0 = qt * ATT_T + 4 * rq;                  // tile positions p0 .. p0 + 3
+        f32x4 v = zero4();
 #pragma unroll
-      for (int ww = 0; ww < ATT_NT; ++ww) v += *reinterpret_cast<const f32x4*>(&dQp[ww * ATT_T * ATT_DMAX + srow * ATT_DMAX + sc4]);
-      if (qq < N && sc4 < dh) {
-        v *= scale;
-        *reinterpret_cast<f32x4*>(dqbase + (size_t)qq * ldq + sc4) = v;
+        for (int ww = 0; ww < ATT_NT; ++ww) v += *reinterpret_cast<const f32x4*>(&dQp[ww * (ATT_DMAX * ATT_QPITCH) + ch * ATT_QPITCH + 4 * rq]);
+        const int rlo = max(0, sft - p0), rhi = min(4, N + sft - p0);
+        if (ch < dh && rlo < rhi) {
+          v *= scale;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dq_sum += (r >= rlo && r < rhi) ? v[r] : 0.f;
+          att_store_p_col4(dP_out, p_ncb, (int)tok0 - sft + p0, head * dh + ch, v, rlo, rhi);
+        }
+      } else {
+        const int qq = qt * ATT_T + srow;
+        f32x4 v = zero4();
+#pragma unroll
+        for (int ww = 0; ww < ATT_NT; ++ww) v += *reinterpret_cast<const f32x4*>(&dQp[ww * ATT_T * ATT_DMAX + srow * ATT_DMAX + sc4]);
+        if (qq < N && sc4 < dh) {
+          v *= scale;
+          *reinterpret_cast<f32x4*>(dqbase + (size_t)qq * ldq + sc4) = v;
+        }
       }
     }
     // no third barrier: the next partial-dQ writes come after the next (A), the next dS writes after this (B)
   }
   // ---- dK (x scale), dV: dK[dt][r] = dK[key 16w + 4g + r][channel 16 dt + c] ----
+  if (!PF) {
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int kk = w * ATT_T + 4 * g + r;
-    if (kk < N) {
-      float* dkp = dkbase + (size_t)kk * ldq + c;
-      float* dvp = dvbase + (size_t)kk * ldq + c;
+    for (int r = 0; r < 4; ++r) {
+      const int kk = w * ATT_T + 4 * g + r;
+      if (kk < N) {
+        float* dkp = dkbase + (size_t)kk * ldq + c;
+        float* dvp = dvbase + (size_t)kk * ldq + c;
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-        if (16 * dt + c < dh) { dkp[16 * dt] = dK[dt][r] * scale; dvp[16 * dt] = dV[dt][r]; }
+        for (int dt = 0; dt < 4; ++dt)
+          if (16 * dt + c < dh) { dkp[16 * dt] = dK[dt][r] * scale; dvp[16 * dt] = dV[dt][r]; }
+      }
+    }
+    return;
+  }
+  {
+    const int k0 = w * ATT_T + 4 * g, row0 = (int)tok0 - sft + k0;                     // row0 % 4 == 0
+    const int rlo = max(0, sft - k0), rhi = min(4, N + sft - k0);                      // this image's rows of the slot
+    float* cs = dQp;                                       // [13 waves][2][64] column sums of this wave's dK / dV rows (dQp is free now)
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int ch = 16 * dt + c;
+      f32x4 kq = dK[dt] * scale, vq = dV[dt];
+      float sk = 0.f, sv = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        if (r < rlo || r >= rhi) { kq[r] = 0.f; vq[r] = 0.f; }
+        sk += kq[r]; sv += vq[r];
+      }
+      sk += __shfl_xor(sk, 16, 64); sk += __shfl_xor(sk, 32, 64);
+      sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
+      if (g == 0) { cs[(w * 2 + 0) * 64 + ch] = sk; cs[(w * 2 + 1) * 64 + ch] = sv; }
+      if (ch < dh && rlo < rhi) {
+        att_store_p_col4(dP_out, p_ncb, row0, H * dh + head * dh + ch, kq, rlo, rhi);
+        att_store_p_col4(dP_out, p_ncb, row0, 2 * H * dh + head * dh + ch, vq, rlo, rhi);
+      }
+    }
+    // dQ column sums: thread (channel t & 63, row quad t >> 6) holds its sum over the query tiles; the four quads are added in order
+    float* qs = cs + ATT_NT * 2 * 64;
+    if (t < 256) qs[(t >> 6) * 64 + (t & 63)] = dq_sum;
+    __syncthreads();
+    if (t < 192) {
+      const int part = t >> 6, ch = t & 63;
+      float sum = 0.f;
+      if (part == 0) {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) sum += qs[rr * 64 + ch];
+      } else {
+#pragma unroll
+        for (int ww = 0; ww < ATT_NT; ++ww) sum += cs[(ww * 2 + (part - 1)) * 64 + ch];
+      }
+      if (ch < dh) colpart[(size_t)b * (3 * H * dh) + part * (H * dh) + head * dh + ch] = sum;
     }
   }
 }
 
-constexpr size_t BWD_LDS =
-    (size_t)(ATT_NMAX * ATT_LD + 4 * ATT_T * ATT_LD + ATT_T * ATT_DSLD + ATT_NT * ATT_T * ATT_DMAX + 2 * ATT_NMAX) * sizeof(float);
+constexpr size_t BWD_LDS_BASE = (size_t)(ATT_NMAX * ATT_LD + 4 * ATT_T * ATT_LD + ATT_T * ATT_DSLD + 2 * ATT_NMAX) * sizeof(float);
+constexpr size_t BWD_LDS = BWD_LDS_BASE + (size_t)(ATT_NT * ATT_T * ATT_DMAX) * sizeof(float);
+constexpr size_t BWD_LDS_P = BWD_LDS_BASE + (size_t)(ATT_NT * ATT_DMAX * ATT_QPITCH) * sizeof(float);
 
 int check_shape(int B, int N, int H, int dh) {
   if (B <= 0 || N <= 0 || H <= 0 || dh <= 0) return OFB_EINVAL;
@@ -444,19 +549,46 @@ extern "C" int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32
   return ofb_launch_status();
 }
 
+namespace {
+int attention_bwd_launch(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv, char* dP_out, int p_ncb,
+                         float* colpart, int B, int N, int H, int dh, float scale, hipStream_t s) {
+  // the attribute is per device and the call is cheap: set it on every launch (a per-process flag would leave a second GPU
+  // of the same process without it, and is not thread-safe)
+  const void* fn = dP_out ? (const void*)attn_bwd_kernel<true> : (const void*)attn_bwd_kernel<false>;
+  const size_t ldsb = dP_out ? BWD_LDS_P : BWD_LDS;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return (int)hipGetLastError();
+  ofb_prof_pre(4, s, 10.0 * B * H * (double)N * N * dh);
+  if (dP_out)
+    hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B * H), dim3(ATT_THREADS), ldsb, s, qkv, out, lse, dout, dqkv, dP_out, p_ncb, colpart,
+                       B, N, H, dh, scale);
+  else
+    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * H), dim3(ATT_THREADS), ldsb, s, qkv, out, lse, dout, dqkv, dP_out, p_ncb, colpart,
+                       B, N, H, dh, scale);
+  ofb_prof_post(4, s);
+  return ofb_launch_status();
+}
+}  // namespace
+
 // dqkv: same packing as qkv (dq | dk | dv).  Needs the forward's out and lse.
 extern "C" int ofb_attention_bwd(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
                                  int32_t B, int32_t N, int32_t H, int32_t dh, float scale, void* stream) {
   if (!qkv || !out || !lse || !dout || !dqkv) return OFB_EINVAL;
   if (int rc = check_shape(B, N, H, dh)) return rc;
   if (!ofb_aligned16(qkv) || !ofb_aligned16(out) || !ofb_aligned16(dout) || !ofb_aligned16(dqkv)) return OFB_EINVAL;
-  // the attribute is per device and the call is cheap: set it on every launch (a per-process flag would leave a second GPU
-  // of the same process without it, and is not thread-safe)
-  if (hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS) != hipSuccess)
-    return (int)hipGetLastError();
-  hipStream_t s = (hipStream_t)stream;
-  ofb_prof_pre(4, s, 10.0 * B * H * (double)N * N * dh);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(ATT_THREADS), BWD_LDS, s, qkv, out, lse, dout, dqkv, B, N, H, dh, scale);
-  ofb_prof_post(4, s);
-  return ofb_launch_status();
+  return attention_bwd_launch(qkv, out, lse, dout, dqkv, nullptr, 0, nullptr, B, N, H, dh, scale, (hipStream_t)stream);
+}
+
+// The same gradient as P-format planes of the [B*N][3*H*dh] matrix (ofb_pformat_bytes(B*N, 3*H*dh) bytes; rows >= B*N of the
+// last 16-row group must be zero beforehand when B*N % 16 != 0) plus colpart[B][3*H*dh], the column sums over each image's
+// tokens (added in a fixed order).  The planes hold exactly the f32 values ofb_attention_bwd writes.
+extern "C" int ofb_attention_bwd_p(const float* qkv, const float* out, const float* lse, const float* dout, void* dqkv_p,
+                                   float* colpart, int32_t B, int32_t N, int32_t H, int32_t dh, float scale, void* stream) {
+  if (!qkv || !out || !lse || !dout || !dqkv_p || !colpart) return OFB_EINVAL;
+  if (int rc = check_shape(B, N, H, dh)) return rc;
+  if (!ofb_aligned16(qkv) || !ofb_aligned16(out) || !ofb_aligned16(dout) || !ofb_aligned16(dqkv_p)) return OFB_EINVAL;
+  int smax = 0;                                           // the tiles start (b N % 4) positions before the image's first token
+  for (int bb = 0; bb < B && bb < 4; ++bb) smax = ((bb * N) & 3) > smax ? ((bb * N) & 3) : smax;
+  if (N + smax > ATT_NMAX) return OFB_ELIMIT;
+  return attention_bwd_launch(qkv, out, lse, dout, nullptr, (char*)dqkv_p, (3 * H * dh + 15) / 16, colpart, B, N, H, dh, scale,
+                              (hipStream_t)stream);
 }

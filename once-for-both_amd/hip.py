@@ -42,7 +42,7 @@ ENGINE = os.environ.get('OFB_GEMM_ENGINE', 'p')
 SYMBOLS = [
     'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_colsum_slabs', 'ofb_colsum',
-    'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd',
+    'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets',
     'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
@@ -160,6 +160,15 @@ class PMat:
         f.restype = C.c_int64
         self.R, self.C, self.ncb = int(R), int(C_), (int(C_) + 15) // 16
         self.buf = buf if buf is not None else torch.empty(int(f(_i(R), _i(C_))), device=device, dtype=torch.uint8)
+
+    @staticmethod
+    def for_rows_written_by_kernel(R, C_, device):
+        """planes that a producer kernel fills element by element (attention backward): the padding rows / columns of the last
+        granules, which a reduction along the rows / columns would read, are zeroed here"""
+        pm = PMat(R, C_, device)
+        if R % 16 or C_ % 16:
+            pm.buf.zero_()
+        return pm
 
     def to_f32(self):
         out = torch.empty(self.R, self.C, device=self.buf.device, dtype=torch.float32)
@@ -358,6 +367,14 @@ def attention_fwd(qkv, out, lse, B, N, H, dh, scale):
 def attention_bwd(qkv, out, lse, dout, dqkv, B, N, H, dh, scale):
     check(lib().ofb_attention_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), _i(B), _i(N), _i(H), _i(dh),
                                   _f(scale), stream()), 'ofb_attention_bwd')
+
+
+def attention_bwd_p(qkv, out, lse, dout, dqkvP, colpart, B, N, H, dh, scale):
+    """dq | dk | dv as P-format planes (PMat [B*N][3*H*dh]) + per-image column sums colpart [B][3*H*dh]."""
+    if dqkvP.R != B * N or dqkvP.C != 3 * H * dh or colpart.numel() < B * 3 * H * dh:
+        raise OfbError('attention_bwd_p: output shapes')
+    check(lib().ofb_attention_bwd_p(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkvP.buf), ptr(colpart), _i(B), _i(N), _i(H),
+                                    _i(dh), _f(scale), stream()), 'ofb_attention_bwd_p')
 
 
 # ---- gates / losses -------------------------------------------------------------------------------

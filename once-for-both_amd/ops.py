@@ -337,10 +337,14 @@ def _attn_backward_p(ctx, dout):
     dwp = dwp if dwp is not None else _new(d2, D, Hd)
     with (hip.side_work(d2.device, keep=[d2sP.buf, oP.buf]) if _side_ok(wproj) else _nullctx()):
         p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=dwp)
-    dqkv = torch.empty_like(qkv)
-    hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
-    dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
-    dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw)
+    # dq | dk | dv leave the attention kernel as planes, with the per-image column sums the qkv bias gradient is made of
+    dqkvP = hip.PMat.for_rows_written_by_kernel(M, 3 * Hd, d2.device)
+    colpart = _new(d2, B, 3 * Hd)
+    hip.attention_bwd_p(qkv, o, lse, do, dqkvP, colpart, B, N, heads, dh, scale)
+    dbq_raw = None
+    if bqkv is not None:
+        dbq_raw = _new(d2, 3 * Hd)
+        hip.colsum(colpart, 3 * Hd, B, 3 * Hd, dbq_raw)
     dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None)
     dg = None
     if dg3 is not None:                                   # dg3 may still be in flight on the side stream: add it up there

@@ -46,6 +46,21 @@ def test_attention_fwd_bwd(B, N, H, dh):
           f'(scale {dqkv_ref.abs().max():.2e})')
     assert not torch.isnan(dqkv).any()
     assert err.max().item() < 5e-5 * max(1.0, dqkv_ref.abs().max().item())
+    # the P-format form of the same gradient: the planes hold exactly the f32 values, the column sums are per image
+    dP = hip.PMat.for_rows_written_by_kernel(B * N, 3 * Hd, 'cuda')
+    colpart = torch.full((B, 3 * Hd), float('nan'), device='cuda')
+    hip.attention_bwd_p(qd, o, lse, dout.cuda(), dP, colpart, B, N, H, dh, scale)
+    dpf = dP.to_f32()
+    # image 0 starts on a granule boundary: same tiling as the f32 kernel, so the planes hold exactly its values; the other
+    # images' tiles start (b N % 4) positions earlier (other summation grouping): same error bound against the fp64 gradient
+    assert torch.equal(dpf[:N], dqkv[:N])
+    assert (dpf.cpu().double() - dqkv_ref).abs().max().item() < 5e-5 * max(1.0, dqkv_ref.abs().max().item())
+    cs_ref = dpf.double().reshape(B, N, 3 * Hd).sum(1)
+    assert (colpart.double() - cs_ref).abs().max().item() < 1e-5 * max(1.0, cs_ref.abs().max().item())
+    again = hip.PMat.for_rows_written_by_kernel(B * N, 3 * Hd, 'cuda')
+    cp2 = torch.empty_like(colpart)
+    hip.attention_bwd_p(qd, o, lse, dout.cuda(), again, cp2, B, N, H, dh, scale)
+    assert torch.equal(cp2, colpart)                      # fixed summation order
 
 
 def test_attention_peaked_softmax():
