@@ -140,9 +140,20 @@ int ofb_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, void* stream);
  * ------------------------------------------------------------------------------------------- */
 int ofb_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                       int32_t rows, int32_t D, float eps, void* stream);
+/* y (optional, may be NULL) and the same rows as P-format planes y_p[rows][D] (the operand form of the following GEMM, see
+ * ofb_gemm_p; ofb_pformat_bytes(rows, D) bytes).  Row groups 0 .. ceil(rows/4)-1 are written whole (padding as zeros); the caller
+ * zeroes what is left of the last 16-row group when rows % 16 is in 1..12. */
+int ofb_layernorm_fwd_p(const float* x, const float* gamma, const float* beta, float* y, void* y_p, float* mean, float* rstd,
+                        int32_t rows, int32_t D, float eps, void* stream);
 int32_t ofb_layernorm_bwd_blocks(int32_t rows);
 int ofb_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                       const float* dres, float* dx, float* partials, int32_t rows, int32_t D, void* stream);
+/* Same, and dx * rowscale[row / rs_div] (rowscale optional: the DropPath factor of the branch this gradient flows into) also as
+ * P-format planes dx_p[rows][D]; partials is then [ofb_layernorm_bwd_blocks(rows)][3][D]: dgamma | dbeta | column sums of the
+ * scaled dx rows (that branch's output-bias gradient). */
+int ofb_layernorm_bwd_p(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                        const float* dres, float* dx, float* partials, void* dx_p, const float* rowscale, int32_t rs_div,
+                        int32_t rows, int32_t D, void* stream);
 
 /* out[N] = column sums of x[M][ld] (optionally rows scaled by rowscale[m / rs_div]): bias gradients of every
  * Linear on the path.  scratch: ofb_colsum_slabs(M, N) * N floats. */

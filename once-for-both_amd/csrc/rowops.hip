@@ -35,76 +35,130 @@ __device__ __forceinline__ void ln_store(const float (&v)[LN_MAXE], float* __res
   }
 }
 
-template <int V>
+// PF: the normalised rows also leave as P-format planes yP (operand form of the following GEMM, csrc/gemm_p.hip): the four waves of
+// a block hold the four rows of one row group; they meet in LDS and every thread writes whole 8-byte plane slots of its columns.
+template <int V, bool PF>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ y,
+                                                     const float* __restrict__ beta, float* __restrict__ y, char* __restrict__ yP,
                                                      float* __restrict__ mean, float* __restrict__ rstd, int rows, int D,
                                                      float eps) {
-  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  float v[LN_MAXE], g[LN_MAXE], b[LN_MAXE];
-  ln_load<V>(v, x + (size_t)row * D, D, lane);
-  ln_load<V>(g, gamma, D, lane);
-  ln_load<V>(b, beta, D, lane);
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < LN_MAXE; ++i) s += v[i];
-  const float mu = ofb_wave_sum(s) / (float)D;
-  float q = 0.f;
-#pragma unroll
-  for (int i = 0; i < LN_MAXE; ++i) {
-    const int c = ln_col<V>(lane, i / V, i % V);
-    const float d = (c < D) ? v[i] - mu : 0.f;
-    q += d * d;
-  }
-  const float rs = 1.0f / sqrtf(ofb_wave_sum(q) / (float)D + eps);
-#pragma unroll
-  for (int i = 0; i < LN_MAXE; ++i) v[i] = (v[i] - mu) * rs * g[i] + b[i];
-  ln_store<V>(v, y + (size_t)row * D, D, lane);
-  if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
-}
-
-// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)) (+ dres); per-block partial dgamma/dbeta
-template <int V>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
-                                                     float* __restrict__ dx, float* __restrict__ part, int rows, int D) {
-  __shared__ float red[4 * 2 * 1024];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  float g[LN_MAXE], ag[LN_MAXE], ab[LN_MAXE];
-  ln_load<V>(g, gamma, D, lane);
-#pragma unroll
-  for (int i = 0; i < LN_MAXE; ++i) ag[i] = ab[i] = 0.f;
-  for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
-    float v[LN_MAXE], d[LN_MAXE];
+  __shared__ float tile[PF ? 4 * 64 * LN_MAXE : 1];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, row = blockIdx.x * 4 + w;
+  if (!PF && row >= rows) return;
+  float v[LN_MAXE];
+  if (row < rows) {
+    float g[LN_MAXE], b[LN_MAXE];
     ln_load<V>(v, x + (size_t)row * D, D, lane);
-    ln_load<V>(d, dy + (size_t)row * D, D, lane);
-    const float mu = mean[row], rs = rstd[row];
-    float s1 = 0.f, s2 = 0.f;
+    ln_load<V>(g, gamma, D, lane);
+    ln_load<V>(b, beta, D, lane);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXE; ++i) s += v[i];
+    const float mu = ofb_wave_sum(s) / (float)D;
+    float q = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXE; ++i) {
       const int c = ln_col<V>(lane, i / V, i % V);
-      const float xh = (c < D) ? (v[i] - mu) * rs : 0.f;
-      const float dg = d[i] * g[i];
-      ag[i] += d[i] * xh;
-      ab[i] += d[i];
-      s1 += dg;
-      s2 += dg * xh;
-      v[i] = xh;
-      d[i] = dg;
+      const float d = (c < D) ? v[i] - mu : 0.f;
+      q += d * d;
     }
-    const float c1 = ofb_wave_sum(s1) / (float)D, c2 = ofb_wave_sum(s2) / (float)D;
+    const float rs = 1.0f / sqrtf(ofb_wave_sum(q) / (float)D + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXE; ++i) v[i] = rs * (d[i] - c1 - v[i] * c2);
-    if (dres) {
-      float r[LN_MAXE];
-      ln_load<V>(r, dres + (size_t)row * D, D, lane);
+    for (int i = 0; i < LN_MAXE; ++i) v[i] = (v[i] - mu) * rs * g[i] + b[i];
+    if (y) ln_store<V>(v, y + (size_t)row * D, D, lane);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  } else {
 #pragma unroll
-      for (int i = 0; i < LN_MAXE; ++i) v[i] += r[i];
-    }
-    ln_store<V>(v, dx + (size_t)row * D, D, lane);
+    for (int i = 0; i < LN_MAXE; ++i) v[i] = 0.f;                      // padding rows of the last row group: zero planes
   }
+  if (PF) {
+    const int Dp = (D + 15) & ~15;
+#pragma unroll
+    for (int i = 0; i < LN_MAXE; ++i) {
+      const int c = ln_col<V>(lane, i / V, i % V);
+      if (c < Dp) tile[w * (64 * LN_MAXE) + c] = (c < D) ? v[i] : 0.f;
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < Dp; c += 256)
+      ofb_store_p4(yP, Dp >> 4, blockIdx.x, c, tile[c], tile[64 * LN_MAXE + c], tile[2 * 64 * LN_MAXE + c], tile[3 * 64 * LN_MAXE + c]);
+  }
+}
+
+// dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)) (+ dres); per-block partial dgamma/dbeta
+// PF: dx * rowscale[row / rs_div] also leaves as P-format planes dxP (the gradient w.r.t. the previous branch's output is the dY
+// operand of that branch's gradient GEMMs, DropPath factor applied), and part gets a third [D] section per block: the column sums
+// of those scaled rows (that branch's last bias gradient).
+template <int V, bool PF>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                     float* __restrict__ dx, float* __restrict__ part, int rows, int D,
+                                                     char* __restrict__ dxP, const float* __restrict__ rowscale, int rs_div) {
+  __shared__ float red[4 * 2 * 1024];
+  constexpr int NS = PF ? 3 : 2;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float g[LN_MAXE], ag[LN_MAXE], ab[LN_MAXE];
+  float cacc[PF ? 4 : 1];                                  // PF: column sums of the scaled rows, columns threadIdx.x + 256 k
+  ln_load<V>(g, gamma, D, lane);
+#pragma unroll
+  for (int i = 0; i < LN_MAXE; ++i) ag[i] = ab[i] = 0.f;
+#pragma unroll
+  for (int k = 0; k < (PF ? 4 : 1); ++k) cacc[k] = 0.f;
+  const int Dp = (D + 15) & ~15;
+  for (int row0 = blockIdx.x * 4; row0 < rows; row0 += gridDim.x * 4) {
+    const int row = row0 + w;
+    float v[LN_MAXE];
+    if (row < rows) {
+      float d[LN_MAXE];
+      ln_load<V>(v, x + (size_t)row * D, D, lane);
+      ln_load<V>(d, dy + (size_t)row * D, D, lane);
+      const float mu = mean[row], rs = rstd[row];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < LN_MAXE; ++i) {
+        const int c = ln_col<V>(lane, i / V, i % V);
+        const float xh = (c < D) ? (v[i] - mu) * rs : 0.f;
+        const float dg = d[i] * g[i];
+        ag[i] += d[i] * xh;
+        ab[i] += d[i];
+        s1 += dg;
+        s2 += dg * xh;
+        v[i] = xh;
+        d[i] = dg;
+      }
+      const float c1 = ofb_wave_sum(s1) / (float)D, c2 = ofb_wave_sum(s2) / (float)D;
+#pragma unroll
+      for (int i = 0; i < LN_MAXE; ++i) v[i] = rs * (d[i] - c1 - v[i] * c2);
+      if (dres) {
+        float r[LN_MAXE];
+        ln_load<V>(r, dres + (size_t)row * D, D, lane);
+#pragma unroll
+        for (int i = 0; i < LN_MAXE; ++i) v[i] += r[i];
+      }
+      ln_store<V>(v, dx + (size_t)row * D, D, lane);
+    }
+    if (PF) {
+      // the block's four rows are one row group: scaled copies meet in LDS (the first 4 x 1024 floats of red), one thread per column
+      const float sc = (row < rows) ? (rowscale ? rowscale[rs_div == 1 ? row : row / rs_div] : 1.f) : 0.f;
+      __syncthreads();                                     // the previous trip's readers are done
+#pragma unroll
+      for (int i = 0; i < LN_MAXE; ++i) {
+        const int c = ln_col<V>(lane, i / V, i % V);
+        if (c < Dp) red[w * 1024 + c] = (row < rows && c < D) ? v[i] * sc : 0.f;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < Dp) {
+          const float a0 = red[c], a1 = red[1024 + c], a2 = red[2048 + c], a3 = red[3072 + c];
+          cacc[k] += (a0 + a1) + (a2 + a3);
+          ofb_store_p4(dxP, Dp >> 4, row0 >> 2, c, a0, a1, a2, a3);
+        }
+      }
+    }
+  }
+  if (PF) __syncthreads();
   // cross-wave reduction of the per-lane column partials
 #pragma unroll
   for (int i = 0; i < LN_MAXE; ++i) {
@@ -116,8 +170,180 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
     float sg = 0.f, sb = 0.f;
 #pragma unroll
     for (int k = 0; k < 4; ++k) { sg += red[k * 2048 + c]; sb += red[k * 2048 + 1024 + c]; }
-    part[(size_t)blockIdx.x * 2 * D + c] = sg;
-    part[(size_t)blockIdx.x * 2 * D + D + c] = sb;
+    part[(size_t)blockIdx.x * NS * D + c] = sg;
+    part[(size_t)blockIdx.x * NS * D + D + c] = sb;
+  }
+  if (PF) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int c = threadIdx.x + 256 * k;
+      if (c < D) part[(size_t)blockIdx.x * NS * D + 2 * D + c] = cacc[k];
+    }
+  }
+}
+
+// ---- P-format variants for even D: one WAVE per row group (4 rows), lane owns the column pairs 2 (64 j + lane) + {0, 1}, j < NJ: the
+// four rows of a column sit in one lane's registers and leave as whole plane slots (two adjacent slots = one 16-byte store per
+// plane), with no LDS and no block barrier ----
+template <int NJ>
+__device__ __forceinline__ void ln_p_store(char* __restrict__ P, int ncb, int rg, int lane, int Dp, const float (&v)[4][2 * NJ]) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (j * 64 + lane) * 2;
+    if (c < Dp) {
+      unsigned h[4], m[4], l[4];                            // [column e][row pair]
+#pragma unroll
+      for (int e = 0; e < 2; ++e) {
+        ofb_split_pair(v[0][2 * j + e], v[1][2 * j + e], h[2 * e], m[2 * e], l[2 * e]);
+        ofb_split_pair(v[2][2 * j + e], v[3][2 * j + e], h[2 * e + 1], m[2 * e + 1], l[2 * e + 1]);
+      }
+      char* slot = P + ((size_t)rg * ncb + (c >> 4)) * OFB_PGRAN + (c & 15) * 8;
+      *reinterpret_cast<uint4*>(slot) = make_uint4(h[0], h[1], h[2], h[3]);
+      *reinterpret_cast<uint4*>(slot + 128) = make_uint4(m[0], m[1], m[2], m[3]);
+      *reinterpret_cast<uint4*>(slot + 256) = make_uint4(l[0], l[1], l[2], l[3]);
+    }
+  }
+}
+template <int NJ>
+__device__ __forceinline__ void ln_p_load(float (&v)[2 * NJ], const float* __restrict__ p, int D, int lane) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (j * 64 + lane) * 2;
+    float2 t = make_float2(0.f, 0.f);
+    if (c < D) t = *reinterpret_cast<const float2*>(p + c);
+    v[2 * j] = t.x; v[2 * j + 1] = t.y;
+  }
+}
+
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_fwd_p_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ y, char* __restrict__ yP,
+                                                       float* __restrict__ mean, float* __restrict__ rstd, int rows, int D, float eps) {
+  constexpr int NE = 2 * NJ;
+  const int lane = threadIdx.x & 63, rg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (4 * rg >= rows) return;
+  float g[NE], b[NE], v[4][NE];
+  ln_p_load<NJ>(g, gamma, D, lane);
+  ln_p_load<NJ>(b, beta, D, lane);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * rg + r;
+    if (row < rows) ln_p_load<NJ>(v[r], x + (size_t)row * D, D, lane);
+    else {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[r][i] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * rg + r;
+    if (row >= rows) continue;                             // padding rows of the last row group stay zero
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) s += v[r][i];
+    const float mu = ofb_wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int c = ((i >> 1) * 64 + lane) * 2 + (i & 1);
+      const float d = (c < D) ? v[r][i] - mu : 0.f;
+      q += d * d;
+    }
+    const float rs = 1.0f / sqrtf(ofb_wave_sum(q) / (float)D + eps);
+#pragma unroll
+    for (int i = 0; i < NE; ++i) v[r][i] = (v[r][i] - mu) * rs * g[i] + b[i];     // columns >= D: g = b = 0 -> 0
+    if (y) {
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = (j * 64 + lane) * 2;
+        if (c < D) *reinterpret_cast<float2*>(y + (size_t)row * D + c) = make_float2(v[r][2 * j], v[r][2 * j + 1]);
+      }
+    }
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+  }
+  const int Dp = (D + 15) & ~15;
+  ln_p_store<NJ>(yP, Dp >> 4, rg, lane, Dp, v);
+}
+
+template <int NJ>
+__global__ __launch_bounds__(256) void ln_bwd_p_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                       const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                       float* __restrict__ dx, float* __restrict__ part, int rows, int D,
+                                                       char* __restrict__ dxP, const float* __restrict__ rowscale, int rs_div) {
+  constexpr int NE = 2 * NJ;
+  __shared__ float red[4 * 3 * 128 * NJ];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int Dp = (D + 15) & ~15;
+  float g[NE], ag[NE], ab[NE], ac[NE];
+  ln_p_load<NJ>(g, gamma, D, lane);
+#pragma unroll
+  for (int i = 0; i < NE; ++i) ag[i] = ab[i] = ac[i] = 0.f;
+  for (int rg = blockIdx.x * 4 + w; 4 * rg < rows; rg += gridDim.x * 4) {
+    float o[4][NE];                                        // dx * rowscale of the group's rows
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 4 * rg + r;
+      if (row >= rows) {
+#pragma unroll
+        for (int i = 0; i < NE; ++i) o[r][i] = 0.f;
+        continue;
+      }
+      float v[NE], d[NE];
+      ln_p_load<NJ>(v, x + (size_t)row * D, D, lane);
+      ln_p_load<NJ>(d, dy + (size_t)row * D, D, lane);
+      const float mu = mean[row], rs = rstd[row];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) {
+        const int c = ((i >> 1) * 64 + lane) * 2 + (i & 1);
+        const float xh = (c < D) ? (v[i] - mu) * rs : 0.f;
+        const float dg = d[i] * g[i];
+        ag[i] += d[i] * xh;
+        ab[i] += d[i];
+        s1 += dg;
+        s2 += dg * xh;
+        v[i] = xh;
+        d[i] = dg;
+      }
+      const float c1 = ofb_wave_sum(s1) / (float)D, c2 = ofb_wave_sum(s2) / (float)D;
+#pragma unroll
+      for (int i = 0; i < NE; ++i) v[i] = rs * (d[i] - c1 - v[i] * c2);
+      if (dres) {
+        float rr[NE];
+        ln_p_load<NJ>(rr, dres + (size_t)row * D, D, lane);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) v[i] += rr[i];
+      }
+      const float sc = rowscale ? rowscale[rs_div == 1 ? row : row / rs_div] : 1.f;
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) {
+        const int c = (j * 64 + lane) * 2;
+        if (c < D) *reinterpret_cast<float2*>(dx + (size_t)row * D + c) = make_float2(v[2 * j], v[2 * j + 1]);
+        o[r][2 * j] = (c < D) ? v[2 * j] * sc : 0.f;
+        o[r][2 * j + 1] = (c < D) ? v[2 * j + 1] * sc : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NE; ++i) ac[i] += (o[0][i] + o[1][i]) + (o[2][i] + o[3][i]);
+    ln_p_store<NJ>(dxP, Dp >> 4, rg, lane, Dp, o);
+  }
+  // cross-wave reduction of the per-lane column partials: dgamma | dbeta | column sums of the scaled rows
+  constexpr int SEC = 128 * NJ;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    const int c = ((i >> 1) * 64 + lane) * 2 + (i & 1);
+    red[(w * 3 + 0) * SEC + c] = ag[i]; red[(w * 3 + 1) * SEC + c] = ab[i]; red[(w * 3 + 2) * SEC + c] = ac[i];
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < D; c += 256) {
+#pragma unroll
+    for (int sct = 0; sct < 3; ++sct) {
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) sum += red[(k * 3 + sct) * SEC + c];
+      part[(size_t)blockIdx.x * 3 * D + sct * D + c] = sum;
+    }
   }
 }
 
@@ -184,32 +410,85 @@ __global__ __launch_bounds__(256) void gate_fold_bwd_kernel(const float* __restr
 
 }  // namespace
 
+namespace {
+int ln_fwd_launch(const float* x, const float* gamma, const float* beta, float* y, char* yP, float* mean, float* rstd, int rows, int D,
+                  float eps, hipStream_t s) {
+  const dim3 grid(ofb_cdiv(rows, 4));
+  ofb_prof_pre(2, s, (yP ? 14.0 : 8.0) * rows * (double)D);
+  if (yP && D % 2 == 0) {
+    const dim3 gp(ofb_cdiv(rows, 16));
+    const int nj = ofb_cdiv(D, 128);
+    if (nj <= 2) hipLaunchKernelGGL(ln_fwd_p_kernel<2>, gp, dim3(256), 0, s, x, gamma, beta, y, yP, mean, rstd, rows, D, eps);
+    else if (nj <= 3) hipLaunchKernelGGL(ln_fwd_p_kernel<3>, gp, dim3(256), 0, s, x, gamma, beta, y, yP, mean, rstd, rows, D, eps);
+    else if (nj <= 6) hipLaunchKernelGGL(ln_fwd_p_kernel<6>, gp, dim3(256), 0, s, x, gamma, beta, y, yP, mean, rstd, rows, D, eps);
+    else hipLaunchKernelGGL(ln_fwd_p_kernel<8>, gp, dim3(256), 0, s, x, gamma, beta, y, yP, mean, rstd, rows, D, eps);
+  } else if (yP) {
+    hipLaunchKernelGGL((ln_fwd_kernel<1, true>), grid, dim3(256), 0, s, x, gamma, beta, y, yP, mean, rstd, rows, D, eps);
+  } else {
+    if (D % 2 == 0) hipLaunchKernelGGL((ln_fwd_kernel<2, false>), grid, dim3(256), 0, s, x, gamma, beta, y, yP, mean, rstd, rows, D, eps);
+    else hipLaunchKernelGGL((ln_fwd_kernel<1, false>), grid, dim3(256), 0, s, x, gamma, beta, y, yP, mean, rstd, rows, D, eps);
+  }
+  ofb_prof_post(2, s);
+  return ofb_launch_status();
+}
+}  // namespace
+
 extern "C" int ofb_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                                  int32_t rows, int32_t D, float eps, void* stream) {
   if (!x || !gamma || !beta || !y || !mean || !rstd || rows <= 0 || D <= 0) return OFB_EINVAL;
   if (D > 64 * LN_MAXE) return OFB_ELIMIT;
-  const dim3 grid(ofb_cdiv(rows, 4));
-  hipStream_t s = (hipStream_t)stream;
-  ofb_prof_pre(2, s, 8.0 * rows * (double)D);
-  if (D % 2 == 0) hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, D, eps);
-  else hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, dim3(256), 0, s, x, gamma, beta, y, mean, rstd, rows, D, eps);
-  ofb_prof_post(2, s);
-  return ofb_launch_status();
+  return ln_fwd_launch(x, gamma, beta, y, nullptr, mean, rstd, rows, D, eps, (hipStream_t)stream);
+}
+
+// y (optional) and the same rows as P-format planes y_p[rows][D] (ofb_pformat_bytes(rows, D) bytes).  Row groups 0 .. ceil(rows / 4) - 1
+// are written whole (padding rows and columns as zeros); the caller zeroes what is left of the last 16-row group (rows % 16 in 1..12).
+extern "C" int ofb_layernorm_fwd_p(const float* x, const float* gamma, const float* beta, float* y, void* y_p, float* mean,
+                                   float* rstd, int32_t rows, int32_t D, float eps, void* stream) {
+  if (!x || !gamma || !beta || !y_p || !mean || !rstd || rows <= 0 || D <= 0) return OFB_EINVAL;
+  if (D > 64 * LN_MAXE) return OFB_ELIMIT;
+  return ln_fwd_launch(x, gamma, beta, y, (char*)y_p, mean, rstd, rows, D, eps, (hipStream_t)stream);
 }
 
 extern "C" int32_t ofb_layernorm_bwd_blocks(int32_t rows) { return rows >= 4096 ? 1024 : ofb_cdiv(rows, 4); }
+
+namespace {
+int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
+                  float* partials, int rows, int D, char* dxP, const float* rowscale, int rs_div, hipStream_t s) {
+  const dim3 grid(ofb_layernorm_bwd_blocks(rows));
+  ofb_prof_pre(3, s, (dxP ? 22.0 : 16.0) * rows * (double)D);
+  if (dxP && D % 2 == 0) {
+    const int nj = ofb_cdiv(D, 128);
+    if (nj <= 2) hipLaunchKernelGGL(ln_bwd_p_kernel<2>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
+    else if (nj <= 3) hipLaunchKernelGGL(ln_bwd_p_kernel<3>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
+    else if (nj <= 6) hipLaunchKernelGGL(ln_bwd_p_kernel<6>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
+    else hipLaunchKernelGGL(ln_bwd_p_kernel<8>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
+  } else if (dxP) {
+    hipLaunchKernelGGL((ln_bwd_kernel<1, true>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
+  } else {
+    if (D % 2 == 0) hipLaunchKernelGGL((ln_bwd_kernel<2, false>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
+    else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
+  }
+  ofb_prof_post(3, s);
+  return ofb_launch_status();
+}
+}  // namespace
 
 extern "C" int ofb_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                  const float* dres, float* dx, float* partials, int32_t rows, int32_t D, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !partials || rows <= 0 || D <= 0) return OFB_EINVAL;
   if (D > 64 * LN_MAXE) return OFB_ELIMIT;
-  const dim3 grid(ofb_layernorm_bwd_blocks(rows));
-  hipStream_t s = (hipStream_t)stream;
-  ofb_prof_pre(3, s, 16.0 * rows * (double)D);
-  if (D % 2 == 0) hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D);
-  else hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D);
-  ofb_prof_post(3, s);
-  return ofb_launch_status();
+  return ln_bwd_launch(dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, nullptr, nullptr, 1, (hipStream_t)stream);
+}
+
+// Same, and dx * rowscale[row / rs_div] (rowscale optional) also as P-format planes dx_p[rows][D]; partials is then
+// [ofb_layernorm_bwd_blocks(rows)][3][D]: dgamma | dbeta | column sums of the scaled dx rows.
+extern "C" int ofb_layernorm_bwd_p(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                   const float* dres, float* dx, float* partials, void* dx_p, const float* rowscale, int32_t rs_div,
+                                   int32_t rows, int32_t D, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !partials || !dx_p || rows <= 0 || D <= 0) return OFB_EINVAL;
+  if (rowscale && rs_div <= 0) return OFB_EINVAL;
+  if (D > 64 * LN_MAXE) return OFB_ELIMIT;
+  return ln_bwd_launch(dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, (char*)dx_p, rowscale, rs_div, (hipStream_t)stream);
 }
 
 extern "C" int32_t ofb_colsum_slabs(int32_t M, int32_t N) {

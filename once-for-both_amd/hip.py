@@ -41,7 +41,7 @@ ENGINE = os.environ.get('OFB_GEMM_ENGINE', 'p')
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
     'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
-    'ofb_layernorm_fwd', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_colsum_slabs', 'ofb_colsum',
+    'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets',
@@ -328,6 +328,18 @@ def _f(v):
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps):
     check(lib().ofb_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), _i(rows), _i(D), _f(eps),
                                   stream()), 'ofb_layernorm_fwd')
+
+
+def layernorm_fwd_p(x, gamma, beta, y, yP, mean, rstd, rows, D, eps):
+    """LayerNorm rows as f32 `y` (may be None) and as P-format planes `yP` (PMat [rows][D]) from one pass."""
+    check(lib().ofb_layernorm_fwd_p(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(yP.buf), ptr(mean), ptr(rstd), _i(rows), _i(D),
+                                    _f(eps), stream()), 'ofb_layernorm_fwd_p')
+
+
+def layernorm_bwd_p(dy, x, gamma, mean, rstd, dres, dx, partials, dxP, rowscale, rs_div, rows, D):
+    """LayerNorm backward that also writes dx * rowscale[row // rs_div] as planes `dxP`; partials: [blocks][3][D]."""
+    check(lib().ofb_layernorm_bwd_p(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(partials),
+                                    ptr(dxP.buf), ptr(rowscale), _i(rs_div), _i(rows), _i(D), stream()), 'ofb_layernorm_bwd_p')
 
 
 def layernorm_bwd_blocks(rows):

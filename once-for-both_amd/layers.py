@@ -364,8 +364,8 @@ class Attention(nn.Module):
             raise NotImplementedError('attention/projection dropout is 0 on the OFB path')
 
     def _branch(self, x, resid, gate, rowscale, heads):
-        return ops.AttnBranch.apply(x, resid, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, gate, rowscale,
-                                    heads, float(self.scale))
+        return ops.attn_branch(x, resid, self.qkv.weight, self.qkv.bias, self.proj.weight, self.proj.bias, gate, rowscale,
+                               heads, float(self.scale))
 
     def forward(self, x):
         zero = torch.zeros_like(x)
@@ -536,7 +536,7 @@ class Mlp(nn.Module):
             raise NotImplementedError('MLP dropout is 0 on the OFB path')
 
     def _branch(self, x, resid, gate, rowscale):
-        return ops.MlpBranch.apply(x, resid, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, gate, rowscale)
+        return ops.mlp_branch(x, resid, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, gate, rowscale)
 
     def forward(self, x):
         return self._branch(x, torch.zeros_like(x), None, None)

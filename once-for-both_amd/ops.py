@@ -224,19 +224,54 @@ class Linear(torch.autograd.Function):
         return dx, dW, db
 
 
+# Hand-overs around LayerNorm on the P-format path (no extra kernels, no extra passes over the activations):
+#  * forward: the LN kernel writes its rows as planes too; the wrapper below hangs them on the output tensor (`_ofb_p`), where the
+#    branch that consumes it (AttnBranch / MlpBranch -> _P) finds them instead of converting.
+#  * backward: the gradient LN returns is the dY of the branch that produced LN's input.  That branch tags its output with its
+#    DropPath row scales (`_ofb_up`, see attn_branch / mlp_branch); LN's backward kernel then also writes dx * rowscale as planes
+#    and its column sums (the branch's output-bias gradient), parked in _grad_p under the gradient tensor's identity, where the
+#    branch's backward picks them up (_take_grad_p) instead of running ofb_to_pformat_colsum over the gradient.
+_ln_pending = [None]
+_grad_p = {}
+
+
+def _put_grad_p(dx, dxP, colsum, rowscale):
+    if len(_grad_p) >= 4:                                    # entries are taken within the same backward pass; drop leftovers
+        _grad_p.clear()
+    _grad_p[dx.data_ptr()] = (dx, dx._version, dxP, colsum, 0 if rowscale is None else rowscale.data_ptr())
+
+
+def _take_grad_p(d2, rowscale, M, D):
+    """(PMat of d2 * rowscale, its column sums) if LayerNorm's backward already produced them for exactly this tensor"""
+    e = _grad_p.pop(d2.data_ptr(), None)
+    if e is None:
+        return None
+    dx, ver, dxP, colsum, rs_ptr = e
+    if dx._version != ver or dx.numel() != M * D or dxP.R != M or dxP.C != D or rs_ptr != (0 if rowscale is None else rowscale.data_ptr()):
+        return None
+    return dxP, colsum
+
+
 class LayerNorm(torch.autograd.Function):
     """layers.py:96-98 (F.layer_norm, eps inside the sqrt).  Optional `dres` fork: the op also returns its input
-    unchanged so that the residual stream's gradient is added inside the backward kernel."""
+    unchanged so that the residual stream's gradient is added inside the backward kernel.  `up`: None, or the 1-tuple
+    (rowscale or None) of the branch whose output this LayerNorm reads (see the hand-over note above)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, fork):
+    def forward(ctx, x, gamma, beta, eps, fork, up):
         x = _c(x)
         D = x.shape[-1]
         rows = x.numel() // D
         y, mean, rstd = torch.empty_like(x), _new(x, rows), _new(x, rows)
-        hip.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps)
+        if _use_p() and x.is_cuda:
+            yP = hip.PMat.for_rows_written_by_kernel(rows, D, x.device)
+            hip.layernorm_fwd_p(x, gamma, beta, y, yP, mean, rstd, rows, D, eps)
+            _ln_pending[0] = yP
+        else:
+            hip.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps)
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.fork = fork
+        ctx.up = up
         if fork:
             return y, x.view_as(x)
         return y
@@ -247,21 +282,40 @@ class LayerNorm(torch.autograd.Function):
         D = x.shape[-1]
         rows = x.numel() // D
         nb = hip.layernorm_bwd_blocks(rows)
-        part = _new(x, nb, 2 * D)
         dx = torch.empty_like(x)
+        if ctx.up is not None and _use_p():
+            rowscale = ctx.up[0]
+            part = _new(x, nb, 3 * D)
+            dxP = hip.PMat.for_rows_written_by_kernel(rows, D, x.device)
+            hip.layernorm_bwd_p(_c(dy), x, gamma, mean, rstd, _c(dres) if dres is not None else None, dx, part, dxP, rowscale,
+                                _rs_div(rowscale, rows), rows, D)
+            dgb = _new(x, 3 * D)
+            hip.colsum(part, 3 * D, nb, 3 * D, dgb)
+            _put_grad_p(dx, dxP, dgb[2 * D:], rowscale)
+            return dx, dgb[:D], dgb[D:2 * D], None, None, None
+        part = _new(x, nb, 2 * D)
         hip.layernorm_bwd(_c(dy), x, gamma, mean, rstd, _c(dres) if dres is not None else None, dx, part, rows, D)
         dgb = _new(x, 2 * D)
         hip.colsum(part, 2 * D, nb, 2 * D, dgb)
-        return dx, dgb[:D], dgb[D:], None, None
+        return dx, dgb[:D], dgb[D:], None, None, None
+
+
+def _ln_apply(x, gamma, beta, eps, fork):
+    _ln_pending[0] = None
+    out = LayerNorm.apply(x, gamma, beta, eps, fork, getattr(x, '_ofb_up', None))
+    yP, _ln_pending[0] = _ln_pending[0], None
+    if yP is not None:
+        (out[0] if fork else out)._ofb_p = yP
+    return out
 
 
 def layer_norm(x, gamma, beta, eps):
-    return LayerNorm.apply(x, gamma, beta, eps, False)
+    return _ln_apply(x, gamma, beta, eps, False)
 
 
 def layer_norm_fork(x, gamma, beta, eps):
     """returns (LN(x), x): use the second output as the residual input of the following branch."""
-    return LayerNorm.apply(x, gamma, beta, eps, True)
+    return _ln_apply(x, gamma, beta, eps, True)
 
 
 class AttnBranch(torch.autograd.Function):
@@ -329,8 +383,12 @@ def _attn_backward_p(ctx, dout):
     xP, oP = _pm(xbuf, M, D), _pm(obuf, M, Hd)
     d2 = _c(dout).view(M, D)
     # gradient of the branch output: DropPath factor applied, planes written and the projection's bias gradient summed in ONE pass
-    dbp = _new(d2, D) if has_pb else None
-    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=dbp)
+    hit = _take_grad_p(d2, rowscale, M, D)
+    if hit is not None:
+        d2sP, dbp = hit[0], (hit[1] if has_pb else None)
+    else:
+        dbp = _new(d2, D) if has_pb else None
+        d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=dbp)
     wqP, wpP = ctx.wp
     do, _ = p_linear_bwd_input(d2sP, M, D, wpP, Hd)
     dwp = grad_slot(wproj)
@@ -412,8 +470,12 @@ def _mlp_backward_p(ctx, dout):
     M, hid = B * N, w1.shape[0]
     xP, hP = _pm(xbuf, M, D), _pm(hbuf, M, hid)
     d2 = _c(dout).view(M, D)
-    db2 = _new(d2, D) if has_b2 else None
-    d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=db2)
+    hit = _take_grad_p(d2, rowscale, M, D)
+    if hit is not None:
+        d2sP, db2 = hit[0], (hit[1] if has_b2 else None)
+    else:
+        db2 = _new(d2, D) if has_b2 else None
+        d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=db2)
     # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> P-format only
     w1P, w2P = ctx.wp
     # the fc1 bias gradient (column sums of this P-format-only result) rides on the epilogue
@@ -430,6 +492,18 @@ def _mlp_backward_p(ctx, dout):
 
 
 MlpBranch._backward_p = staticmethod(_mlp_backward_p)
+
+
+def attn_branch(x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale):
+    out = AttnBranch.apply(x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale)
+    out._ofb_up = (rowscale,)                                # for the LayerNorm that reads this output (see LayerNorm)
+    return out
+
+
+def mlp_branch(x, resid, w1, b1, w2, b2, g, rowscale):
+    out = MlpBranch.apply(x, resid, w1, b1, w2, b2, g, rowscale)
+    out._ofb_up = (rowscale,)
+    return out
 
 
 class PatchEmbedTokens(torch.autograd.Function):

@@ -45,6 +45,54 @@ def test_layernorm_fwd_bwd(rows, D):
     _close(dx, xd.grad, 5e-6, 'ln dx')
 
 
+@pytest.mark.parametrize('rows,D', [(394, 384), (197 * 8, 192), (33, 102), (200, 768), (7, 1024), (5000, 384), (20, 77), (64, 96)])
+def test_layernorm_pformat_outputs(rows, D):
+    """the P-format variants (planes written by the LayerNorm kernels themselves): same f32 rows as the plain kernels (up to the
+    compiler's fma contraction), planes == the kernel's own f32 rows (x the DropPath row scale in backward) exactly, third partial
+    section = their column sums"""
+    from ofb_amd import hip
+    x, g, b = (_mk((rows, D), 1) * 2 + 0.3).cuda(), (_mk((D,), 2) * 0.2 + 1).cuda(), (_mk((D,), 3) * 0.1).cuda()
+    dy, dres = _mk((rows, D), 4).cuda(), _mk((rows, D), 5).cuda()
+    y0, y1 = torch.empty(rows, D, device='cuda'), torch.empty(rows, D, device='cuda')
+    m0, r0, m1, r1 = (torch.empty(rows, device='cuda') for _ in range(4))
+    hip.layernorm_fwd(x, g, b, y0, m0, r0, rows, D, 1e-6)
+    yP = hip.PMat.for_rows_written_by_kernel(rows, D, 'cuda')
+    hip.layernorm_fwd_p(x, g, b, y1, yP, m1, r1, rows, D, 1e-6)
+    _close(y1, y0.cpu(), 1e-6, 'ln fwd rows of the P variant')
+    _close(m1, m0.cpu(), 1e-6, 'mean')
+    _close(r1, r0.cpu(), 1e-6, 'rstd')
+    assert torch.equal(yP.to_f32(), y1)
+    y0 = y1
+    # as a GEMM operand (reduction along the columns and along the rows): padding rows / columns must be zero
+    w = _mk((48, D), 8).cuda()
+    out = torch.empty(rows, 48, device='cuda')
+    hip.gemm_p(yP, hip.to_pformat(w), 1, 1, rows, 48, D, C_out=out, ldc=48)
+    _close(out, y0.double().cpu() @ w.double().cpu().t(), 2e-6, 'LN planes as GEMM operand (K along columns)')
+    out2 = torch.empty(D, 48, device='cuda')
+    z = _mk((rows, 48), 9).cuda()
+    hip.gemm_p(yP, hip.to_pformat(z), 0, 0, D, 48, rows, C_out=out2, ldc=48)
+    _close(out2, y0.double().cpu().t() @ z.double().cpu(), 2e-6, 'LN planes as GEMM operand (K along rows)')
+
+    nb = hip.layernorm_bwd_blocks(rows)
+    for rs_div, use_res in ((1, True), (rows if rows % 197 else 197, False), (0, True)):
+        rowscale = None if rs_div == 0 else (torch.rand((rows + rs_div - 1) // rs_div, device='cuda') + 0.5)
+        dr = dres if use_res else None
+        part2, dx0 = torch.empty(nb, 2, D, device='cuda'), torch.empty(rows, D, device='cuda')
+        hip.layernorm_bwd(dy, x, g, m0, r0, dr, dx0, part2, rows, D)
+        part3, dx1 = torch.empty(nb, 3, D, device='cuda'), torch.empty(rows, D, device='cuda')
+        dxP = hip.PMat.for_rows_written_by_kernel(rows, D, 'cuda')
+        hip.layernorm_bwd_p(dy, x, g, m0, r0, dr, dx1, part3, dxP, rowscale, max(rs_div, 1), rows, D)
+        _close(dx1, dx0.cpu(), 2e-6, 'ln dx of the P variant')
+        sc = torch.ones(rows, device='cuda') if rowscale is None else rowscale[torch.arange(rows, device='cuda') // rs_div]
+        scaled = dx1 * sc.unsqueeze(1)
+        assert torch.equal(dxP.to_f32(), scaled)
+        s2, s3 = torch.empty(2 * D, device='cuda'), torch.empty(3 * D, device='cuda')
+        hip.colsum(part2, 2 * D, nb, 2 * D, s2)
+        hip.colsum(part3, 3 * D, nb, 3 * D, s3)
+        _close(s3[:2 * D], s2.cpu(), 2e-6, 'dgamma | dbeta of the P variant')
+        _close(s3[2 * D:], scaled.double().sum(0).cpu(), 1e-5, 'column sums of the scaled dx rows')
+
+
 @pytest.mark.parametrize('M,N', [(25216, 1152), (1576, 384), (130, 70), (3, 5), (128, 1000)])
 def test_colsum(M, N):
     from ofb_amd import hip
