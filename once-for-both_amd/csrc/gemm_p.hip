@@ -15,11 +15,16 @@
 // and a 32x32 accumulator block (lane = column, 4 consecutive rows per register group) stores P-format with 8-byte stores that
 // fill whole 128-B lines, so a GEMM epilogue can feed the next GEMM directly.
 //
-// Kernel: 256x256 tile, 8 waves (2 x 4), wave tile 128x64 = 4x2 blocks of v_mfma_f32_32x32x16_bf16, K step 16 (48 MFMAs per
-// wave), three 48-KB LDS stages filled by global_load_lds_dwordx4 three steps ahead (inline asm: through the builtin hipcc
-// drains every LDS-DMA with vmcnt(0) before the next ds_read), one barrier per K step placed BETWEEN the two halves of the step
-// with the fragment reads of the next half-step issued in the MFMA gaps of the current one.  Scheduling is the hybrid stream-K
-// of gemm_plan.h (data-parallel rounds + K-split tail + deterministic fix-up).
+// Kernel (product configuration C128): 128 x 192 tile, 4 waves (2 x 2), wave tile 64 x 96 = 2 x 3 blocks of
+// v_mfma_f32_32x32x16_bf16, K step 16 (36 MFMAs per wave), TWO workgroups per CU, two 30-KB LDS stages filled by
+// global_load_lds_dwordx4 two steps ahead (inline asm: through the builtin hipcc drains every LDS-DMA with vmcnt(0) before the next
+// ds_read), one barrier per K step placed BETWEEN the two halves of the step with the fragment reads of the next half-step issued
+// in the MFMA gaps of the current one; epilogue through LDS with compile-time forms.  Scheduling is the hybrid stream-K of
+// gemm_plan.h (data-parallel rounds + K-split tail + deterministic fix-up).
+// Measured alternatives (same-box A/B, scripts/lab/ab_gemm_p.sh): 256 x 192 / 8 waves / 3 stages (C192, lab builds) is not faster
+// on any product of the step; v_mfma_f32_16x16x32_bf16 fragments carrying two planes each (scripts/lab/gemm_p_mfma16_paired.hip.txt)
+// hold a higher clock but need 24 KB instead of 15 KB of fragment reads per wave and step: equal step time; s_setprio around the
+// MFMA bursts and a half-unit start stagger of a CU's two workgroups: no gain.
 #include "ofb_common.h"
 #include "gemm_plan.h"
 #include <cstdlib>
@@ -299,29 +304,9 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
   // six product terms, smallest first: (mid,mid) (hi,lo) (lo,hi) (hi,mid) (mid,hi) (hi,hi)
   constexpr int TA[6] = {1, 0, 2, 0, 1, 0}, TB[6] = {1, 2, 0, 1, 0, 0};
   constexpr int NMF = 6 * HA * NI, RD2 = 6 * HA + 6 * NI;       // MFMAs per half step; fragment reads riding in the second half
-#ifndef OFB_P_PRIO_HI
-#define OFB_P_PRIO_HI 1
-#endif
-#ifdef OFB_P_PRIO
-#define OFB_PRIO(x) __builtin_amdgcn_s_setprio(x)
-#else
-#define OFB_PRIO(x) do { } while (0)
-#endif
-#ifdef OFB_P_SHAPE16_TIMING
-  // lab, WRONG RESULTS: same operand traffic and matrix-pipe cycles on the 16x16x32 shape (clock the chip holds under this shape)
-#define OFB_MMA_HALF(AF, BF, BLK0)                                                                                                   \
-  _Pragma("unroll") for (int q = 0; q < 6; ++q) _Pragma("unroll") for (int i = 0; i < HA; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) { \
-      f32x4 lo_ = {acc[BLK0 + i][j][0], acc[BLK0 + i][j][1], acc[BLK0 + i][j][2], acc[BLK0 + i][j][3]};                                 \
-      f32x4 hi_ = {acc[BLK0 + i][j][4], acc[BLK0 + i][j][5], acc[BLK0 + i][j][6], acc[BLK0 + i][j][7]};                                 \
-      lo_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][TA[q]], BF[j][TB[q]], lo_, 0, 0, 0);                                        \
-      hi_ = __builtin_amdgcn_mfma_f32_16x16x32_bf16(AF[i][TB[q]], BF[j][TA[q]], hi_, 0, 0, 0);                                        \
-      acc[BLK0 + i][j][0] = lo_[0]; acc[BLK0 + i][j][1] = lo_[1]; acc[BLK0 + i][j][2] = lo_[2]; acc[BLK0 + i][j][3] = lo_[3];          \
-      acc[BLK0 + i][j][4] = hi_[0]; acc[BLK0 + i][j][5] = hi_[1]; acc[BLK0 + i][j][6] = hi_[2]; acc[BLK0 + i][j][7] = hi_[3]; }
-#else
 #define OFB_MMA_HALF(AF, BF, BLK0)                                                                                                   \
   _Pragma("unroll") for (int q = 0; q < 6; ++q) _Pragma("unroll") for (int i = 0; i < HA; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
       acc[BLK0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AF[i][TA[q]], BF[j][TB[q]], acc[BLK0 + i][j], 0, 0, 0);
-#endif
 #define OFB_INTERLEAVE(NM, ND)                                                               \
   _Pragma("unroll") for (int z_ = 0; z_ < (NM); ++z_) {                                      \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
@@ -370,12 +355,10 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
       const int nbuf = buf + 1 == NST ? 0 : buf + 1;
       // first half: lower row blocks x B(i); the reads of the upper row blocks ride in the MFMA gaps
       __builtin_amdgcn_sched_barrier(0);
-      OFB_PRIO(OFB_P_PRIO_HI);
       rdA(ahi, buf, HA);
       OFB_MMA_HALF(alo, bb[par], 0)
       OFB_INTERLEAVE(NMF, 1)
       __builtin_amdgcn_sched_barrier(0);
-      OFB_PRIO(0);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                     // this wave is done reading buf(i)
       {                                                                      // own pieces of stage i+1 landed; later stages may fly
         int young = nk - i - 2;
@@ -387,14 +370,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
       // second half: upper row blocks x B(i); the reads of step i+1 (lower row blocks and B) ride in the gaps (after the last
       // step they fetch a stale buffer that nothing consumes)
       __builtin_amdgcn_sched_barrier(0);
-      OFB_PRIO(OFB_P_PRIO_HI);
       rdA(alo, nbuf, 0);
       rdB(bb[par ^ 1], nbuf);
       OFB_MMA_HALF(ahi, bb[par], HA)
       OFB_INTERLEAVE(RD2 > NMF ? RD2 - NMF : 0, 2)
       OFB_INTERLEAVE(RD2 > NMF ? 2 * NMF - RD2 : NMF, 1)
       __builtin_amdgcn_sched_barrier(0);
-      OFB_PRIO(0);
     };
     int buf = 0, i = 0;
     for (; i + 1 < nk; i += 2) {
