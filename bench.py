@@ -207,6 +207,7 @@ def main():
                     help="search: the BASELINE metric (default); finetune: configs[4], a pruned OFB-DeiT-C-like subnet (not a bench line)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip per-kernel HIP-event timing')
+    ap.add_argument('--prof-all', action='store_true', help='bracket every tagged kernel family in the sampled steps (default: the GEMM only)')
     ap.add_argument('--force-dp', action='store_true', help='exercise the DP bucket path even with one rank (debug)')
     args = ap.parse_args()
 
@@ -312,14 +313,14 @@ def main():
     # per-launch HIP events (on the launch stream) bracket the kernels of the LAST `prof_steps` timed steps only: each
     # bracket costs a few microseconds of inter-kernel bubble, so sampling keeps `value` honest while still measuring
     # inside the timed region
-    prof_steps = 0 if args.no_prof else min(3, args.steps)
+    prof_steps = 0 if args.no_prof else min(2, args.steps)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
         if prof_steps and i == args.steps - prof_steps:
             # the sampled steps run with the side stream off: per-launch durations of kernels that overlap on two streams are not
             # attributable to one kernel (each stretches while the other shares the chip); `value` includes these slower steps
-            hip.prof_enable(True)
+            hip.prof_enable(True if args.prof_all else 1)     # bit 0: the GEMM (the roofline kernel); --prof-all: every tagged kernel
             side_was, hip.SIDE_STREAM = hip.SIDE_STREAM, False
         out = step()
     if prof_steps:

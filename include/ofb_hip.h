@@ -126,7 +126,7 @@ int ofb_splitk_reduce(const float* workspace, int32_t splits, int64_t count, flo
  * Tags: 0 gemm, 1 attention fwd, 2 layernorm fwd, 3 layernorm bwd, 4 attention bwd.
  * ofb_prof_collect synchronises the recorded events and fills out[tag*3 + {0 launches, 1 ms, 2 work}].
  * ------------------------------------------------------------------------------------------- */
-int ofb_prof_enable(int32_t on);
+int ofb_prof_enable(int32_t on);   /* on: bit t set -> bracket the launches of tag t; 0: off */
 int ofb_prof_collect(double* out, int32_t ntags);
 /* diagnostic: `blocks` workgroups x 4 waves each issue 4*iters back-to-back f32 MFMAs (measures the sustained roof) */
 int ofb_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, void* stream);

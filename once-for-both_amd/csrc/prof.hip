@@ -5,7 +5,7 @@
 
 namespace {
 struct Rec { hipEvent_t a, b; int tag; double work; };
-bool g_on = false;
+unsigned g_on = 0;       // bit t: bracket the launches of tag t
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
 hipEvent_t get_event() {
@@ -18,19 +18,20 @@ hipEvent_t get_event() {
 }  // namespace
 
 void ofb_prof_pre(int tag, hipStream_t s, double work) {
-  if (!g_on) return;
+  if (!((g_on >> tag) & 1u)) return;
   Rec r; r.a = get_event(); r.b = get_event(); r.tag = tag; r.work = work;
   (void)hipEventRecord(r.a, s);
   g_recs.push_back(r);
 }
 void ofb_prof_post(int tag, hipStream_t s) {
-  if (!g_on) return;
-  (void)tag;
+  if (!((g_on >> tag) & 1u)) return;
   (void)hipEventRecord(g_recs.back().b, s);
 }
 
+// on: bit t set -> launches of tag t are bracketed (0: off; each bracket costs an inter-kernel bubble, so the bench samples
+// only the tags it reports)
 extern "C" int ofb_prof_enable(int32_t on) {
-  g_on = on != 0;
+  g_on = (unsigned)on;
   return OFB_OK;
 }
 

@@ -308,7 +308,9 @@ def splitk_reduce(ws, splits, count, out, accumulate=False):
 
 
 def prof_enable(on):
-    check(lib().ofb_prof_enable(C.c_int32(int(on))), 'ofb_prof_enable')
+    """on: False / 0 = off; True = every tag; an int = bit mask of the tags to bracket (bit 0: the GEMM)"""
+    mask = 0x7fffffff if on is True else int(on)
+    check(lib().ofb_prof_enable(C.c_int32(mask)), 'ofb_prof_enable')
 
 
 def prof_collect(ntags=8):
