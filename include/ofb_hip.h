@@ -27,6 +27,9 @@ extern "C" {
 #define OFB_ACT_NONE 0
 #define OFB_ACT_GELU 1      /* aux <- pre-activation (if aux), C <- gelu_erf(pre)            */
 #define OFB_ACT_DGELU 2     /* C <- value * gelu_erf'(aux[m][n])                              */
+/* ofb_gemm_p only: the forward saves the DERIVATIVE (it has Phi and phi in hand already), the backward epilogue is one multiply */
+#define OFB_ACT_GELU_GRAD 3 /* aux <- gelu_erf'(pre) (aux required), C <- gelu_erf(pre)       */
+#define OFB_ACT_MULAUX 4    /* C <- value * aux[m][n]                                         */
 
 /* ---------------------------------------------------------------------------------------------
  * Dense f32 contraction on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, six terms of an exact 3-way operand split, f32

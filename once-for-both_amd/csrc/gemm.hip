@@ -680,6 +680,7 @@ extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream) {
   if (g.a_kc == 0 && g.b_kc == 1) return OFB_ELIMIT;           // A^T * B^T is not on the path
   if (g.kscale && (g.a_kc != 0 || g.ks_div <= 0)) return OFB_EINVAL;
   if (g.rowscale && g.rs_div <= 0) return OFB_EINVAL;
+  if (g.act < OFB_ACT_NONE || g.act > OFB_ACT_DGELU) return OFB_EINVAL;   // the save-derivative forms exist in ofb_gemm_p only
   if (g.act == OFB_ACT_DGELU && !g.aux) return OFB_EINVAL;
   if (g.a_colsum && g.a_kc != 0) return OFB_EINVAL;
   // minimum leading dimensions for the declared storage

@@ -180,8 +180,15 @@ __device__ __forceinline__ float epi_value(const ofb_gemm_p_args& g, float accv,
   if (g.act == OFB_ACT_GELU) {
     if (g.aux && ok) g.aux[(size_t)row * g.ldaux + col] = v;
     v = ofb_gelu(v);
+  } else if (g.act == OFB_ACT_GELU_GRAD) {
+    float Phi, phi;
+    ofb_gelu_parts(v, Phi, phi);
+    if (ok) g.aux[(size_t)row * g.ldaux + col] = Phi + v * phi;
+    v *= Phi;
   } else if (g.act == OFB_ACT_DGELU) {
     v *= ofb_dgelu(ok ? g.aux[(size_t)row * g.ldaux + col] : 0.f);
+  } else if (g.act == OFB_ACT_MULAUX) {
+    v *= ok ? g.aux[(size_t)row * g.ldaux + col] : 0.f;
   }
   if (g.rowscale) v *= ok ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
   if (g.resid) v += ok ? g.resid[(size_t)row * g.ldr + col] : 0.f;
@@ -207,7 +214,7 @@ __device__ __forceinline__ void vm_wait(int n) {           // n is wave-uniform
 // Epilogue forms are compile-time (EPI = set of E_* bits): with run-time flags hipcc has to assume that a side-input load may
 // follow an aliasing store and puts s_waitcnt vmcnt(0) between the stores of every element (measured: a 128 x 192 tile took longer
 // to store than to compute).  Each instantiation is straight-line: all loads of a pass, then arithmetic, then stores.
-enum : int { E_C = 1, E_P = 2, E_GELU = 4, E_DGELU = 8, E_RS = 16, E_RES = 32, E_ANY = 64 };
+enum : int { E_C = 1, E_P = 2, E_GELU = 4, E_DGELU = 8, E_RS = 16, E_RES = 32, E_ANY = 64, E_GELUG = 128, E_MULAUX = 256 };
 
 template <class CF, bool A_KC, bool B_KC, bool TAIL, int EPI>
 __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args g, const Plan p) {
@@ -404,6 +411,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
       // which parts exist: known at compile time for the specialised forms, asked at run time by the generic form (E_ANY)
       const bool has_c = ANY ? g.C != nullptr : (EPI & E_C) != 0, has_p = ANY ? g.Cp != nullptr : (EPI & E_P) != 0;
       const bool gelu = ANY ? g.act == OFB_ACT_GELU : (EPI & E_GELU) != 0, dg = ANY ? g.act == OFB_ACT_DGELU : (EPI & E_DGELU) != 0;
+      const bool gelug = ANY ? g.act == OFB_ACT_GELU_GRAD : (EPI & E_GELUG) != 0, mula = ANY ? g.act == OFB_ACT_MULAUX : (EPI & E_MULAUX) != 0;
       const bool has_rs = ANY ? g.rowscale != nullptr : (EPI & E_RS) != 0, has_res = ANY ? g.resid != nullptr : (EPI & E_RES) != 0;
       float* T = reinterpret_cast<float*>(lds);
       float* __restrict__ Cout = g.C;
@@ -471,7 +479,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
 #pragma unroll
                   for (int c = 0; c < NC; ++c) {
                     const int col = cur.n0 + lane + 64 * c, colc = (!GD || col < g.N) ? col : g.N - 1;
-                    side[kk * NC + c][tt] = dg ? auxr[(size_t)rowc * g.ldaux + colc] : 0.f;
+                    side[kk * NC + c][tt] = (dg || mula) ? auxr[(size_t)rowc * g.ldaux + colc] : 0.f;
                     side2[kk * NC + c][tt] = has_res ? resid[(size_t)rowc * g.ldr + colc] : 0.f;
                   }
                 }
@@ -493,8 +501,15 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
                     if (gelu) {
                       if (auxw && ok) auxw[(size_t)row * g.ldaux + col] = val;
                       val = ofb_gelu(val);
+                    } else if (gelug) {
+                      float Phi, phi;
+                      ofb_gelu_parts(val, Phi, phi);
+                      if (ok) auxw[(size_t)row * g.ldaux + col] = Phi + val * phi;
+                      val *= Phi;
                     } else if (dg) {
                       val *= ofb_dgelu(side[kk * NC + c][tt]);
+                    } else if (mula) {
+                      val *= side[kk * NC + c][tt];
                     }
                     val = val * rsv[kk][tt] + side2[kk * NC + c][tt];
                     if (has_c && ok) Cout[(size_t)row * g.ldc + col] = val;
@@ -653,13 +668,14 @@ template <class CF, bool A_KC, bool B_KC>
 int launch_p(const ofb_gemm_p_args& g, const Plan& p, hipStream_t s) {
   if (p.full_rounds > 0) {
     const int f = (g.C ? E_C : 0) | (g.Cp ? E_P : 0) | (g.act == OFB_ACT_GELU ? E_GELU : 0) | (g.act == OFB_ACT_DGELU ? E_DGELU : 0) |
+                  (g.act == OFB_ACT_GELU_GRAD ? E_GELUG : 0) | (g.act == OFB_ACT_MULAUX ? E_MULAUX : 0) |
                   (g.rowscale ? E_RS : 0) | (g.resid ? E_RES : 0);
     switch (f) {     // the forms the model issues; anything else takes the generic (run-time flags) instantiation
       case E_C: launch_full<CF, A_KC, B_KC, E_C>(g, p, s); break;
       case E_C | E_RES: launch_full<CF, A_KC, B_KC, E_C | E_RES>(g, p, s); break;
       case E_C | E_RS | E_RES: launch_full<CF, A_KC, B_KC, E_C | E_RS | E_RES>(g, p, s); break;
-      case E_P | E_GELU: launch_full<CF, A_KC, B_KC, E_P | E_GELU>(g, p, s); break;
-      case E_P | E_DGELU: launch_full<CF, A_KC, B_KC, E_P | E_DGELU>(g, p, s); break;
+      case E_P | E_GELUG: launch_full<CF, A_KC, B_KC, E_P | E_GELUG>(g, p, s); break;
+      case E_P | E_MULAUX: launch_full<CF, A_KC, B_KC, E_P | E_MULAUX>(g, p, s); break;
       case E_P: launch_full<CF, A_KC, B_KC, E_P>(g, p, s); break;
       default: launch_full<CF, A_KC, B_KC, E_ANY>(g, p, s); break;
     }
@@ -747,7 +763,8 @@ extern "C" int ofb_gemm_p(const ofb_gemm_p_args* args, void* stream) {
   if (g.a_kc == 0 && g.b_kc == 1) return OFB_ELIMIT;           // A^T * B^T is not on the path
   if (g.colpart && C128::BM != 128) return OFB_ELIMIT;
   if (g.rowscale && g.rs_div <= 0) return OFB_EINVAL;
-  if (g.act == OFB_ACT_DGELU && !g.aux) return OFB_EINVAL;
+  if (g.act < OFB_ACT_NONE || g.act > OFB_ACT_MULAUX) return OFB_EINVAL;
+  if ((g.act == OFB_ACT_DGELU || g.act == OFB_ACT_GELU_GRAD || g.act == OFB_ACT_MULAUX) && !g.aux) return OFB_EINVAL;
   if (g.C && g.ldc < g.N) return OFB_EINVAL;
   if (g.Cp && g.c_ncb < (g.N + 15) / 16) return OFB_EINVAL;
   // granule columns of each operand's P matrix must cover its extent along that axis

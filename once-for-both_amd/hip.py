@@ -34,7 +34,7 @@ class GemmArgs(C.Structure):
     ]
 
 
-ACT_NONE, ACT_GELU, ACT_DGELU = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4      # the last two: ofb_gemm_p only
 # 'p': f32-operand GEMM calls convert to P-format and run csrc/gemm_p.hip; 'split': the in-loop split engine of csrc/gemm.hip
 ENGINE = os.environ.get('OFB_GEMM_ENGINE', 'p')
 

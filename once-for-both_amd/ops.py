@@ -432,9 +432,10 @@ class MlpBranch(torch.autograd.Function):
         if _use_p():
             xP, w1P, w2P = _P(x, M, D), hip.weight_p(w1), hip.weight_p(w2)
             ctx.wp = (w1P, w2P)
-            # gelu(g * fc1(x)) leaves the kernel as the P-format operand of fc2 (and of the fc2 weight gradient); only the f32
-            # pre-activation is kept beside it for GELU'
-            _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU, aux=hpre, want_f32=False, want_p=True)
+            # gelu(g * fc1(x)) leaves the kernel as the P-format operand of fc2 (and of the fc2 weight gradient); beside it only
+            # GELU'(pre-activation) is kept in f32 (`hpre` holds the derivative here): the epilogue has Phi and phi in hand, and the
+            # backward epilogue becomes a single multiply
+            _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU_GRAD, aux=hpre, want_f32=False, want_p=True)
             out, _ = p_linear_fwd(hP, M, hid, w2P, b2, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
             ctx.save_for_backward(xP.buf, hpre, hP.buf, w1, b1, w2, gv, rowscale)
             ctx.meta = (B, N, D, resid is None, b2 is not None)
@@ -480,7 +481,7 @@ def _mlp_backward_p(ctx, dout):
     w1P, w2P = ctx.wp
     # the fc1 bias gradient (column sums of this P-format-only result) rides on the epilogue
     db1_raw = _new(hpre, hid) if b1 is not None else None
-    _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_DGELU, aux=hpre, want_f32=False, want_p=True, colsum_out=db1_raw)
+    _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True, colsum_out=db1_raw)
     dw2 = grad_slot(w2)
     dw2 = dw2 if dw2 is not None else _new(d2, D, hid)
     with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2) else _nullctx()):

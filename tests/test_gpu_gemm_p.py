@@ -106,6 +106,15 @@ def test_gemm_p_epilogues(M, N, K):
     dref = (x.double() @ w.double().t()) * p.grad
     _close(dp.to_f32(), dref, 'dgelu (P-format)')
     _close(cs_out, dref.sum(0), 'column sums of the output from the fused epilogue', tol=1e-5)
+    # the pair the MLP branch uses: the forward saves GELU'(pre-activation), the backward epilogue multiplies by it
+    gaux, hp2 = torch.full((M, N), float('nan'), device='cuda'), hip.PMat(M, N, 'cuda')
+    hip.gemm_p(xp, wp, 1, 1, M, N, K, Cp=hp2, bias=bd, colscale=csd, aux=gaux, ldaux=N, act=hip.ACT_GELU_GRAD)
+    _close(gaux, p.grad, 'saved gelu derivative')
+    assert torch.equal(hp2.to_f32(), hp.to_f32())
+    dp2, cs2 = hip.PMat(M, N, 'cuda'), torch.full((N,), float('nan'), device='cuda')
+    hip.gemm_p(xp, wp, 1, 1, M, N, K, Cp=dp2, aux=gaux, ldaux=N, act=hip.ACT_MULAUX, colsum_out=cs2)
+    _close(dp2.to_f32(), dref, 'value x saved derivative (P-format)')
+    _close(cs2, dref.sum(0), 'column sums (saved-derivative form)', tol=1e-5)
 
 
 def test_gemm_p_deit_small_layer_shapes():
@@ -139,3 +148,5 @@ def test_gemm_p_rejects_bad_arguments():
         hip.gemm_p(a, a, 1, 1, 32, 32, 64, C_out=out, ldc=32)          # K beyond the operand's granule columns
     with pytest.raises(hip.OfbError):
         hip.gemm_p(a, a, 1, 1, 32, 32, 32, C_out=out, ldc=32, act=hip.ACT_DGELU)   # dGELU without aux
+    with pytest.raises(hip.OfbError):
+        hip.gemm_p(a, a, 1, 1, 32, 32, 32, C_out=out, ldc=32, act=hip.ACT_GELU_GRAD)   # save-derivative form without aux
