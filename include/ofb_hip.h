@@ -270,6 +270,11 @@ int ofb_embed_assemble_bwd(const float* dtokens, const float* conv, const float*
  * 47x47 box statistics, count_include_pad=False.  imgs/out/scratch1/scratch2: [planes][H][W]. */
 int ofb_norm_targets(const float* imgs, float* out, float* scratch1, float* scratch2, int32_t planes, int32_t Hh, int32_t Ww,
                      int32_t ksize, void* stream);
+/* The same values for the pixels of the listed patches only (the PMIM loss reads nothing else: M = 0 on unmasked patches):
+ * patch_ids[n_ids] = b*L + l (L = gw*gw patches of P x P pixels per plane, P <= 16); one fused kernel, the patch's 62 x 62 window
+ * staged in LDS; out [B*C][H][W] receives those pixels, the rest of it is left untouched. */
+int ofb_norm_targets_masked(const float* imgs, const int32_t* patch_ids, int32_t n_ids, float* out, int32_t B, int32_t C, int32_t L,
+                            int32_t P, int32_t Hh, int32_t Ww, int32_t ksize, void* stream);
 
 /* PMIM masked L1 loss (models/vision_transformer.py:724-729) evaluated in PATCH layout: rec [B*L][C*P*P] is the
  * decoder 1x1-conv output before PixelShuffle (channel c*P*P+i*P+j <-> pixel (c, P*py+i, P*px+j)), targets

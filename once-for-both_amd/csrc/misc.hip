@@ -127,6 +127,55 @@ __global__ __launch_bounds__(256) void box_v_norm_kernel(const float* __restrict
   }
 }
 
+// The same statistics for the pixels the loss reads only (the masked patches: M = 0 elsewhere, vision_transformer.py:724-729), in
+// one kernel: block = (masked patch, image plane); the patch's (P + K - 1)^2 window (P x P pixels + the K/2 halo) is loaded into
+// LDS once, the horizontal and the vertical K-sums run out of LDS in the same order as box_h_kernel / box_v_norm_kernel, and the
+// P x P normalised pixels are written to their place in the [planes][H][W] target buffer (the rest of it is never read).
+template <int K, int PMAX>
+__global__ __launch_bounds__(256) void norm_targets_masked_kernel(const float* __restrict__ img, const int32_t* __restrict__ ids,
+                                                                  float* __restrict__ out, int C, int L, int gw, int P, int Hh, int Ww) {
+  constexpr int R = K / 2, WIN = PMAX + K - 1, PITCH = WIN + 1;
+  __shared__ float win[WIN * PITCH], h1[WIN * PMAX], h2[WIN * PMAX];
+  const int patch = ids[blockIdx.x], c = blockIdx.y, b = patch / L, l = patch % L, py = l / gw, px = l % gw;
+  const float* plane = img + ((size_t)b * C + c) * Hh * Ww;
+  const int y0 = py * P - R, x0 = px * P - R, wn = P + K - 1;
+  for (int i = threadIdx.x; i < wn * wn; i += 256) {
+    const int yy = i / wn, xx = i % wn, y = y0 + yy, x = x0 + xx;
+    win[yy * PITCH + xx] = (y >= 0 && y < Hh && x >= 0 && x < Ww) ? plane[(size_t)y * Ww + x] : 0.f;
+  }
+  __syncthreads();
+  // horizontal zero-padded window sums of v and v^2 for the P columns of the patch, every row of the window: a thread keeps K + 3
+  // values of one row in registers and forms four neighbouring sums from them (each still added left to right); consecutive
+  // threads take consecutive rows (odd LDS pitch: conflict free)
+  for (int i = threadIdx.x; i < wn * ((P + 3) / 4); i += 256) {
+    const int yy = i % wn, j0 = 4 * (i / wn);
+    const float* rowp = &win[yy * PITCH + j0];
+    float v[K + 3];
+#pragma unroll
+    for (int k = 0; k < K + 3; ++k) v[k] = (j0 + k < wn) ? rowp[k] : 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float a = 0.f, q = 0.f;
+#pragma unroll
+      for (int k = 0; k < K; ++k) { a += v[t + k]; q += v[t + k] * v[t + k]; }
+      if (j0 + t < P) { h1[yy * PMAX + j0 + t] = a; h2[yy * PMAX + j0 + t] = q; }
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < P * P; i += 256) {
+    const int ii = i / P, j = i % P, y = py * P + ii, x = px * P + j;
+    float sa = 0.f, sq = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) { sa += h1[(ii + k) * PMAX + j]; sq += h2[(ii + k) * PMAX + j]; }
+    const float cx = (float)(min(x + R, Ww - 1) - max(x - R, 0) + 1);
+    const float cnt = cx * (float)(min(y + R, Hh - 1) - max(y - R, 0) + 1);
+    const float mean = sa / cnt, sqm = sq / cnt;
+    float var = (sqm - mean * mean) * (cnt / (cnt - 1.0f));
+    var = fmaxf(var, 0.f);
+    out[((size_t)b * C + c) * Hh * Ww + (size_t)y * Ww + x] = (win[(ii + R) * PITCH + j + R] - mean) / sqrtf(var + 1.e-6f);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // PMIM masked L1 (vision_transformer.py:724-729) in PATCH layout: rec[b*L+l][c*P*P + i*P + j] is pixel
 // (c, P*py+i, P*px+j) after PixelShuffle.  One block per patch; unmasked patches contribute exactly 0.
@@ -337,6 +386,22 @@ extern "C" int ofb_norm_targets(const float* imgs, float* out, float* scratch1, 
 }
 
 // rec [B*L][C*P*P] patch layout, targets [B][C][img][img], mask [B*L] in {0,1}; partial [B*L]; out2 = {loss, grad scale}
+// norm_targets restricted to the pixels of the listed patches (ids: global patch index b * L + l, L = gw * gw patches of P x P
+// pixels per plane): writes only those pixels of out [B*C][H][W]; every other element of out is left untouched.
+extern "C" int ofb_norm_targets_masked(const float* imgs, const int32_t* patch_ids, int32_t n_ids, float* out, int32_t B, int32_t C,
+                                       int32_t L, int32_t P, int32_t Hh, int32_t Ww, int32_t ksize, void* stream) {
+  if (!imgs || !patch_ids || !out || n_ids <= 0 || B <= 0 || C <= 0 || L <= 0 || P <= 0 || Hh <= 0 || Ww <= 0) return OFB_EINVAL;
+  if (ksize != 47 || P > 16) return OFB_ELIMIT;         // the reference hard-codes 47 (vision_transformer.py:727); DeiT patches are 16 x 16
+  int gw = 1;
+  while (gw * gw < L) ++gw;
+  if (gw * gw != L || gw * P > Hh || gw * P > Ww) return OFB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ofb_prof_pre(5, s, 16.0 * n_ids * C * (double)P * P);
+  hipLaunchKernelGGL((norm_targets_masked_kernel<47, 16>), dim3(n_ids, C), dim3(256), 0, s, imgs, patch_ids, out, C, L, gw, P, Hh, Ww);
+  ofb_prof_post(5, s);
+  return ofb_launch_status();
+}
+
 extern "C" int ofb_pmim_loss_fwd(const float* rec, const float* targets, const float* mask, const int32_t* patch_ids,
                                  int32_t n_rows, float* partial, float* out2, int32_t B, int32_t L, int32_t P, int32_t C,
                                  void* stream) {

@@ -44,7 +44,7 @@ SYMBOLS = [
     'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
-    'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets',
+    'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
     'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
     'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm', 'ofb_random_erase',
     'ofb_randaug_layer', 'ofb_normalize_u8',
@@ -464,6 +464,11 @@ def embed_assemble_bwd(dtokens, conv, g, pos, cls, mask_token, mask, dconv, ppos
 def norm_targets(imgs, out, s1, s2, planes, H, W, k=47):
     check(lib().ofb_norm_targets(ptr(imgs), ptr(out), ptr(s1), ptr(s2), _i(planes), _i(H), _i(W), _i(k), stream()),
           'ofb_norm_targets')
+
+
+def norm_targets_masked(imgs, ids, out, B, Cc, L, P, H, W, k=47):
+    check(lib().ofb_norm_targets_masked(ptr(imgs), ptr(ids), _i(ids.numel()), ptr(out), _i(B), _i(Cc), _i(L), _i(P), _i(H), _i(W), _i(k),
+                                        stream()), 'ofb_norm_targets_masked')
 
 
 def pmim_loss_fwd(rec, targets, mask, ids, n_rows, partial, out2, B, L, P, Cc):

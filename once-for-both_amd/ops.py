@@ -570,6 +570,16 @@ def norm_targets(imgs, ksize=47):
     return out
 
 
+def norm_targets_masked(imgs, patch_ids, L, P, ksize=47):
+    """norm_targets for the pixels of the listed patches only (ids = b * L + l): the other pixels of the returned buffer are
+    uninitialised and must not be read (PmimLoss with the same patch_ids reads exactly the listed patches)."""
+    imgs = _c(imgs)
+    B, Cc, Hh, Ww = imgs.shape
+    out = torch.empty_like(imgs)
+    hip.norm_targets_masked(imgs, patch_ids, out, B, Cc, L, P, Hh, Ww, ksize)
+    return out
+
+
 class PmimLoss(torch.autograd.Function):
     """sum(|t - x_rec| * M) / (sum(M) + 1e-5) / C evaluated in patch layout (vision_transformer.py:724-729).
     patch_ids (int32, optional): rec holds only those patches (the masked ones); exact, since M = 0 elsewhere."""

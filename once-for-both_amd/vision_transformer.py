@@ -377,22 +377,7 @@ class MIMVisionTransformer(MAEBaseModel):
         x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x, mask, None, None
 
-    def _targets_async(self, imgs):
-        """norm_targets(imgs, 47) depends only on the input batch: run its two HBM-bound kernels on a side stream so they
-        overlap the MFMA-bound trunk (the persistent GEMM workgroups leave half of every CU's wave slots free)."""
-        main = torch.cuda.current_stream()
-        if self._side_stream is None:
-            self._side_stream = torch.cuda.Stream(device=imgs.device)
-        side = self._side_stream
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
-            targets = norm_targets(imgs, 47)
-        imgs.record_stream(side)
-        return targets, side
-
     def forward(self, imgs):
-        pending = self._targets_async(imgs) if (self.mae and self.training and imgs.is_cuda and
-                                                int(self.num_patches * self.patch_ratio_list[0]) != self.num_patches) else None
         latent, mask, _, _ = self.forward_features(imgs)
         B, T, D = latent.shape
         if self.mae and mask is not None:
@@ -404,10 +389,9 @@ class MIMVisionTransformer(MAEBaseModel):
             z = latent.reshape(B * T, D).index_select(0, tok_rows)
             dec = self.decoder[0]
             rec = ops.Linear.apply(z, dec.weight.view(dec.weight.shape[0], -1), dec.bias)      # 1x1 conv, patch layout
-            if pending is not None:
-                targets, side = pending
-                torch.cuda.current_stream().wait_stream(side)
-                targets.record_stream(torch.cuda.current_stream())
+            # norm_targets(imgs, 47) for the masked patches' pixels only: one fused kernel over their 62 x 62 windows
+            if imgs.is_cuda and ids.numel() > 0 and P <= 16:
+                targets = ops.norm_targets_masked(imgs, ids, L, P, 47)
             else:
                 targets = norm_targets(imgs, 47)
             decoder_loss = ops.PmimLoss.apply(rec, targets, mask, ids, B, L, P, Cc)

@@ -25,6 +25,11 @@ run('fc1 shape: GELU f32 out, no aux', lambda: hip.gemm_p(xp, w3p, 1, 1, M, HID,
 run('fc1 shape: GELU + aux, f32 out', lambda: hip.gemm_p(xp, w3p, 1, 1, M, HID, D, C_out=y, ldc=HID, bias=b3, colscale=g3, act=hip.ACT_GELU, aux=aux, ldaux=HID), F)
 run('fc1 shape: GELU + aux, P out (the real fc1)', lambda: hip.gemm_p(xp, w3p, 1, 1, M, HID, D, Cp=hP, bias=b3, colscale=g3, act=hip.ACT_GELU, aux=aux, ldaux=HID), F)
 run('fc1 shape: dGELU(aux) P out (the real dH)', lambda: hip.gemm_p(xp, w3p, 1, 1, M, HID, D, Cp=hP, act=hip.ACT_DGELU, aux=aux, ldaux=HID), F)
+run('fc1 shape: GELU_GRAD + aux, P out (the real fc1 now)', lambda: hip.gemm_p(xp, w3p, 1, 1, M, HID, D, Cp=hP, bias=b3, colscale=g3, act=hip.ACT_GELU_GRAD, aux=aux, ldaux=HID), F)
+run('fc1 shape: MULAUX P out (the real dH now)', lambda: hip.gemm_p(xp, w3p, 1, 1, M, HID, D, Cp=hP, act=hip.ACT_MULAUX, aux=aux, ldaux=HID), F)
+cs = torch.empty(HID, device='cuda')
+run('fc1 shape: MULAUX P out + column sums', lambda: hip.gemm_p(xp, w3p, 1, 1, M, HID, D, Cp=hP, act=hip.ACT_MULAUX, aux=aux, ldaux=HID, colsum_out=cs), F)
+run('fc1 shape: P out + column sums', lambda: hip.gemm_p(xp, w3p, 1, 1, M, HID, D, Cp=hP, colsum_out=cs), F)
 w4 = r(D, HID); w4p = hip.to_pformat(w4); y2 = torch.empty(M, D, device='cuda'); rs = torch.rand(M, device='cuda')
 run('fc2 shape: plain f32 out', lambda: hip.gemm_p(hP, w4p, 1, 1, M, D, HID, C_out=y2, ldc=D), F)
 run('fc2 shape: bias+rowscale+resid (real)', lambda: hip.gemm_p(hP, w4p, 1, 1, M, D, HID, C_out=y2, ldc=D, bias=b3[:D].contiguous(), rowscale=rs, resid=x, ldr=D), F)

@@ -26,6 +26,28 @@ def test_norm_targets_golden_and_oracle():
     assert float((got - O.norm_targets(x)).abs().max()) < 1e-4
 
 
+def test_norm_targets_masked_patches_only():
+    """the fused kernel over the masked patches' windows: those pixels equal the full-image kernels' values (same summation
+    order), corner / edge patches (partial windows, count_include_pad=False) included; nothing else is written"""
+    from ofb_amd import hip, ops
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 3, 224, 224, generator=g).cuda()
+    full = ops.norm_targets(x)
+    L, P = 196, 16
+    ids = torch.tensor([0, 13, 14 * 13, 195, 196 + 7, 196 + 100, 2 * 196 + 97, 2 * 196 + 195], dtype=torch.int32, device='cuda')
+    out = torch.full_like(x, float('nan'))
+    hip.norm_targets_masked(x, ids, out, 3, 3, L, P, 224, 224)
+    seen = torch.zeros(3, 224, 224, dtype=torch.bool, device='cuda')
+    for pid in ids.tolist():
+        b, l = divmod(pid, L)
+        py, px = divmod(l, 14)
+        sl = (b, slice(None), slice(py * P, py * P + P), slice(px * P, px * P + P))
+        assert float((out[sl] - full[sl]).abs().max()) <= 1e-6 * float(full[sl].abs().max())
+        seen[b, py * P:py * P + P, px * P:px * P + P] = True
+    assert torch.isnan(out[:, 0][~seen]).all()            # the rest of the buffer is untouched
+    assert float((out.cpu()[0, :, :16, :16] - O.norm_targets(x.cpu())[0, :, :16, :16]).abs().max()) < 1e-4
+
+
 def test_patch_mask_and_ce():
     from ofb_amd import hip, ops
     n = torch.from_numpy(fill.patch_noise(5))
