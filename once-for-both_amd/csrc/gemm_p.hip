@@ -384,14 +384,29 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
       OFB_INTERLEAVE(RD2 > NMF ? 2 * NMF - RD2 : NMF, 1)
       __builtin_amdgcn_sched_barrier(0);
     };
-    int buf = 0, i = 0;
-    for (; i + 1 < nk; i += 2) {
-      step(i, buf, std::integral_constant<int, 0>{});
-      buf = buf + 1 == NST ? 0 : buf + 1;
-      step(i + 1, buf, std::integral_constant<int, 1>{});
-      buf = buf + 1 == NST ? 0 : buf + 1;
+    // A wave whose whole 64 x 96 part of the tile lies outside the matrix (ragged shapes: N = 264 in 192-column tiles, ...) takes
+    // part in the staging and the barriers only: no fragment reads, no MFMAs (its accumulators stay zero and are never stored); the
+    // matrix pipe and the power budget go to the other waves and the co-resident workgroup
+    if (cur.m0 + wm0 < g.M && cur.n0 + wn0 < g.N) {
+      int buf = 0, i = 0;
+      for (; i + 1 < nk; i += 2) {
+        step(i, buf, std::integral_constant<int, 0>{});
+        buf = buf + 1 == NST ? 0 : buf + 1;
+        step(i + 1, buf, std::integral_constant<int, 1>{});
+        buf = buf + 1 == NST ? 0 : buf + 1;
+      }
+      if (i < nk) step(i, buf, std::integral_constant<int, 0>{});
+    } else {
+      int buf = 0;
+      for (int i = 0; i < nk; ++i) {
+        int young = nk - i - 2;
+        young = young < 0 ? 0 : (young > NST - 2 ? NST - 2 : young);
+        vm_wait(young * n_w);
+        __builtin_amdgcn_s_barrier();
+        if (i + NST < nk) issue(buf, a_base + (size_t)(i + NST) * a_step, b_base + (size_t)(i + NST) * b_step);
+        buf = buf + 1 == NST ? 0 : buf + 1;
+      }
     }
-    if (i < nk) step(i, buf, std::integral_constant<int, 0>{});
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the trailing (unused) fragment reads
     OFB_PSTAMP(2);
 

@@ -69,18 +69,31 @@ def check(rc, what):
         raise OfbError(f'{what} failed with code {rc}' + (' (rejected arguments)' if rc < 0 else ' (hipError_t)'))
 
 
+_OK_DTYPES = frozenset((torch.float32, torch.int64, torch.int32, torch.uint8, torch.bool))
+_void_p = C.c_void_p
+
+
 def ptr(t):
+    # ~900 calls per search step: kept to two attribute reads and one ctypes object
     if t is None:
         return None
     if not t.is_cuda:
         raise OfbError('once-for-both_amd kernels need device tensors (no CPU fallback); got a CPU tensor')
-    if t.dtype != torch.float32 and t.dtype not in (torch.int64, torch.int32, torch.uint8, torch.bool):
+    if t.dtype not in _OK_DTYPES:
         raise OfbError(f'unsupported dtype {t.dtype}')
-    return C.c_void_p(t.data_ptr())
+    return _void_p(t.data_ptr())
+
+
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+_get_device = getattr(torch._C, '_cuda_getDevice', None)
 
 
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """the current HIP stream of the current device as a void* (torch's raw-stream accessor: ~0.3 us instead of ~8 us for a
+    torch.cuda.Stream object per launch)"""
+    if _raw_stream is not None and _get_device is not None:
+        return _void_p(_raw_stream(_get_device()))
+    return _void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def _f32c(t, name):
@@ -96,7 +109,8 @@ def _workspace(device, nbytes):
     """one stream-K workspace per (device, stream): successive GEMMs on ONE stream may reuse it (stream order serialises the
     partial tiles), GEMMs on different streams (an EMA / eval forward on a side stream, user code) must not share it.
     A grown buffer replaces the old one; the caching allocator keeps the old block alive until the stream has passed it."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    key = (device, _raw_stream(device.index if device.index is not None else torch.cuda.current_device())
+           if _raw_stream is not None and isinstance(device, torch.device) else torch.cuda.current_stream(device).cuda_stream)
     ws = _gemm_ws.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
         ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
