@@ -637,6 +637,11 @@ int p_tile_choice(const ofb_gemm_p_args&) {
 template <class CF>
 Plan plan_p(const ofb_gemm_p_args& g) {
   int W = p_cu_count() * CF::WGS;
+  if (!g.a_kc && !g.b_kc) {                                          // weight-gradient form (lab knob): workgroups per CU
+    static int dw_wgs = -1;
+    if (dw_wgs < 0) { const char* e = getenv("OFB_GEMM_P_DW_WGS"); dw_wgs = e ? atoi(e) : 0; }
+    if (dw_wgs > 0 && dw_wgs < CF::WGS) W = p_cu_count() * dw_wgs;
+  }
 #ifdef OFB_P_STAMPS
   { const char* e = getenv("OFB_GEMM_P_WCAP"); if (e && atoi(e) > 0 && atoi(e) < W) W = atoi(e); }   // lab: fewer resident workgroups
 #endif
