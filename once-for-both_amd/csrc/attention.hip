@@ -31,14 +31,18 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 // ------------------------------------------------------------------------------------------------------------------
 // forward: streaming (flash) form on the bf16 matrix pipe at fp32 accuracy
 // ------------------------------------------------------------------------------------------------------------------
-// Same exact three-way bf16 split and six product terms as the GEMM (csrc/gemm.hip), here on v_mfma_f32_16x16x32_bf16:
+// Same exact three-way bf16 split and six product terms as the GEMM (csrc/gemm_p.hip), here on v_mfma_f32_16x16x32_bf16:
 // lane l gives A[i = l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][col = l&15] (j = 0..7, one 16-byte fragment);
 // D[i = 4*(l>>4) + r][col = l&15].  Wave w owns query tile w; keys stream through LDS in blocks of 32 (two 16-key tiles),
-// double-buffered, each K / V value split ONCE per workgroup while it is staged:
-//   K planes  [3][32 keys][64 d + 8]      : A operand of S^T = K Q^T (fragment = 8 consecutive d of one key)
-//   V^T planes [3][64 ch][32 slots + 8]   : A operand of O^T = V^T P^T; slot (g, j) holds key 4g + j (j < 4) or 16 + 4g + j - 4,
-//                                           the keys whose P^T values lane group g owns in its two S^T accumulators, so the
-//                                           probabilities feed the next MFMA from registers (split into planes on the way).
+// double-buffered, each K / V value split ONCE per workgroup while it is staged, both as row-major planes [3][32 keys][64] bf16
+// (128-B rows, 8-byte stores) with the 16-byte chunks of a row XOR-swizzled by the key so that the fragment reads are conflict free:
+//   K planes: chunk ^ ((key >> 1) & 7).  A operand of S^T = K Q^T: fragment = 8 consecutive d of one key = one ds_read_b128
+//   V planes: chunk ^ (((key >> 1) & 3) << 1).  A operand of O^T = V^T P^T: rows = channels, k-slot (g, j) = key 4g + j (j < 4) or
+//             16 + 4g + j - 4 - the keys whose P^T values lane group g owns in its two S^T accumulators, so the probabilities feed
+//             the MFMA from registers.  The fragment is two ds_read_b64_tr_b16: lane 4e + q of a 16-lane group addresses the four
+//             channels 16 dt + 4q .. of key 4g + e, the hardware transpose hands lane i the keys 4g .. 4g + 3 of channel 16 dt + i.
+// (Round-2a layout: padded 144-B K rows and a slot-ordered V^T image written with 2-byte scattered stores: 61 % of the kernel's LDS
+// cycles were bank conflicts, SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE.)
 // Online softmax over the key blocks (running max m, running sum l, O rescaled when m grows); lse = m + log l.
 typedef __bf16 att_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 att_bf16x2 __attribute__((ext_vector_type(2)));
@@ -46,11 +50,11 @@ typedef float att_f32x2 __attribute__((ext_vector_type(2)));
 
 #define AF_KB 32                       // keys per block
 #define AF_NB ((ATT_NMAX + AF_KB - 1) / AF_KB)      // 7 blocks cover 224 >= 208 keys
-#define AF_KPITCH 144                  // bytes per K row of one plane: 64 bf16 + 16 pad
-#define AF_KPLANE (AF_KB * AF_KPITCH)
-#define AF_VPITCH 80                   // bytes per V^T row of one plane: 32 bf16 + 16 pad
-#define AF_VPLANE (ATT_DMAX * AF_VPITCH)
-#define AF_STAGE (3 * AF_KPLANE + 3 * AF_VPLANE)
+#define AF_PITCH 128                   // bytes per key row of one plane: 64 bf16
+#define AF_PLANE (AF_KB * AF_PITCH)
+#define AF_STAGE (6 * AF_PLANE)        // K planes then V planes
+typedef short att_s16x4 __attribute__((ext_vector_type(4)));
+typedef short att_s16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ unsigned att_pack(float a, float b) {
   att_f32x2 v = {a, b};
@@ -112,29 +116,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
     for (int i = 0; i < 2; ++i) {
       const int idx = t + ATT_THREADS * i;
       if (idx >= 1024) continue;
-      const int kk = (idx & 511) >> 4, d4 = (idx & 15) << 2;
+      const int kk = (idx & 511) >> 4, d16 = idx & 15, chunk = d16 >> 1;
       unsigned h0, m0, l0, h1, m1, l1;
       att_split_pair(sreg[i][0], sreg[i][1], h0, m0, l0);
       att_split_pair(sreg[i][2], sreg[i][3], h1, m1, l1);
-      if (idx < 512) {
-        char* p = st + kk * AF_KPITCH + d4 * 2;
-        *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(p + AF_KPLANE) = make_uint2(m0, m1);
-        *reinterpret_cast<uint2*>(p + 2 * AF_KPLANE) = make_uint2(l0, l1);
-      } else {
-        // V[key kk][d4 + e] -> V^T planes row (d4 + e), slot of key kk: tile = kk>>4, g' = (kk&15)>>2, r = kk&3 -> 8g' + 4*tile + r
-        const int slot = (((kk & 15) >> 2) << 3) + ((kk >> 4) << 2) + (kk & 3);
-        char* p = st + 3 * AF_KPLANE + d4 * AF_VPITCH + slot * 2;
-        const unsigned hs[2] = {h0, h1}, ms[2] = {m0, m1}, ls[2] = {l0, l1};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int sh = (e & 1) * 16;
-          unsigned short* q0 = reinterpret_cast<unsigned short*>(p + e * AF_VPITCH);
-          q0[0] = (unsigned short)(hs[e >> 1] >> sh);
-          *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(q0) + AF_VPLANE) = (unsigned short)(ms[e >> 1] >> sh);
-          *reinterpret_cast<unsigned short*>(reinterpret_cast<char*>(q0) + 2 * AF_VPLANE) = (unsigned short)(ls[e >> 1] >> sh);
-        }
-      }
+      const bool isk = idx < 512;
+      const int sw = isk ? ((kk >> 1) & 7) : (((kk >> 1) & 3) << 1);
+      char* p = st + (isk ? 0 : 3 * AF_PLANE) + kk * AF_PITCH + ((chunk ^ sw) << 4) + ((d16 & 1) << 3);
+      *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(p + AF_PLANE) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(p + 2 * AF_PLANE) = make_uint2(l0, l1);
     }
   };
   stage_load(0);
@@ -160,6 +151,16 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) O[dt] = zero4();
   float m_run = -INFINITY, l_run = 0.f;
+  // fragment read offsets inside a stage (bytes): K: key row 16 tk + c, chunk (4 ks + g) ^ ((c >> 1) & 7);
+  // V (transposed reads): this lane addresses key 4g + (c >> 2), channels 16 dt + 4 (c & 3) ..: chunk (2 dt + ((c & 3) >> 1)) ^ swizzle
+  int k_off[2], v_off[4];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) k_off[ks] = c * AF_PITCH + (((4 * ks + g) ^ ((c >> 1) & 7)) << 4);
+  {
+    const int vkey = 4 * g + (c >> 2), q = c & 3, sw = ((vkey >> 1) & 3) << 1;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) v_off[dt] = 3 * AF_PLANE + vkey * AF_PITCH + (((2 * dt + (q >> 1)) ^ sw) << 4) + ((q & 1) << 3);
+  }
   __syncthreads();
 
   const bool active = w * ATT_T < N;
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
           att_bf16x8 kf[3];
 #pragma unroll
           for (int pl = 0; pl < 3; ++pl)
-            kf[pl] = *reinterpret_cast<const att_bf16x8*>(st + pl * AF_KPLANE + (16 * tk + c) * AF_KPITCH + (32 * ks + 8 * g) * 2);
+            kf[pl] = *reinterpret_cast<const att_bf16x8*>(st + pl * AF_PLANE + 16 * tk * AF_PITCH + k_off[ks]);
           acc = att_mfma6(kf, qf[ks], acc);
         }
         S[tk] = acc;
@@ -215,8 +216,13 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
       for (int dt = 0; dt < 4; ++dt) {
         att_bf16x8 vf[3];
 #pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-          vf[pl] = *reinterpret_cast<const att_bf16x8*>(st + 3 * AF_KPLANE + pl * AF_VPLANE + (16 * dt + c) * AF_VPITCH + g * 16);
+        for (int pl = 0; pl < 3; ++pl) {
+          const char* vp = st + pl * AF_PLANE + v_off[dt];
+          const att_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)(vp));
+          const att_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)(vp + 16 * AF_PITCH));
+          const att_s16x8 v8 = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+          vf[pl] = __builtin_bit_cast(att_bf16x8, v8);
+        }
         O[dt] *= alpha;
         O[dt] = att_mfma6(vf, pf, O[dt]);
       }

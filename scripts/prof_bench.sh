@@ -6,6 +6,7 @@ R=$GRAFT_REPO_ROOT
 tag=${1:-run}
 rm -rf $R/gpurun_out/prof_$tag
 OFB_SIDE_STREAM=0 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$tag -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prof > $R/gpurun_out/prof_$tag.log 2>&1 || exit 1
-python3 $R/scripts/prof_summary.py $R/gpurun_out/prof_$tag 12 30   # 6 initialisation + 2 warm-up + 4 timed steps > $R/gpurun_out/prof_$tag.txt
+# 12 = 6 initialisation + 2 warm-up + 4 timed steps
+python3 $R/scripts/prof_summary.py $R/gpurun_out/prof_$tag 12 30 > $R/gpurun_out/prof_$tag.txt
 cd $R && python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-prof 2>/dev/null | tail -1 >> $R/gpurun_out/prof_$tag.txt
 cat $R/gpurun_out/prof_$tag.txt
