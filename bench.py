@@ -208,6 +208,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip per-kernel HIP-event timing')
     ap.add_argument('--prof-all', action='store_true', help='bracket every tagged kernel family in the sampled steps (default: the GEMM only)')
+    ap.add_argument('--graph', action='store_true', help='search mode, one rank: capture the whole step into a hipGraph and replay it '
+                    '(engine.GraphedStep); for launch-bound sizes (small batches); the sampled profile steps stay eager')
     ap.add_argument('--force-dp', action='store_true', help='exercise the DP bucket path even with one rank (debug)')
     args = ap.parse_args()
 
@@ -241,6 +243,9 @@ def main():
     from ofb_amd import engine, hip
     from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
 
+    use_graph = args.graph and args.mode == 'search' and world == 1
+    if use_graph:
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))     # the whole job on ONE non-default stream: capturable (GraphedStep)
     torch.manual_seed(0 + rank)                              # per-rank init streams (search.py:381); the reducer broadcasts rank 0's replica
     ncls = 1000
     eff_bs = args.batch * world
@@ -305,6 +310,11 @@ def main():
     # once in 60 steps).  These INIT_STEPS run before the W warm-up steps so that the timed region starts from a settled process.
     for _ in range(INIT_STEPS):
         step()
+    eager_step = step
+    if use_graph:
+        gstep = engine.GraphedStep(eager_step, (opt_p, opt_a, opt_d))
+        gstep.capture()                                      # two more eager steps on the capture stream, then the capture
+        step = gstep
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -322,6 +332,7 @@ def main():
             # attributable to one kernel (each stretches while the other shares the chip); `value` includes these slower steps
             hip.prof_enable(True if args.prof_all else 1)     # bit 0: the GEMM (the roofline kernel); --prof-all: every tagged kernel
             side_was, hip.SIDE_STREAM = hip.SIDE_STREAM, False
+            step = eager_step                                 # events cannot be recorded inside a replayed graph
         out = step()
     if prof_steps:
         hip.SIDE_STREAM = side_was
@@ -390,6 +401,7 @@ def main():
                            collective=dict(backend='nccl (RCCL over xGMI)' if dist.is_initialized() else 'none',
                                            ranks=dist.get_world_size() if dist.is_initialized() else 1,
                                            buckets=len(reducer.buckets) if reducer is not None else 0), init_steps=INIT_STEPS,
+                           hip_graph=bool(use_graph),
                            step_tflops_per_gpu=round(step_tflops, 2), step_frac_of_f32_mfma_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)),
                roofline=roof)
     if ft_info:

@@ -308,10 +308,17 @@ int ofb_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int
 int ofb_index_select(const float* src, const int32_t* idx, float* dst, int64_t outer, int64_t n_src, int64_t n_idx, int64_t inner,
                      int32_t* bad, void* stream);
 
+/* hipMemcpyAsync(host -> device) of a small pointer table from PINNED host memory on `stream` (capturable: a memcpy node) */
+int ofb_upload(void* dst_dev, const void* src_pinned, int64_t nbytes, void* stream);
+
 /* Multi-tensor AdamW, one launch per parameter group (optim.py:56-120): decoupled decay, bias-corrected Adam. */
 typedef struct ofb_adamw_tensor { float* p; const float* g; float* m; float* v; int64_t n; } ofb_adamw_tensor;
 int ofb_adamw_step(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int32_t step, void* stream);
+/* The same update with hyper_dev[3] = {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step)} read from device memory: the form a step
+ * captured in a hipGraph replays (the host refreshes the three floats before each replay). */
+int ofb_adamw_step_dev(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, const float* hyper_dev, float beta1,
+                       float beta2, float eps, float weight_decay, void* stream);
 
 /* Multi-tensor weight EMA (utils.py:430-441 `ema_v.copy_(ema_v * decay + (1 - decay) * model_v)`), one launch for the
  * whole state_dict; products and the sum are rounded separately (no FMA contraction) so the result is bit-identical to

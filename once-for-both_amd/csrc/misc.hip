@@ -333,9 +333,12 @@ __global__ __launch_bounds__(256) void index_select_kernel(const float* __restri
 // ---------------------------------------------------------------------------------------------------
 // multi-tensor AdamW (optim.py:56-120): p *= 1 - lr*wd; m,v EMA; p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
 // ---------------------------------------------------------------------------------------------------
+// hyper (optional): device copy of {lr, bc1, 1 / sqrt(bc2)} read instead of the by-value arguments: the form a captured hipGraph
+// replays (the host refreshes the three floats before every replay; same values, same arithmetic as the by-value form)
 __global__ __launch_bounds__(256) void adamw_kernel(const ofb_adamw_tensor* __restrict__ tab, float lr, float beta1, float beta2,
-                                                    float eps, float wd, float bc1, float rsqrt_bc2) {
+                                                    float eps, float wd, float bc1, float rsqrt_bc2, const float* __restrict__ hyper) {
   const ofb_adamw_tensor tt = tab[blockIdx.y];
+  if (hyper) { lr = hyper[0]; bc1 = hyper[1]; rsqrt_bc2 = hyper[2]; }
   const float step = lr / bc1, decay = 1.0f - lr * wd;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tt.n; i += (int64_t)gridDim.x * 256) {
     const float g = tt.g[i];
@@ -480,17 +483,40 @@ extern "C" int ofb_index_select(const float* src, const int32_t* idx, float* dst
   return ofb_launch_status();
 }
 
+// Host-to-device copy of a small table from PINNED host memory on `stream` (plain hipMemcpyAsync: legal inside a stream capture,
+// where it becomes a memcpy node that every replay re-reads from the same host address; torch's own non_blocking copy also
+// records allocator events, which a capture does not allow from the autograd thread).
+extern "C" int ofb_upload(void* dst_dev, const void* src_pinned, int64_t nbytes, void* stream) {
+  if (!dst_dev || !src_pinned || nbytes <= 0) return OFB_EINVAL;
+  return (int)hipMemcpyAsync(dst_dev, src_pinned, (size_t)nbytes, hipMemcpyHostToDevice, (hipStream_t)stream);
+}
+
+namespace {
+int adamw_launch(const ofb_adamw_tensor* table_dev, int n_tensors, int64_t max_numel, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, float bc1, float rsqrt_bc2, const float* hyper, hipStream_t s) {
+  int bx = (int)((max_numel + 256 * 8 - 1) / (256 * 8));
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  ofb_prof_pre(6, s, 0.0);
+  hipLaunchKernelGGL(adamw_kernel, dim3(bx, n_tensors), dim3(256), 0, s, table_dev, lr, beta1, beta2, eps, weight_decay, bc1, rsqrt_bc2,
+                     hyper);
+  ofb_prof_post(6, s);
+  return ofb_launch_status();
+}
+}  // namespace
+
 extern "C" int ofb_adamw_step(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float lr, float beta1,
                               float beta2, float eps, float weight_decay, int32_t step, void* stream) {
   if (!table_dev || n_tensors <= 0 || max_numel <= 0 || step <= 0) return OFB_EINVAL;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-  int bx = (int)((max_numel + 256 * 8 - 1) / (256 * 8));
-  if (bx > 256) bx = 256;
-  if (bx < 1) bx = 1;
-  hipStream_t s = (hipStream_t)stream;
-  ofb_prof_pre(6, s, 0.0);
-  hipLaunchKernelGGL(adamw_kernel, dim3(bx, n_tensors), dim3(256), 0, s, table_dev, lr, beta1, beta2, eps, weight_decay,
-                     (float)bc1, (float)(1.0 / sqrt(bc2)));
-  ofb_prof_post(6, s);
-  return ofb_launch_status();
+  return adamw_launch(table_dev, n_tensors, max_numel, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), nullptr,
+                      (hipStream_t)stream);
+}
+
+// The same update with {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step)} read from device memory (hyper_dev[3]): for a step captured
+// in a hipGraph, whose replays must not bake the step count or the learning rate into the launch arguments.
+extern "C" int ofb_adamw_step_dev(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, const float* hyper_dev,
+                                  float beta1, float beta2, float eps, float weight_decay, void* stream) {
+  if (!table_dev || !hyper_dev || n_tensors <= 0 || max_numel <= 0) return OFB_EINVAL;
+  return adamw_launch(table_dev, n_tensors, max_numel, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, hyper_dev, (hipStream_t)stream);
 }

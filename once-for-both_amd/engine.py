@@ -46,6 +46,60 @@ def search_step(model, criterion, samples, targets, target_flops, optimizers, fi
     return base, arch, decoder_loss, total
 
 
+class GraphedStep:
+    """One whole training step (forward, losses, backward, optimizer steps) captured ONCE into a hipGraph and replayed: ~650
+    kernel launches per step leave the host as a single hipGraphLaunch (the launch-bound sizes - small batches, pruned models - are
+    host bound otherwise).  `fn()` must be the step as it runs eagerly, on static input tensors, after a few eager executions
+    (allocator / workspaces warm); it may use the side stream (it is forked from and joined into the capturing stream).  The AdamW
+    instances passed in read their learning rate and bias corrections from device memory inside the graph (optim.AdamW.begin_capture)
+    and are refreshed before every replay; random draws (DropPath, patch masking) come from torch's graph-safe generator.
+    Not for world size > 1 (the RCCL exchange is not captured) and not across compress() (shapes change: capture again)."""
+
+    def __init__(self, fn, optimizers):
+        self.fn, self.opts = fn, [o for o in optimizers if o is not None]
+        self.graph, self.out, self.k, self._keep = None, None, 0, None
+
+    def capture(self, warm_steps=2):
+        from . import hip
+        hip.join_side()
+        torch.cuda.synchronize()
+        # Autograd runs every parameter's AccumulateGrad on the stream the parameter was set up on and syncs it with the stream of
+        # backward.  For a model built on the legacy default stream that pulls the (uncapturable) null stream into the capture and
+        # hipStreamEndCapture faults.  So the whole job must live on ONE non-default stream: create it before the model is built
+        # (`torch.cuda.set_stream(torch.cuda.Stream())`, as bench.py does) and the capture uses that same stream.
+        cur = torch.cuda.current_stream()
+        if cur == torch.cuda.default_stream():
+            raise RuntimeError('GraphedStep: build the model and run the step on a non-default stream '
+                               '(torch.cuda.set_stream(torch.cuda.Stream()) before creating it)')
+        self.stream = cur
+        for _ in range(warm_steps):
+            self.out = self.fn()
+        hip.join_side()
+        self.stream.synchronize()
+        self.out = None
+        keep = hip.begin_capture_arena()
+        for o in self.opts:
+            o.begin_capture()
+        graph = torch.cuda.CUDAGraph()
+        try:
+            with torch.cuda.graph(graph, stream=self.stream):
+                self.out = self.fn()
+        finally:
+            hip.end_capture_arena()
+            for o in self.opts:
+                o.end_capture()
+        self.graph, self._keep, self.k = graph, keep, 0
+
+    def __call__(self):
+        if self.graph is None:
+            self.capture()
+        for o in self.opts:
+            o.refresh_hyper(self.k)
+        self.graph.replay()
+        self.k += 1
+        return self.out
+
+
 def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_param, optimizer_decoder, optimizer_arch,
                      lr_scheduler_param, lr_scheduler_arch, lr_scheduler_decoder, device, epoch, max_norm=0, model_ema=None,
                      mixup_fn=None, set_training_mode=True, use_amp=False, finish_search=False, args=None, progressive=True,

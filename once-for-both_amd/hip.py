@@ -45,7 +45,7 @@ SYMBOLS = [
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
-    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
+    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
     'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm', 'ofb_random_erase',
     'ofb_randaug_layer', 'ofb_normalize_u8',
 ]
@@ -437,11 +437,39 @@ class AdamwTensor(C.Structure):
     _fields_ = [('p', C.c_void_p), ('g', C.c_void_p), ('m', C.c_void_p), ('v', C.c_void_p), ('n', C.c_int64)]
 
 
+# While a step is being captured into a hipGraph (engine.GraphedStep) the pointer tables the step uploads (gate descriptors, AdamW
+# tensor lists) are staged in ONE pinned arena that the capture owns: each upload becomes a memcpy node that every replay re-reads
+# from the same host address.  (torch's pinned allocator and its non_blocking copies record / query events, which a capture does not
+# allow - least of all from the autograd thread.)
+_arena = None
+
+
+def begin_capture_arena(nbytes=1 << 20):
+    global _arena
+    _arena = dict(host=torch.empty(nbytes, dtype=torch.uint8).pin_memory(), off=0)
+    return _arena
+
+
+def end_capture_arena():
+    global _arena
+    _arena = None
+
+
 def upload_structs(array, device):
     """ctypes struct array -> device byte tensor (pinned staging, async on the current stream)."""
     if torch.device(device).type != 'cuda':
         raise OfbError('once-for-both_amd kernels need device tensors (no CPU fallback); got a CPU tensor')
     raw = bytes(array)
+    if _arena is not None:
+        n, off = len(raw), (_arena['off'] + 63) & ~63
+        if off + n > _arena['host'].numel():
+            raise OfbError('capture arena exhausted')
+        host = _arena['host'][off:off + n]
+        C.memmove(host.data_ptr(), raw, n)
+        _arena['off'] = off + n
+        dev = torch.empty(n, dtype=torch.uint8, device=device)
+        check(lib().ofb_upload(ptr(dev), C.c_void_p(host.data_ptr()), C.c_int64(n), stream()), 'ofb_upload')
+        return dev, host
     host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
     return host.to(device, non_blocking=True), host
 
@@ -541,6 +569,11 @@ def index_select(t, index, dim):
 def adamw_step(table_dev, n_tensors, max_numel, lr, beta1, beta2, eps, wd, step):
     check(lib().ofb_adamw_step(ptr(table_dev), _i(n_tensors), C.c_int64(max_numel), _f(lr), _f(beta1), _f(beta2), _f(eps),
                                _f(wd), _i(step), stream()), 'ofb_adamw_step')
+
+
+def adamw_step_dev(table_dev, n_tensors, max_numel, hyper_dev, beta1, beta2, eps, wd):
+    check(lib().ofb_adamw_step_dev(ptr(table_dev), _i(n_tensors), C.c_int64(max_numel), ptr(hyper_dev), _f(beta1), _f(beta2), _f(eps),
+                                   _f(wd), stream()), 'ofb_adamw_step_dev')
 
 
 def patch_mask(noise, mask, B, L, len_keep, masked_ids=None):

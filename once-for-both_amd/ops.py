@@ -4,6 +4,7 @@ Each Function is one fused op group of SURVEY.md 2.3 with a hand-written backwar
 allocates buffers and orders the graph.  All tensors are contiguous fp32 device tensors.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -102,10 +103,14 @@ def p_linear_bwd_weight(dyP, xP, M, N, K, out=None):
 _cb_queued = [False]
 
 
-def _side_ok(*params):
+_SIDE_MIN_TOKENS = int(os.environ.get('OFB_SIDE_MIN_TOKENS', '12000'))
+
+
+def _side_ok(*params, tokens=None):
     """weight-gradient work may go to the side stream unless a gradient is being accumulated into (AccumulateGrad would add on
-    the main stream at once) or the feature is off"""
-    if not hip.SIDE_STREAM:
+    the main stream at once), the feature is off, or the step is host bound anyway (few tokens: the fork / join bookkeeping costs
+    ~4 ms of host time per step - DeiT-T bs 8: 13.5 vs 9.4 ms per step - and buys nothing while the GPU waits for launches)"""
+    if not hip.SIDE_STREAM or (tokens is not None and tokens < _SIDE_MIN_TOKENS):
         return False
     if any(p is not None and p.grad is not None for p in params):
         return False
@@ -129,7 +134,7 @@ def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None):
     N, K = WP.R, WP.C
     W = W.view(N, K)
     slot = grad_slot(W)
-    side = _side_ok(W, b)
+    side = _side_ok(W, b, tokens=M)
     if gvec is None:
         dx, _ = p_linear_bwd_input(dyP, M, N, WP, K, resid=resid)
         dW = slot if slot is not None else _new(W, N, K)
@@ -393,7 +398,7 @@ def _attn_backward_p(ctx, dout):
     do, _ = p_linear_bwd_input(d2sP, M, D, wpP, Hd)
     dwp = grad_slot(wproj)
     dwp = dwp if dwp is not None else _new(d2, D, Hd)
-    with (hip.side_work(d2.device, keep=[d2sP.buf, oP.buf]) if _side_ok(wproj) else _nullctx()):
+    with (hip.side_work(d2.device, keep=[d2sP.buf, oP.buf]) if _side_ok(wproj, tokens=M) else _nullctx()):
         p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=dwp)
     # dq | dk | dv leave the attention kernel as planes, with the per-image column sums the qkv bias gradient is made of
     dqkvP = hip.PMat.for_rows_written_by_kernel(M, 3 * Hd, d2.device)
@@ -484,7 +489,7 @@ def _mlp_backward_p(ctx, dout):
     _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True, colsum_out=db1_raw)
     dw2 = grad_slot(w2)
     dw2 = dw2 if dw2 is not None else _new(d2, D, hid)
-    with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2) else _nullctx()):
+    with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2, tokens=M) else _nullctx()):
         p_linear_bwd_weight(d2sP, hP, M, D, hid, out=dw2)
 
     dx, dw1, db1, dg = _p_gated_linear_bwd(dhP, lambda: db1_raw, xP, M, w1, w1P, b1, gv, resid=d2 if self_resid else None)

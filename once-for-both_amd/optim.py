@@ -1,4 +1,7 @@
 """AdamW with the reference's interface (reference optim.py:7-182) on one fused multi-tensor kernel per group."""
+import math
+import struct
+
 import torch
 from torch.optim.optimizer import Optimizer
 
@@ -13,6 +16,33 @@ class AdamW(Optimizer):
             raise ValueError('invalid AdamW hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
         self.param_names = param_names
+        self._cap = None          # while / after a hipGraph capture of step(): device-resident {lr, bc1, 1/sqrt(bc2)} per launch
+
+    # ---- hipGraph support (engine.GraphedStep) ---------------------------------------------------------------------------------
+    # A captured step() must not bake the learning rate or the step count into its launch arguments: while capturing, every launch
+    # reads them from a slot of a small device tensor; refresh_hyper(k) recomputes the slots on the host (same double-precision
+    # formulas as the eager path) for the k-th replay and copies them over, outside the graph.
+    def begin_capture(self, max_launches=16):
+        dev = next(p for g in self.param_groups for p in g['params']).device
+        self._cap = dict(active=True, slots=[], dev=torch.zeros(4 * max_launches, device=dev), max=max_launches)
+
+    def end_capture(self):
+        if self._cap is not None:
+            self._cap['active'] = False
+
+    def refresh_hyper(self, k):
+        cap = self._cap
+        vals = [0.0] * (4 * cap['max'])
+        for i, (group, step0, plist) in enumerate(cap['slots']):
+            t = step0 + k
+            # the eager entry point receives the betas as C floats and forms the corrections in double: same here, bit for bit
+            b1, b2 = (struct.unpack('f', struct.pack('f', b))[0] for b in group['betas'])
+            vals[4 * i], vals[4 * i + 1], vals[4 * i + 2] = group['lr'], 1.0 - math.pow(b1, t), 1.0 / math.sqrt(1.0 - math.pow(b2, t))
+            for p in plist:
+                self.state[p]['step'] = t
+        # a fresh pinned staging tensor per refresh: the host may run several replays ahead of the GPU, and torch's pinned
+        # allocator does not hand a block out again before the copy that reads it has completed
+        cap['dev'].copy_(torch.tensor(vals, dtype=torch.float32).pin_memory(), non_blocking=True)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -47,7 +77,15 @@ class AdamW(Optimizer):
                     maxn = max(maxn, p.numel())
                     keep.append(g)
                 dev_tab, host = hip.upload_structs(tab, plist[0].device)
-                hip.adamw_step(dev_tab, len(plist), maxn, group['lr'], b1, b2, group['eps'], group['weight_decay'], step)
+                if self._cap is not None and self._cap['active']:
+                    cap = self._cap
+                    i = len(cap['slots'])
+                    if i >= cap['max']:
+                        raise hip.OfbError('AdamW capture: more launches than hyper-parameter slots')
+                    cap['slots'].append((group, step, list(plist)))
+                    hip.adamw_step_dev(dev_tab, len(plist), maxn, cap['dev'][4 * i:4 * i + 4], b1, b2, group['eps'], group['weight_decay'])
+                else:
+                    hip.adamw_step(dev_tab, len(plist), maxn, group['lr'], b1, b2, group['eps'], group['weight_decay'], step)
                 self._keep = (dev_tab, host, keep)
         hip.bump_weight_epoch()                  # the P-format copies of the weights (hip.weight_p) are stale now
         return loss

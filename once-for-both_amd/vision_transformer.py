@@ -481,10 +481,10 @@ class MIMVisionTransformer(MAEBaseModel):
     def _patch_cell_loss(self, zero):
         """patch term of the adaptive one-hot loss (reference base_model.py:39-51): entropy + tan term over the live patch cells
         (no 1/n, no score term).  Five scalars: a handful of ATen ops, only when patch_search is on."""
-        sw = self.switch_cell_patch.to(self.alpha_patch.device)
-        n = int(self.switch_cell_patch.sum())
+        n = int(self.switch_cell_patch.sum())               # host-side state (it changes in compress() only)
         if n == 1:
             return zero
+        sw = self.switch_cell_patch.to(self.alpha_patch.device)
         pr = torch.softmax(self.alpha_patch[sw], dim=-1)
         sigma = ((pr - pr.mean()) ** 2).sum() / (1.0 - 1.0 / n)
         return -(pr * pr.log()).sum() + torch.tan(math.pi / 2 - math.pi * sigma)

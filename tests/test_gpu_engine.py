@@ -143,3 +143,52 @@ def test_search_epoch_fed_by_device_loader():
                                         args=args, print_freq=1)
     torch.cuda.synchronize()
     assert all(torch.isfinite(torch.tensor(v)) for v in stats.values()), stats
+
+
+def test_graphed_step_reproduces_eager_steps():
+    """engine.GraphedStep: the whole search step (forward, losses, backward, the three AdamW steps) captured into a hipGraph and
+    replayed must walk the parameters exactly like eager steps do (forced mask / DropPath noise: no random draws; AdamW's learning
+    rate and bias corrections come from device memory inside the graph and are refreshed per replay)."""
+    import torch
+    from ofb_amd import engine
+    from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
+    from tests.golden_util import load_case
+    from tests.test_gpu_model import build_product
+    z, cfg, st, inputs, lr = load_case('micro_a')
+    prev = torch.cuda.current_stream()
+    torch.cuda.set_stream(torch.cuda.Stream())               # the job lives on one non-default stream (see GraphedStep.capture)
+    try:
+        results = []
+        for graphed in (False, False, True):
+            m = build_product(cfg, st, inputs)
+            opts = engine.build_optimizers(m, 1e-3)
+            crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), torch.device('cuda'),
+                                 attn_w=0.5, mlp_w=0.5, patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+            imgs, labels = inputs['imgs'].cuda(), inputs['labels'].cuda()
+            step = lambda: engine.search_step(m, crit, imgs, labels, 1.0, opts)
+            n_replay = 3
+            if graphed:
+                gs = engine.GraphedStep(step, opts)
+                gs.capture(warm_steps=2)                     # two eager steps on the capture stream, then the capture
+                for g in opts[0].param_groups:
+                    g['lr'] = 2e-3                           # a scheduler change between replays must reach the graph
+                for _ in range(n_replay):
+                    out = gs()
+            else:
+                for i in range(2 + n_replay):
+                    if i == 2:
+                        for g in opts[0].param_groups:
+                            g['lr'] = 2e-3
+                    out = step()
+            torch.cuda.synchronize()
+            results.append(({k: v.detach().clone() for k, v in m.state_dict().items()}, float(out[3])))
+        (sd_e, loss_e), (sd_e2, loss_e2), (sd_g, loss_g) = results
+        rel = lambda a, b: {k: float((a[k].double() - b[k].double()).abs().max() / (a[k].double().abs().max() + 1e-12)) for k in a}
+        r_ee, r_eg = rel(sd_e, sd_e2), rel(sd_e, sd_g)
+        k_ee, k_eg = max(r_ee, key=r_ee.get), max(r_eg, key=r_eg.get)
+        print(f'eager vs eager: worst {r_ee[k_ee]:.2e} ({k_ee}); graphed vs eager: loss {loss_g:.6f} / {loss_e:.6f}, worst {r_eg[k_eg]:.2e} ({k_eg})')
+        print('   differing:', {k: f'{v:.1e}' for k, v in r_eg.items() if v > 1e-7})
+        assert abs(loss_e - loss_g) <= 1e-5 * max(1.0, abs(loss_e))
+        assert r_eg[k_eg] <= max(1e-5, 2 * r_ee[k_ee])
+    finally:
+        torch.cuda.set_stream(prev)
