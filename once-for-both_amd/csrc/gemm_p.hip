@@ -104,6 +104,20 @@ __global__ void to_pformat_kernel(const float* __restrict__ X, int R, int C, int
   }
   store_p4(P + ((size_t)rg * ncb + (c >> 4)) * GRAN + (c & 15) * 8, v[0], v[1], v[2], v[3]);
 }
+// Many matrices in ONE launch (the weights of the model, once per optimizer step): blockIdx.z picks the matrix, the grid covers the
+// largest one and the blocks beyond a matrix's own extent leave at once.
+__global__ void to_pformat_multi_kernel(const ofb_pformat_job* __restrict__ jobs) {
+  const ofb_pformat_job j = jobs[blockIdx.z];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, rg = blockIdx.y, ncb = (j.C + 15) >> 4;
+  if (c >= ncb * 16 || rg >= ((j.R + 15) >> 4) * 4) return;
+  float v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = 4 * rg + t;
+    v[t] = (r < j.R && c < j.C) ? j.X[(size_t)r * j.ld + c] : 0.f;
+  }
+  store_p4((char*)j.P + ((size_t)rg * ncb + (c >> 4)) * GRAN + (c & 15) * 8, v[0], v[1], v[2], v[3]);
+}
 // The same conversion for a gradient whose column sums are wanted as well (bias gradients: db = colsum(dY)): one pass over dY
 // writes the planes AND partial[slab][c] = sum of the slab's (scaled) rows, added in row order; the slabs are summed by ofb_colsum.
 // grid (ceil(C16 / 64), slabs of 256 rows), 256 threads: wave w converts the row groups w, w + 4, ... of the slab, lane = column.
@@ -736,6 +750,14 @@ extern "C" int ofb_to_pformat(const float* X, int32_t R, int32_t C, int32_t ld, 
   const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4;
   hipLaunchKernelGGL(to_pformat_kernel, dim3((ncb * 16 + 255) / 256, rgs), dim3(256), 0, (hipStream_t)stream, X, R, C, ld, (char*)P,
                      ncb, rowscale, rs_div);
+  return ofb_launch_status();
+}
+
+// jobs_dev: n_jobs descriptors in device memory; max_R / max_C: the largest R and C among them (grid extent)
+extern "C" int ofb_to_pformat_multi(const ofb_pformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, void* stream) {
+  if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535 || max_R <= 0 || max_C <= 0) return OFB_EINVAL;
+  const int ncb = (max_C + 15) / 16, rgs = ((max_R + 15) / 16) * 4;
+  hipLaunchKernelGGL(to_pformat_multi_kernel, dim3((ncb * 16 + 255) / 256, rgs, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return ofb_launch_status();
 }
 

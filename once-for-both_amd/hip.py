@@ -40,7 +40,7 @@ ENGINE = os.environ.get('OFB_GEMM_ENGINE', 'p')
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
@@ -272,20 +272,79 @@ def bump_weight_epoch():
     _weight_epoch += 1
 
 
+class PformatJob(C.Structure):
+    _fields_ = [('X', C.c_void_p), ('P', C.c_void_p), ('R', C.c_int32), ('C', C.c_int32), ('ld', C.c_int32), ('pad_', C.c_int32)]
+
+
+# Every weight that has ever been asked for in P-format is registered (weak reference + its persistent plane buffer).  The first
+# request of a new epoch converts ALL registered weights that are stale in ONE multi-tensor launch (ofb_to_pformat_multi): ~70
+# launches per DeiT search step become one.  The job table is re-uploaded only when the set of (pointer, shape) entries changed.
+_wp_reg = {}                 # id(W) -> (weakref(W), (N, K))
+_wp_table = [None, None, 0, 0]   # key tuple, device table (kept alive), max_R, max_C
+
+
+def _wp_fresh(W):
+    ent = getattr(W, '_ofb_wp', None)
+    return ent is not None and ent[0] == _weight_epoch and ent[1] == W._version and ent[3] == tuple(W.shape)
+
+
+def _wp_refresh_all(device):
+    import weakref
+    jobs, live = [], []
+    for key, (ref, shape2d) in list(_wp_reg.items()):
+        W = ref()
+        if W is None or getattr(W, '_ofb_wp', None) is None or W._ofb_wp[3] != tuple(W.shape):
+            del _wp_reg[key]
+            continue
+        if W.device != device or _wp_fresh(W):
+            continue
+        live.append(W)
+        jobs.append((W.data_ptr(), W._ofb_wp[2].buf.data_ptr(), shape2d[0], shape2d[1]))
+    if not jobs:
+        return
+    key = tuple(jobs)
+    if _wp_table[0] != key:
+        tab = (PformatJob * len(jobs))()
+        for t, (x, pp, R, Cc) in zip(tab, jobs):
+            t.X, t.P, t.R, t.C, t.ld = x, pp, R, Cc, Cc
+        dev_tab, host = upload_structs(tab, device)
+        _wp_table[:] = [key, (dev_tab, host), max(j[2] for j in jobs), max(j[3] for j in jobs)]
+    check(lib().ofb_to_pformat_multi(ptr(_wp_table[1][0]), _i(len(jobs)), _i(_wp_table[2]), _i(_wp_table[3]), stream()),
+          'ofb_to_pformat_multi')
+    for W in live:
+        W._ofb_wp = (_weight_epoch, W._version, W._ofb_wp[2], tuple(W.shape))
+
+
+_WP_MULTI = os.environ.get('OFB_WP_MULTI', '1') != '0'
+
+
 def weight_p(W, shape2d=None):
     """P-format copy of a weight viewed as W[N][K] (shape2d: the 2-D view of a conv weight)."""
-    ent = getattr(W, '_ofb_wp', None)
-    if ent is not None and ent[0] == _weight_epoch and ent[1] == W._version and ent[3] == tuple(W.shape):
-        return ent[2]
+    if _wp_fresh(W):
+        return W._ofb_wp[2]
     if not W.is_contiguous():
         raise OfbError('weight_p needs a contiguous weight')
     N, K = shape2d if shape2d is not None else W.shape
-    pm = to_pformat(W, N, K, K)
+    if not _WP_MULTI:
+        pm = to_pformat(W, N, K, K)
+        try:
+            W._ofb_wp = (_weight_epoch, W._version, pm, tuple(W.shape))
+        except AttributeError:
+            pass
+        return pm
+    ent = getattr(W, '_ofb_wp', None)
     try:
+        if ent is None or ent[3] != tuple(W.shape) or ent[2].R != N or ent[2].C != K:
+            import weakref
+            W._ofb_wp = (-1, -1, PMat(N, K, W.device), tuple(W.shape))        # persistent planes; stale until converted
+            _wp_reg[id(W)] = (weakref.ref(W), (int(N), int(K)))
+    except (AttributeError, TypeError):
+        return to_pformat(W, N, K, K)                    # an object that takes no attributes / weak references: convert in place
+    _wp_refresh_all(W.device)
+    if not _wp_fresh(W):                                 # e.g. registered under another id: fall back to a single conversion
+        pm = to_pformat(W, N, K, K)
         W._ofb_wp = (_weight_epoch, W._version, pm, tuple(W.shape))
-    except AttributeError:
-        pass
-    return pm
+    return W._ofb_wp[2]
 
 
 def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,

@@ -150,3 +150,31 @@ def test_gemm_p_rejects_bad_arguments():
         hip.gemm_p(a, a, 1, 1, 32, 32, 32, C_out=out, ldc=32, act=hip.ACT_DGELU)   # dGELU without aux
     with pytest.raises(hip.OfbError):
         hip.gemm_p(a, a, 1, 1, 32, 32, 32, C_out=out, ldc=32, act=hip.ACT_GELU_GRAD)   # save-derivative form without aux
+
+
+def test_weight_planes_are_refreshed_together():
+    """hip.weight_p: every registered weight is converted by ONE multi-tensor launch per epoch (ofb_to_pformat_multi); the planes
+    equal a single conversion, follow raw-pointer updates after bump_weight_epoch() and torch in-place edits (_version)"""
+    from ofb_amd import hip
+    shapes = [(1152, 384), (384, 384), (1536, 384), (384, 1536), (1000, 384), (70, 36), (33, 100)]
+    ws = [torch.nn.Parameter(_mk(s, 40 + i).cuda()) for i, s in enumerate(shapes)]
+    for w in ws:
+        assert torch.equal(hip.weight_p(w).to_f32(), w.detach())
+    bufs = [hip.weight_p(w).buf.data_ptr() for w in ws]
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5)                                       # torch in-place edit: _version moves
+    assert torch.equal(hip.weight_p(ws[3]).to_f32(), ws[3].detach())
+    hip.lib().ofb_scale_rows                                  # (a raw-pointer edit below: only the epoch tells)
+    x = ws[0].detach().clone()
+    hip.scale_rows(x, torch.full((1152,), 2.0, device='cuda'), ws[0].data, 1152, 384)
+    assert not torch.equal(hip.weight_p(ws[0]).to_f32(), ws[0].detach())      # stale by design until the epoch is bumped
+    hip.bump_weight_epoch()
+    for w, b in zip(ws, bufs):
+        pm = hip.weight_p(w)
+        assert torch.equal(pm.to_f32(), w.detach()) and pm.buf.data_ptr() == b                # same persistent planes, fresh content
+    # as GEMM operands (padding columns / rows of the multi-tensor conversion must be zero)
+    a = _mk((50, 36), 60).cuda()
+    out = torch.empty(50, 70, device='cuda')
+    hip.gemm_p(hip.to_pformat(a), hip.weight_p(ws[5]), 1, 1, 50, 70, 36, C_out=out, ldc=70)
+    _close(out, a.double().cpu() @ ws[5].detach().double().cpu().t(), 'multi-converted planes as GEMM operand', tol=2e-6)
