@@ -320,11 +320,17 @@ _WP_MULTI = os.environ.get('OFB_WP_MULTI', '1') != '0'
 
 def weight_p(W, shape2d=None):
     """P-format copy of a weight viewed as W[N][K] (shape2d: the 2-D view of a conv weight)."""
-    if _wp_fresh(W):
-        return W._ofb_wp[2]
+    if shape2d is None:
+        shape2d = tuple(W.shape)
+    base = W._base
+    if base is not None and base.is_contiguous() and base.numel() == W.numel() and base.data_ptr() == W.data_ptr():
+        W = base                                         # a reshaping view of a Parameter (decoder / patch-embed weights): cache on the Parameter
+    ent = getattr(W, '_ofb_wp', None)
+    if ent is not None and ent[0] == _weight_epoch and ent[1] == W._version and ent[3] == tuple(W.shape) and (ent[2].R, ent[2].C) == tuple(shape2d):
+        return ent[2]
     if not W.is_contiguous():
         raise OfbError('weight_p needs a contiguous weight')
-    N, K = shape2d if shape2d is not None else W.shape
+    N, K = shape2d
     if not _WP_MULTI:
         pm = to_pformat(W, N, K, K)
         try:
