@@ -187,6 +187,10 @@ int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32
                       void* stream);
 int ofb_attention_bwd(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv, int32_t B,
                       int32_t N, int32_t H, int32_t dh, float scale, void* stream);
+/* Forward that also writes the output rows as P-format planes out_p[B*N][H*dh] (the operand of the projection GEMM; the values
+ * of `out` exactly).  The caller zeroes out_p beforehand when B*N or H*dh is not a multiple of 16; needs N + (b*N mod 4) <= 208. */
+int ofb_attention_fwd_p(const float* qkv, float* out, void* out_p, float* lse, int32_t B, int32_t N, int32_t H, int32_t dh,
+                        float scale, void* stream);
 /* The same gradient written as P-format planes of the [B*N][3*H*dh] matrix (ofb_pformat_bytes(B*N, 3*H*dh) bytes; the operand form
  * of the qkv gradient GEMMs, see ofb_gemm_p) - exactly the f32 values ofb_attention_bwd writes - plus colpart[B][3*H*dh], the
  * column sums over each image's tokens (their sum over B is the raw qkv bias gradient).  The kernel writes the

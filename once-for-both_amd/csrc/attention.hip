@@ -86,8 +86,45 @@ __device__ __forceinline__ f32x4 att_mfma6(const att_bf16x8 (&a)[3], const att_b
   return c;
 }
 
+// P-format stores (csrc/gemm_p.hip: granules of 4 rows x 16 columns, [plane][c % 16][r % 4] bf16, 384 B, stored [rows/4][ncb])
+__device__ __forceinline__ char* att_p_slot(char* P, int ncb, int row, int col) {
+  return P + ((size_t)(row >> 2) * ncb + (col >> 4)) * 384 + (col & 15) * 8 + (row & 3) * 2;
+}
+// four consecutive rows row0.. (row0 % 4 == 0: one 8-byte slot per plane) of one column; only rows [rlo, rhi) belong to the caller
+__device__ __forceinline__ void att_store_p_col4(char* P, int ncb, int row0, int col, f32x4 v, int rlo, int rhi) {
+  unsigned h0, m0, l0, h1, m1, l1;
+  att_split_pair(v[0], v[1], h0, m0, l0);
+  att_split_pair(v[2], v[3], h1, m1, l1);
+  char* q = att_p_slot(P, ncb, row0, col);
+  if (rlo == 0 && rhi == 4) {
+    *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(q + 128) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(q + 256) = make_uint2(l0, l1);
+    return;
+  }
+  const unsigned hs[2] = {h0, h1}, ms[2] = {m0, m1}, ls[2] = {l0, l1};
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    if (r >= rlo && r < rhi) {                             // rows of a neighbouring image in this slot are its workgroup's to write
+      const int sh = (r & 1) * 16;
+      *reinterpret_cast<unsigned short*>(q + 2 * r) = (unsigned short)(hs[r >> 1] >> sh);
+      *reinterpret_cast<unsigned short*>(q + 2 * r + 128) = (unsigned short)(ms[r >> 1] >> sh);
+      *reinterpret_cast<unsigned short*>(q + 2 * r + 256) = (unsigned short)(ls[r >> 1] >> sh);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// backward (one kernel: dq | dk | dv); P recomputed from lse
+// ------------------------------------------------------------------------------------------------------------------
+// PF: the output rows also leave as P-format planes oP (the operand of the projection GEMM).  The accumulators hold four CHANNELS
+// of one query per lane, a plane slot is four QUERIES of one channel: every wave transposes its 16 x 64 tile through a private LDS
+// patch (the stage buffers are free by then), 32 channels at a time.  As in the backward kernel the query tiles are laid from
+// position -(b N % 4), so that every four tile rows are one 4-row granule of the [B N] matrix.
+template <bool PF>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
-                                                               float* __restrict__ lse, int B, int N, int H, int dh, float scale) {
+                                                               float* __restrict__ lse, char* __restrict__ oP, int p_ncb, int B, int N,
+                                                               int H, int dh, float scale) {
   __shared__ __attribute__((aligned(16))) char smem[2 * AF_STAGE];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, head = blockIdx.x % H;
@@ -96,6 +133,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   const float* kbase = qbase + H * dh;
   const float* vbase = qbase + 2 * H * dh;
   const int nb = (N + AF_KB - 1) / AF_KB;
+  const int sft = PF ? (int)(((size_t)b * N) & 3) : 0;       // query tile position p <-> token p - sft (keys are not shifted)
 
   // staging items: idx < 512 -> K float4 (key = idx/16, d = 4*(idx%16)); 512 <= idx < 1024 -> V float4, same coordinates
   f32x4 sreg[2];
@@ -132,7 +170,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   stage_store(0);
 
   // this lane's query row (pre-scaled), d-slices [8g, 8g+8) and [32 + 8g, 32 + 8g + 8), as B-operand planes
-  const int q = w * ATT_T + c;
+  const int q = w * ATT_T + c - sft;
+  const bool qvalid = q >= 0 && q < N;
   att_bf16x8 qf[2][3];
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
@@ -141,7 +180,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
     for (int u = 0; u < 2; ++u) {
       const int d0 = 32 * ks + 8 * g + 4 * u;
       f32x4 v = zero4();
-      if (q < N && d0 < dh) v = *reinterpret_cast<const f32x4*>(qbase + (size_t)q * ldq + d0);
+      if (qvalid && d0 < dh) v = *reinterpret_cast<const f32x4*>(qbase + (size_t)q * ldq + d0);
 #pragma unroll
       for (int j = 0; j < 4; ++j) x[4 * u + j] = v[j] * scale;
     }
@@ -163,7 +202,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   }
   __syncthreads();
 
-  const bool active = w * ATT_T < N;
+  const bool active = w * ATT_T < N + sft;
   for (int kb = 0; kb < nb; ++kb) {
     const char* st = smem + (kb & 1) * AF_STAGE;
     if (kb + 1 < nb) stage_load(kb + 1);
@@ -235,49 +274,43 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   l += __shfl_xor(l, 16, 64);
   l += __shfl_xor(l, 32, 64);
   const float linv = 1.0f / l;
-  if (q < N) {
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) O[dt] *= linv;
+  if (qvalid) {
     if (g == 0) lse[((size_t)b * H + head) * N + q] = m_run + logf(l);
     // O[dt][r] = O^T[channel 16 dt + 4g + r][query c]: four consecutive channels of this lane's query
     float* op = out + ((size_t)b * N + q) * ldo + head * dh;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const int ch = 16 * dt + 4 * g;
-      if (ch < dh) *reinterpret_cast<f32x4*>(op + ch) = O[dt] * linv;
+      if (ch < dh) *reinterpret_cast<f32x4*>(op + ch) = O[dt];
     }
   }
-}
-
-// P-format stores (csrc/gemm_p.hip: granules of 4 rows x 16 columns, [plane][c % 16][r % 4] bf16, 384 B, stored [rows/4][ncb])
-__device__ __forceinline__ char* att_p_slot(char* P, int ncb, int row, int col) {
-  return P + ((size_t)(row >> 2) * ncb + (col >> 4)) * 384 + (col & 15) * 8 + (row & 3) * 2;
-}
-// four consecutive rows row0.. (row0 % 4 == 0: one 8-byte slot per plane) of one column; only rows [rlo, rhi) belong to the caller
-__device__ __forceinline__ void att_store_p_col4(char* P, int ncb, int row0, int col, f32x4 v, int rlo, int rhi) {
-  unsigned h0, m0, l0, h1, m1, l1;
-  att_split_pair(v[0], v[1], h0, m0, l0);
-  att_split_pair(v[2], v[3], h1, m1, l1);
-  char* q = att_p_slot(P, ncb, row0, col);
-  if (rlo == 0 && rhi == 4) {
-    *reinterpret_cast<uint2*>(q) = make_uint2(h0, h1);
-    *reinterpret_cast<uint2*>(q + 128) = make_uint2(m0, m1);
-    *reinterpret_cast<uint2*>(q + 256) = make_uint2(l0, l1);
-    return;
-  }
-  const unsigned hs[2] = {h0, h1}, ms[2] = {m0, m1}, ls[2] = {l0, l1};
+  if (PF) {
+    // wave-private patch [32 ch][16 q + 4] f32 in the (now free) stage buffers: 2.5 KB per wave
+    float* T = reinterpret_cast<float*>(smem) + w * (32 * 20);
+    const int row0 = (int)((size_t)b * N) - sft + w * ATT_T;                            // global row of tile position 0: row0 % 4 == 0
 #pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    if (r >= rlo && r < rhi) {                             // rows of a neighbouring image in this slot are its workgroup's to write
-      const int sh = (r & 1) * 16;
-      *reinterpret_cast<unsigned short*>(q + 2 * r) = (unsigned short)(hs[r >> 1] >> sh);
-      *reinterpret_cast<unsigned short*>(q + 2 * r + 128) = (unsigned short)(ms[r >> 1] >> sh);
-      *reinterpret_cast<unsigned short*>(q + 2 * r + 256) = (unsigned short)(ls[r >> 1] >> sh);
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+      for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T[(16 * dd + 4 * g + r) * 20 + c] = qvalid ? O[2 * half + dd][r] : 0.f;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int pass = 0; pass < 2; ++pass) {
+        const int chl = lane & 31, qg = 2 * pass + (lane >> 5), ch = 32 * half + chl, p0 = w * ATT_T + 4 * qg;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(&T[chl * 20 + 4 * qg]);
+        const int rlo = max(0, sft - p0), rhi = min(4, N + sft - p0);
+        if (ch < dh && rlo < rhi) att_store_p_col4(oP, p_ncb, row0 + 4 * qg, head * dh + ch, v, rlo, rhi);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
     }
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// backward (one kernel: dq | dk | dv); P recomputed from lse
-// ------------------------------------------------------------------------------------------------------------------
 // PF: dq | dk | dv leave the kernel as P-format planes (the operand form of the qkv gradient GEMMs, csrc/gemm_p.hip) together with
 // their per-image column sums colpart[b][3 H dh] (the qkv bias gradient is their sum over b) instead of as f32 rows.  A lane's
 // four accumulator rows are four consecutive tokens of one channel = one 8-byte plane slot IF they start on a 4-row granule
@@ -550,7 +583,25 @@ extern "C" int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32
   if (!ofb_aligned16(out) || ((H * dh) & 3)) return OFB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   ofb_prof_pre(1, s, 4.0 * B * H * (double)N * N * dh);
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3(B * H), dim3(ATT_THREADS), 0, s, qkv, out, lse, B, N, H, dh, scale);
+  hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(ATT_THREADS), 0, s, qkv, out, lse, (char*)nullptr, 0, B, N, H, dh, scale);
+  ofb_prof_post(1, s);
+  return ofb_launch_status();
+}
+
+// out as above AND the same rows as P-format planes out_p[B*N][H*dh] (the operand of the projection GEMM); the caller zeroes
+// out_p beforehand when B*N or H*dh is not a multiple of 16.  Needs N + (b N mod 4) <= 208.
+extern "C" int ofb_attention_fwd_p(const float* qkv, float* out, void* out_p, float* lse, int32_t B, int32_t N, int32_t H, int32_t dh,
+                                   float scale, void* stream) {
+  if (!qkv || !out || !out_p || !lse) return OFB_EINVAL;
+  if (int rc = check_shape(B, N, H, dh)) return rc;
+  if (!ofb_aligned16(qkv) || !ofb_aligned16(out) || !ofb_aligned16(out_p) || ((H * dh) & 3)) return OFB_EINVAL;
+  int smax = 0;
+  for (int bb = 0; bb < B && bb < 4; ++bb) smax = ((bb * N) & 3) > smax ? ((bb * N) & 3) : smax;
+  if (N + smax > ATT_NMAX) return OFB_ELIMIT;
+  hipStream_t s = (hipStream_t)stream;
+  ofb_prof_pre(1, s, 4.0 * B * H * (double)N * N * dh);
+  hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(ATT_THREADS), 0, s, qkv, out, lse, (char*)out_p, (H * dh + 15) / 16, B, N, H, dh,
+                     scale);
   ofb_prof_post(1, s);
   return ofb_launch_status();
 }

@@ -42,7 +42,7 @@ ENGINE = os.environ.get('OFB_GEMM_ENGINE', 'p')
 SYMBOLS = [
     'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum',
-    'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
+    'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_fwd_p', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
     'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
@@ -455,6 +455,14 @@ def gate_fold_bwd(dWraw, W, g, dbraw, b, dW, db, dg, N, K):
 def attention_fwd(qkv, out, lse, B, N, H, dh, scale):
     check(lib().ofb_attention_fwd(ptr(qkv), ptr(out), ptr(lse), _i(B), _i(N), _i(H), _i(dh), _f(scale), stream()),
           'ofb_attention_fwd')
+
+
+def attention_fwd_p(qkv, out, outP, lse, B, N, H, dh, scale):
+    """forward that also writes the output as P-format planes (PMat [B*N][H*dh])"""
+    if outP.R != B * N or outP.C != H * dh:
+        raise OfbError('attention_fwd_p: output shapes')
+    check(lib().ofb_attention_fwd_p(ptr(qkv), ptr(out), ptr(outP.buf), ptr(lse), _i(B), _i(N), _i(H), _i(dh), _f(scale), stream()),
+          'ofb_attention_fwd_p')
 
 
 def attention_bwd(qkv, out, lse, dout, dqkv, B, N, H, dh, scale):

@@ -323,6 +323,12 @@ def layer_norm_fork(x, gamma, beta, eps):
     return _ln_apply(x, gamma, beta, eps, True)
 
 
+def _att_planes_ok(B, N):
+    """the plane-writing attention kernels lay their 16-token tiles from position -(b N mod 4): N plus the largest shift must fit
+    the 208 tile positions"""
+    return N + max((b * N) & 3 for b in range(min(B, 4))) <= 208
+
+
 class AttnBranch(torch.autograd.Function):
     """out = resid + rowscale[token] * proj(attention(g * qkv(x)))   (layers.py:488-517 + residual/DropPath of
     vision_transformer.py:197,203).  If `resid` is None the branch input is also the residual (the search
@@ -343,8 +349,12 @@ class AttnBranch(torch.autograd.Function):
             Hd = qkv.shape[1] // 3
             dh = Hd // heads
             o, lse = _new(x, M, Hd), _new(x, B * heads, N)
-            hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
-            oP = hip.to_pformat(o, M, Hd, Hd)
+            if _att_planes_ok(B, N):                       # the attention kernel writes the projection's operand planes too
+                oP = hip.PMat.for_rows_written_by_kernel(M, Hd, x.device)
+                hip.attention_fwd_p(qkv, o, oP, lse, B, N, heads, dh, scale)
+            else:
+                hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
+                oP = hip.to_pformat(o, M, Hd, Hd)
             out, _ = p_linear_fwd(oP, M, Hd, wpP, bproj, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
             ctx.save_for_backward(xP.buf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, oP.buf)
             ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None)
@@ -401,13 +411,17 @@ def _attn_backward_p(ctx, dout):
     with (hip.side_work(d2.device, keep=[d2sP.buf, oP.buf]) if _side_ok(wproj, tokens=M) else _nullctx()):
         p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=dwp)
     # dq | dk | dv leave the attention kernel as planes, with the per-image column sums the qkv bias gradient is made of
-    dqkvP = hip.PMat.for_rows_written_by_kernel(M, 3 * Hd, d2.device)
-    colpart = _new(d2, B, 3 * Hd)
-    hip.attention_bwd_p(qkv, o, lse, do, dqkvP, colpart, B, N, heads, dh, scale)
-    dbq_raw = None
-    if bqkv is not None:
-        dbq_raw = _new(d2, 3 * Hd)
-        hip.colsum(colpart, 3 * Hd, B, 3 * Hd, dbq_raw)
+    dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
+    if _att_planes_ok(B, N):
+        dqkvP = hip.PMat.for_rows_written_by_kernel(M, 3 * Hd, d2.device)
+        colpart = _new(d2, B, 3 * Hd)
+        hip.attention_bwd_p(qkv, o, lse, do, dqkvP, colpart, B, N, heads, dh, scale)
+        if dbq_raw is not None:
+            hip.colsum(colpart, 3 * Hd, B, 3 * Hd, dbq_raw)
+    else:                                                   # sequence too long for the shifted tile origin: f32 rows + a conversion pass
+        dqkv = torch.empty_like(qkv)
+        hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
+        dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw)
     dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None)
     dg = None
     if dg3 is not None:                                   # dg3 may still be in flight on the side stream: add it up there

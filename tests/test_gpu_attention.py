@@ -38,6 +38,12 @@ def test_attention_fwd_bwd(B, N, H, dh):
     e_l = (lse.cpu().double() - lse_ref).abs().max().item()
     print(f'attn fwd B{B} N{N} H{H} d{dh}: out err {e_o:.2e} lse err {e_l:.2e}')
     assert e_o < 2e-5 and e_l < 2e-5
+    # the P-format form of the output: planes == the kernel's own f32 rows; image 0 (no tile shift) == the plain kernel bit for bit
+    o2, lse2 = torch.full_like(o, float('nan')), torch.full_like(lse, float('nan'))
+    oP = hip.PMat.for_rows_written_by_kernel(B * N, H * dh, 'cuda')
+    hip.attention_fwd_p(qd, o2, oP, lse2, B, N, H, dh, scale)
+    assert torch.equal(oP.to_f32(), o2) and torch.equal(o2[:N], o[:N]) and torch.equal(lse2[:H], lse[:H])
+    assert (o2.cpu().double() - o_ref).abs().max().item() < 2e-5 and (lse2.cpu().double() - lse_ref).abs().max().item() < 2e-5
     dqkv = torch.full((B * N, 3 * H * dh), float('nan'), device='cuda')
     hip.attention_bwd(qd, o, lse, dout.cuda(), dqkv, B, N, H, dh, scale)
     err = (dqkv.cpu().double() - dqkv_ref).abs()
@@ -88,3 +94,30 @@ def test_attention_rejects_unsupported():
         hip.attention_fwd(t, t, t, 1, 300, 1, 64, 0.125)     # N > 208
     with pytest.raises(hip.OfbError):
         hip.attention_fwd(t, t, t, 1, 100, 1, 30, 0.125)     # dh % 4 != 0
+
+
+@pytest.mark.parametrize('B,N', [(3, 197), (2, 207), (2, 50)])
+def test_attention_branch_planes_and_fallback(B, N):
+    """ops.attn_branch end to end (qkv GEMM, attention, projection, residual) against fp64 autograd: N = 197 takes the kernels that
+    write P-format planes (shifted tile origin), N = 207 with two images does not fit the shift and takes the f32 + conversion path"""
+    from ofb_amd import ops
+    H, dh, D = 2, 32, 64
+    g = torch.Generator().manual_seed(N)
+    x = torch.randn(B, N, D, generator=g)
+    wq, bq = torch.randn(3 * H * dh, D, generator=g) * 0.1, torch.randn(3 * H * dh, generator=g) * 0.1
+    wp, bp = torch.randn(D, H * dh, generator=g) * 0.1, torch.randn(D, generator=g) * 0.1
+    dout = torch.randn(B, N, D, generator=g)
+    assert ops._att_planes_ok(B, N) == (N != 207)
+    tens = [t.cuda().requires_grad_(True) for t in (x, wq, bq, wp, bp)]
+    out = ops.attn_branch(tens[0], None, tens[1], tens[2], tens[3], tens[4], None, None, H, dh ** -0.5)
+    out.backward(dout.cuda())
+    ref = [t.double().requires_grad_(True) for t in (x, wq, bq, wp, bp)]
+    qkv = (ref[0] @ ref[1].t() + ref[2]).reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(qkv[0] @ qkv[1].transpose(-2, -1) * dh ** -0.5, -1) @ qkv[2]
+    o_ref = ref[0] + att.transpose(1, 2).reshape(B, N, H * dh) @ ref[3].t() + ref[4]
+    o_ref.backward(dout.double())
+    assert (out.detach().cpu().double() - o_ref.detach()).abs().max().item() < 1e-5
+    for t, r, name in zip(tens, ref, ('dx', 'dWqkv', 'dbqkv', 'dWproj', 'dbproj')):
+        err = (t.grad.cpu().double() - r.grad).abs().max().item() / (r.grad.abs().max().item() + 1e-30)
+        print(f'  {name}: rel err {err:.2e}')
+        assert err < 2e-5, name
