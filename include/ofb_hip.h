@@ -108,9 +108,10 @@ int64_t ofb_pformat_bytes(int32_t R, int32_t C);
 /* X[R][C] (row-major, ld), optionally * rowscale[r / rs_div]  ->  P-format (zero padded).  Used for tensors whose producer is
  * not one of the kernels below (weights once per optimizer step, DropPath-scaled gradients, patchified pixels). */
 int ofb_to_pformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div, void* stream);
-/* Many conversions in one launch (the model's weights, once per optimizer step): jobs_dev[n_jobs] in device memory, each
- * {X (f32 [R][C], row stride ld), P (ofb_pformat_bytes(R, C) bytes), R, C, ld}; max_R / max_C = the largest R / C among them. */
-typedef struct ofb_pformat_job { const float* X; void* P; int32_t R, C, ld, pad_; } ofb_pformat_job;
+/* Many conversions in one launch (the model's weights, once per optimizer step; the gate-scaled weights of one backward pass):
+ * jobs_dev[n_jobs] in device memory, each {X (f32 [R][C], row stride ld), P (ofb_pformat_bytes(R, C) bytes), rowscale (optional:
+ * row r is multiplied by rowscale[r]), R, C, ld}; max_R / max_C = the largest R / C among them. */
+typedef struct ofb_pformat_job { const float* X; void* P; const float* rowscale; int32_t R, C, ld, pad_; } ofb_pformat_job;
 int ofb_to_pformat_multi(const ofb_pformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, void* stream);
 /* the same pass also leaves partial[ofb_colsum_p_slabs(R)][ceil(C/16)*16] = column sums per 256-row slab (sum them with ofb_colsum):
  * a bias gradient db = colsum(dY) rides on the conversion of dY */

@@ -114,7 +114,9 @@ __global__ void to_pformat_multi_kernel(const ofb_pformat_job* __restrict__ jobs
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int r = 4 * rg + t;
-    v[t] = (r < j.R && c < j.C) ? j.X[(size_t)r * j.ld + c] : 0.f;
+    float x = (r < j.R && c < j.C) ? j.X[(size_t)r * j.ld + c] : 0.f;
+    if (j.rowscale && r < j.R) x *= j.rowscale[r];
+    v[t] = x;
   }
   store_p4((char*)j.P + ((size_t)rg * ncb + (c >> 4)) * GRAN + (c & 15) * 8, v[0], v[1], v[2], v[3]);
 }

@@ -270,10 +270,12 @@ _weight_epoch = 0
 def bump_weight_epoch():
     global _weight_epoch
     _weight_epoch += 1
+    _gw_jobs.clear()
 
 
 class PformatJob(C.Structure):
-    _fields_ = [('X', C.c_void_p), ('P', C.c_void_p), ('R', C.c_int32), ('C', C.c_int32), ('ld', C.c_int32), ('pad_', C.c_int32)]
+    _fields_ = [('X', C.c_void_p), ('P', C.c_void_p), ('rowscale', C.c_void_p), ('R', C.c_int32), ('C', C.c_int32), ('ld', C.c_int32),
+                ('pad_', C.c_int32)]
 
 
 # Every weight that has ever been asked for in P-format is registered (weak reference + its persistent plane buffer).  The first
@@ -306,7 +308,7 @@ def _wp_refresh_all(device):
     if _wp_table[0] != key:
         tab = (PformatJob * len(jobs))()
         for t, (x, pp, R, Cc) in zip(tab, jobs):
-            t.X, t.P, t.R, t.C, t.ld = x, pp, R, Cc, Cc
+            t.X, t.P, t.rowscale, t.R, t.C, t.ld = x, pp, None, R, Cc, Cc
         dev_tab, host = upload_structs(tab, device)
         _wp_table[:] = [key, (dev_tab, host), max(j[2] for j in jobs), max(j[3] for j in jobs)]
     check(lib().ofb_to_pformat_multi(ptr(_wp_table[1][0]), _i(len(jobs)), _i(_wp_table[2]), _i(_wp_table[3]), stream()),
@@ -351,6 +353,55 @@ def weight_p(W, shape2d=None):
         pm = to_pformat(W, N, K, K)
         W._ofb_wp = (_weight_epoch, W._version, pm, tuple(W.shape))
     return W._ofb_wp[2]
+
+
+# Gate-scaled weights g[n] * W[n][:] (the B operand of the gated layers' input-gradient products): the forward registers each
+# (W, gate vector) pair, the first request in backward converts ALL pending pairs in one multi-tensor launch into per-weight
+# persistent planes.  Entries live until the next optimizer step (bump_weight_epoch).
+_gw_jobs = []                # (W, gvec, N, K)
+_gw_table = [None, None, 0, 0]
+
+
+def gated_register(W, gvec, N, K):
+    if _WP_MULTI:
+        _gw_jobs.append((W, gvec, int(N), int(K)))
+
+
+def _gw_fresh(W, gvec):
+    ent = getattr(W, '_ofb_gwp', None)
+    return (ent is not None and ent[0] == _weight_epoch and ent[1] == W._version and ent[2] == gvec.data_ptr() and
+            ent[3] == gvec._version)
+
+
+def gated_weight_p(W, gvec, N, K):
+    """P-format planes of gvec[n] * W[n][:] for W viewed as [N][K]"""
+    base = W._base
+    if base is not None and base.is_contiguous() and base.numel() == W.numel() and base.data_ptr() == W.data_ptr():
+        W = base                                         # a reshaping view of the Parameter the forward registered
+    if not _WP_MULTI or not W.is_contiguous():
+        return to_pformat(W, N, K, K, rowscale=gvec)
+    if _gw_fresh(W, gvec) and (W._ofb_gwp[4].R, W._ofb_gwp[4].C) == (N, K):
+        return W._ofb_gwp[4]
+    todo, seen = [], set()
+    for (W_, g_, N_, K_) in _gw_jobs + [(W, gvec, int(N), int(K))]:
+        if id(W_) in seen or W_.device != W.device or _gw_fresh(W_, g_):
+            continue
+        seen.add(id(W_))
+        ent = getattr(W_, '_ofb_gwp', None)
+        pm = ent[4] if ent is not None and (ent[4].R, ent[4].C) == (N_, K_) else PMat(N_, K_, W_.device)
+        todo.append((W_, g_, N_, K_, pm))
+    key = tuple((w_.data_ptr(), g_.data_ptr(), pm.buf.data_ptr(), n_, k_) for (w_, g_, n_, k_, pm) in todo)
+    if _gw_table[0] != key:
+        tab = (PformatJob * len(todo))()
+        for t, (w_, g_, n_, k_, pm) in zip(tab, todo):
+            t.X, t.P, t.rowscale, t.R, t.C, t.ld = w_.data_ptr(), pm.buf.data_ptr(), g_.data_ptr(), n_, k_, k_
+        dev_tab, host = upload_structs(tab, W.device)
+        _gw_table[:] = [key, (dev_tab, host), max(j[2] for j in todo), max(j[3] for j in todo)]
+    check(lib().ofb_to_pformat_multi(ptr(_gw_table[1][0]), _i(len(todo)), _i(_gw_table[2]), _i(_gw_table[3]), stream()),
+          'ofb_to_pformat_multi')
+    for (w_, g_, n_, k_, pm) in todo:
+        w_._ofb_gwp = (_weight_epoch, w_._version, g_.data_ptr(), g_._version, pm)
+    return W._ofb_gwp[4]
 
 
 def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,

@@ -141,7 +141,7 @@ def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None):
         with (hip.side_work(W.device, keep=[dyP.buf, xP.buf]) if side else _nullctx()):
             p_linear_bwd_weight(dyP, xP, M, N, K, out=dW)
         return dx, dW, (dy_colsum() if b is not None else None), None
-    WeffP = hip.to_pformat(W, N, K, K, rowscale=gvec)                    # g[n] * W[n][:] straight into planes
+    WeffP = hip.gated_weight_p(W, gvec, N, K)                            # g[n] * W[n][:] as planes (all gated layers in one launch)
     dx, _ = p_linear_bwd_input(dyP, M, N, WeffP, K, resid=resid)
     dbraw = dy_colsum() if b is not None else None
     dW = slot if slot is not None else _new(W, N, K)
@@ -346,6 +346,8 @@ class AttnBranch(torch.autograd.Function):
             xP, wqP, wpP = _P(x, M, D), hip.weight_p(wqkv), hip.weight_p(wproj)
             ctx.wp = (wqP, wpP)
             qkv, _ = p_linear_fwd(xP, M, D, wqP, bqkv, colscale=g3)
+            if g3 is not None:
+                hip.gated_register(wqkv, g3, wqkv.shape[0], D)
             Hd = qkv.shape[1] // 3
             dh = Hd // heads
             o, lse = _new(x, M, Hd), _new(x, B * heads, N)
@@ -455,6 +457,8 @@ class MlpBranch(torch.autograd.Function):
             # GELU'(pre-activation) is kept in f32 (`hpre` holds the derivative here): the epilogue has Phi and phi in hand, and the
             # backward epilogue becomes a single multiply
             _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU_GRAD, aux=hpre, want_f32=False, want_p=True)
+            if gv is not None:
+                hip.gated_register(w1, gv, hid, D)
             out, _ = p_linear_fwd(hP, M, hid, w2P, b2, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
             ctx.save_for_backward(xP.buf, hpre, hP.buf, w1, b1, w2, gv, rowscale)
             ctx.meta = (B, N, D, resid is None, b2 is not None)
