@@ -100,9 +100,11 @@ typedef struct ofb_gemm_p_args {
   float* aux; int32_t ldaux;
   int32_t act;
   float* workspace; int64_t workspace_bytes;
-  float* colpart;            /* optional [ceil(M/128)][N]: column sums of the OUTPUT per 128-row tile, summed in a fixed order (the bias
-                                gradient of a P-format-only result, e.g. d(pre-activation) of fc1; add the rows with ofb_colsum) */
+  float* colpart;            /* optional [ofb_gemm_p_colpart_rows(args)][N]: partial column sums of the OUTPUT (one row per 128-row tile
+                                row; 32 rows per tile row that runs in the streamed tail), each summed in a fixed order: the bias
+                                gradient of a P-format-only result, e.g. d(pre-activation) of fc1; add the rows with ofb_colsum */
 } ofb_gemm_p_args;
+int32_t ofb_gemm_p_colpart_rows(const ofb_gemm_p_args* args);
 
 int64_t ofb_pformat_bytes(int32_t R, int32_t C);
 /* X[R][C] (row-major, ld), optionally * rowscale[r / rs_div]  ->  P-format (zero padded).  Used for tensors whose producer is

@@ -625,6 +625,10 @@ __global__ __launch_bounds__(CF::BN) void gemm_p_fixup_kernel(const ofb_gemm_p_a
   }
   if (g.Cp && row0 < ((g.M + 15) & ~15) && col < g.c_ncb * 16)
     store_p4((char*)g.Cp + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8, pv[0], pv[1], pv[2], pv[3]);
+  // column sums of the output: the tail is the last R / nt whole tile rows (plan_p); their sums go, one row per 4-row slice, behind
+  // the rows that the data-parallel tiles write (one per tile row): colpart[(mt - R/nt) + (r / nt) * (BM/4) + slice][N]
+  if (g.colpart && colok)
+    g.colpart[((size_t)(p.mt - p.R / p.nt) + (size_t)(r / p.nt) * (BM / 4) + rgl) * g.N + col] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
 }
 
 int p_cu_count() {
@@ -669,8 +673,8 @@ Plan plan_p(const ofb_gemm_p_args& g) {
   // through HBM (~0.019 steps per 96-KB partial at 4.5 TB/s) plus the extra launches (~3.5 steps); one more (partly idle)
   // data-parallel round costs I steps.  The split-major piece count S is chosen to minimise that sum (short tails: few large
   // pieces; weight gradients: one piece per workgroup); the tail must beat the round by 10 % to be worth its HBM traffic.
-  if (p.R > 0 && g.colpart) {                                        // per-tile column sums come from the fused epilogue only
-    p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;
+  if (p.R > 0 && g.colpart && p.R % p.nt != 0) {                     // column sums of tail tiles come from the fix-up kernel, which
+    p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;         // addresses them per whole tile row (colpart layout below)
   }
   if (p.R > 0) {
     const double PC = 0.019, FIX = 3.5;
@@ -798,6 +802,16 @@ extern "C" int64_t ofb_gemm_p_workspace_bytes(const ofb_gemm_p_args* args) {
 #endif
   const Plan p = plan_p<C128>(*args);
   return p.R ? (int64_t)2 * p.W * C128::BM * C128::BN * (int64_t)sizeof(float) : 0;
+}
+
+// rows of the colpart buffer a call with these arguments (colpart given) fills: one per 128-row tile row that runs data-parallel,
+// BM/4 per tile row of the streamed tail
+extern "C" int32_t ofb_gemm_p_colpart_rows(const ofb_gemm_p_args* args) {
+  if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+  ofb_gemm_p_args g = *args;
+  if (!g.colpart) g.colpart = reinterpret_cast<float*>(16);
+  const Plan p = plan_p<C128>(g);
+  return p.R ? (p.mt - p.R / p.nt) + (p.R / p.nt) * (C128::BM / 4) : p.mt;
 }
 
 extern "C" int ofb_gemm_p(const ofb_gemm_p_args* args, void* stream) {

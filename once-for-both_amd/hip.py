@@ -40,7 +40,7 @@ ENGINE = os.environ.get('OFB_GEMM_ENGINE', 'p')
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_gemm_p_colpart_rows', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_fwd_p', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
@@ -420,7 +420,8 @@ def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bia
     g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
     part = None
     if colsum_out is not None:
-        part = torch.empty((M + 127) // 128, N, device=A.buf.device, dtype=torch.float32)
+        rows = int(lib().ofb_gemm_p_colpart_rows(C.byref(g)))
+        part = torch.empty(rows, N, device=A.buf.device, dtype=torch.float32)
         g.colpart = ptr(part)
     lib().ofb_gemm_p_workspace_bytes.restype = C.c_int64
     need = lib().ofb_gemm_p_workspace_bytes(C.byref(g))

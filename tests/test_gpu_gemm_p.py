@@ -129,6 +129,15 @@ def test_gemm_p_deit_small_layer_shapes():
         out = torch.empty(M, N, device='cuda')
         hip.gemm_p(xp, hip.to_pformat(w.cuda()), 1, 1, M, N, D, C_out=out, ldc=N, bias=b.cuda())
         _close(out[rows.cuda()], x[rows].double() @ w.double().t() + b.double(), f'deit-s N {N}')
+    # the fc2 input-gradient form at full size: 1576 tiles = 3 rounds + 5 whole tile rows in the streamed tail; the column sums of the
+    # P-format-only output come from both (fused epilogue of the rounds, fix-up kernel of the tail)
+    N = 1536
+    w, aux = _mk((N, D), 15, 0.05), _mk((M, N), 16)
+    dp, cs = hip.PMat(M, N, 'cuda'), torch.full((N,), float('nan'), device='cuda')
+    hip.gemm_p(xp, hip.to_pformat(w.cuda()), 1, 1, M, N, D, Cp=dp, aux=aux.cuda(), ldaux=N, act=hip.ACT_MULAUX, colsum_out=cs)
+    got = dp.to_f32()
+    _close(got[rows.cuda()], (x[rows].double() @ w.double().t()) * aux[rows].double(), 'value x aux, planes out, full size')
+    _close(cs, got.double().sum(0).cpu(), 'column sums over rounds + tail', tol=2e-6)
     # weight gradient: dW[N][K] = dY^T X over all tokens (12 tiles, K = 25216: tail only)
     dy = _mk((M, 1536), 14)
     dw = torch.empty(1536, D, device='cuda')
