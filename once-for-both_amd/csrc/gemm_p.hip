@@ -388,8 +388,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
         young = young < 0 ? 0 : (young > NST - 2 ? NST - 2 : young);
         vm_wait(young * n_w);
       }
+#ifndef OFB_P_ABL_NOBAR
       __builtin_amdgcn_s_barrier();
+#endif
+#ifndef OFB_P_ABL_NODMA
       if (i + NST < nk) issue(buf, a_base + (size_t)(i + NST) * a_step, b_base + (size_t)(i + NST) * b_step);
+#endif
       // second half: upper row blocks x B(i); the reads of step i+1 (lower row blocks and B) ride in the gaps (after the last
       // step they fetch a stale buffer that nothing consumes)
       __builtin_amdgcn_sched_barrier(0);
