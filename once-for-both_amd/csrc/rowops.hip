@@ -492,7 +492,7 @@ extern "C" int ofb_layernorm_bwd_p(const float* dy, const float* x, const float*
 }
 
 extern "C" int32_t ofb_colsum_slabs(int32_t M, int32_t N) {
-  if (M <= 256) return 1;               // short inputs (second stages, per-block partials): one launch, no scratch
+  if (M <= 512) return 1;               // short inputs (second stages, per-tile / per-block partials): one launch, no scratch
   const int colblocks = ofb_cdiv(N, 64);
   int slabs = ofb_cdiv(2048, colblocks);
   if (slabs > ofb_cdiv(M, 16)) slabs = ofb_cdiv(M, 16);
