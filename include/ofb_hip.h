@@ -32,48 +32,18 @@ extern "C" {
 #define OFB_ACT_MULAUX 4    /* C <- value * aux[m][n]                                         */
 
 /* ---------------------------------------------------------------------------------------------
- * Dense f32 contraction on the bf16 matrix pipe (v_mfma_f32_32x32x16_bf16, six terms of an exact 3-way operand split, f32
- * accumulation: fp32-class accuracy, tests/test_gpu_accuracy_class.py): C[M,N] = A[M,K] * B[K,N], then
- *   v = alpha*acc (+bias[n]) (*colscale[n]); act; (*rowscale[m / rs_div]); (+resid[m*ldr+n]).
- * a_kc / b_kc = 1: operand stored K-contiguous (A[m*lda+k], B[n*ldb+k]); 0: stored
- * MN-contiguous (A[k*lda+m], B[k*ldb+n]).  So (1,1) is x @ W^T (nn.Linear forward,
- * models/layers.py:491,515,845,863; Conv2d patch embed :177; decoder 1x1 conv
- * vision_transformer.py:723; head :744), (1,0) is dY @ W (input gradient) and (0,0) is
- * dY^T @ X (weight gradient, reduction over tokens) of the same Linear layers.
- * kscale (a_kc == 0 only): A's reduction rows are scaled by kscale[k / ks_div] (per-sample
- * DropPath factor inside a weight gradient).
- * Scheduling is hybrid stream-K over persistent workgroups (see csrc/gemm.hip): the tiles that do not fill a whole
- * round of workgroups are cut along K and summed (fixed order, deterministic) by a fix-up launch, so long-K
- * weight gradients and ragged tile counts both keep every CU busy.  `workspace` must hold
- * ofb_gemm_workspace_bytes(args) bytes (0 when no tile is streamed); it may be shared by successive calls on
- * one stream.
- * ------------------------------------------------------------------------------------------- */
-typedef struct ofb_gemm_args {
-  const float* A; const float* B; float* C;
-  int32_t M, N, K;
-  int32_t lda, ldb, ldc;
-  int32_t a_kc, b_kc;
-  float alpha;
-  const float* bias;
-  const float* colscale;
-  const float* rowscale; int32_t rs_div;
-  const float* resid; int32_t ldr;
-  float* aux; int32_t ldaux;
-  int32_t act;
-  const float* kscale; int32_t ks_div;
-  float* workspace; int64_t workspace_bytes;
-  float* a_colsum;          /* a_kc == 0 only: a_colsum[m] = sum_k A[k][m] (*kscale): the bias gradient fused into a weight-gradient
-                               launch; valid only when ofb_gemm_is_streamed(args) (few output tiles), else OFB_ELIMIT */
-} ofb_gemm_args;
-
-int64_t ofb_gemm_workspace_bytes(const ofb_gemm_args* args);
-int32_t ofb_gemm_is_streamed(const ofb_gemm_args* args);   /* 1 when every output tile goes through the stream-K tail */
-int ofb_gemm_f32(const ofb_gemm_args* args, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * The same contraction on operands that are ALREADY split into three bf16 planes ("P-format", csrc/gemm_p.hip): the exact
- * split x = hi + mid + lo that gives the bf16 matrix pipe fp32 accuracy is done ONCE by the producer of each tensor instead
- * of inside every GEMM tile that touches it, and the K loop is LDS-DMA + fragment reads + MFMAs only.
+ * Dense f32 contraction on the bf16 matrix pipe (csrc/gemm_p.hip; v_mfma_f32_32x32x16_bf16, six product terms of an exact 3-way
+ * operand split x = hi + mid + lo, f32 accumulation: fp32-class accuracy, tests/test_gpu_accuracy_class.py):
+ *   C[M,N] = A[M,K] * B[K,N], then  v = alpha*acc (+bias[n]) (*colscale[n]); act; (*rowscale[m / rs_div]); (+resid[m*ldr+n]).
+ * The operands arrive ALREADY split into three bf16 planes ("P-format"): the split is done ONCE by the producer of each tensor
+ * (LayerNorm, attention, GEMM epilogues, ofb_to_pformat* for everything else) instead of inside every GEMM tile that touches it,
+ * and the K loop is LDS-DMA + fragment reads + MFMAs only.  Every nn.Linear / Conv2d-as-GEMM of the path and its autograd runs
+ * here: x @ W^T (models/layers.py:491,515,845,863; patch embed :177; decoder 1x1 conv vision_transformer.py:723; head :744),
+ * dY @ W (input gradient) and dY^T @ X (weight gradient, reduction over tokens).  (The round-1 entry point that split f32
+ * operands inside the loop, ofb_gemm_f32, left the library in round 3: scripts/lab/gemm_split_engine_r1.hip.)
+ * Scheduling is hybrid stream-K over persistent workgroups (csrc/gemm_plan.h): tiles that do not fill a whole round of
+ * workgroups are cut along K and summed in a fixed order by a fix-up launch (deterministic).  `workspace` must hold
+ * ofb_gemm_p_workspace_bytes(args) bytes (0 when no tile is streamed); successive calls on ONE stream may share it.
  *
  * P-format of X[R][C]: granules of 4 rows x 16 columns (384 B), stored [ceil(R/16)*4][ncb = ceil(C/16)]; a granule holds
  * [plane hi|mid|lo][c % 16][r % 4] bf16.  Rows >= R / columns >= C inside the last granules are ZERO (the reduction axis
@@ -83,7 +53,7 @@ int ofb_gemm_f32(const ofb_gemm_args* args, void* stream);
  * models/layers.py:491,515,845,863); 0: along its rows R (W[K..][N] in dY @ W; dY[tokens][N], x[tokens][K] in dY^T @ x).
  * So the SAME P-format copy of an activation or weight feeds its forward, input-gradient and weight-gradient products.
  * Output: f32 C (ldc) and / or P-format Cp ([R = M][C = N], c_ncb granule columns) - e.g. gelu(fc1) leaves the kernel as the
- * P-format operand of fc2 plus the f32 pre-activation in aux.  Epilogue as ofb_gemm_f32.  Deterministic (fixed-order fix-up).
+ * P-format operand of fc2 plus the f32 pre-activation in aux.  Deterministic (fixed-order fix-up).
  * ------------------------------------------------------------------------------------------- */
 typedef struct ofb_gemm_p_args {
   const void* A; const void* B;
@@ -252,15 +222,17 @@ typedef struct ofb_flops_cfg {
   const int32_t* live_slot;  /* [1+2*depth] device array or null */
   const float* wconst;       /* [1+2*depth] device array or null */
   int32_t n_live;            /* entries of wsum / dwsum (1+2*depth when live_slot is null) */
+  const float* active_patches;   /* device scalar: the searched model's patch count (vision_transformer.py:768: weighted_mask.sum()
+                                    once a patch-cell compress() has run, :789-820) or null (= num_patches) */
 } ofb_flops_cfg;
 
 /* spars_out[3] = {attn, mlp, embed} sums, spars_per_module[n_modules]; max_elems = max H*C over modules. */
 int ofb_gates_fwd(const ofb_gate_desc* descs_dev, int32_t n_modules, int32_t max_elems, int32_t entropy, int32_t var,
                   int32_t norm, float* spars_out, float* spars_per_module, void* stream);
 int ofb_gates_bwd(const ofb_gate_desc* descs_dev, const ofb_gate_grad* grads_dev, int32_t n_modules, void* stream);
-/* wsum[n_live] = staircase sums of the live modules in {embed, attn_0, mlp_0, ...} order; out3 =
- * {((searched-target)/total)^2, total, searched}; dwsum[n_live] = d out3[0] / d wsum. */
-int ofb_flops_loss(const float* wsum, const ofb_flops_cfg* cfg, float* out3, float* dwsum, void* stream);
+/* wsum[n_live] = staircase sums of the live modules in {embed, attn_0, mlp_0, ...} order; out4 =
+ * {((searched-target)/total)^2, total, searched, d out4[0] / d active_patches}; dwsum[n_live] = d out4[0] / d wsum. */
+int ofb_flops_loss(const float* wsum, const ofb_flops_cfg* cfg, float* out4, float* dwsum, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Token assembly after the patch-embedding conv (models/vision_transformer.py:615-651, gate of
@@ -322,21 +294,35 @@ int ofb_index_select(const float* src, const int32_t* idx, float* dst, int64_t o
 /* hipMemcpyAsync(host -> device) of a small pointer table from PINNED host memory on `stream` (capturable: a memcpy node) */
 int ofb_upload(void* dst_dev, const void* src_pinned, int64_t nbytes, void* stream);
 
-/* Multi-tensor AdamW, one launch per parameter group (optim.py:56-120): decoupled decay, bias-corrected Adam. */
+/* Non-finite loss watch (engine.py:146-150: the reference reads the loss on the host every micro-step and exits BEFORE backward when
+ * it is not finite).  This path never syncs per step: ofb_nonfinite_watch adds 1 to the device counter flag[0] when any of the n
+ * values is NaN / +-inf, and the parameter-changing kernels below (AdamW, EMA) take that counter as `skip`: once it is non-zero
+ * they leave every tensor untouched, so no optimizer / EMA update is ever applied after a non-finite loss; the host reads the
+ * counter at its print points and stops. */
+int ofb_nonfinite_watch(const float* values, int32_t n, int32_t* flag, void* stream);
+
+/* Multi-tensor AdamW, one launch per parameter group (optim.py:56-120): decoupled decay, bias-corrected Adam.
+ * skip (optional, device): when *skip != 0 the launch changes nothing (see ofb_nonfinite_watch). */
 typedef struct ofb_adamw_tensor { float* p; const float* g; float* m; float* v; int64_t n; } ofb_adamw_tensor;
 int ofb_adamw_step(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float lr, float beta1, float beta2,
-                   float eps, float weight_decay, int32_t step, void* stream);
+                   float eps, float weight_decay, int32_t step, const int32_t* skip, void* stream);
 /* The same update with hyper_dev[3] = {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step)} read from device memory: the form a step
  * captured in a hipGraph replays (the host refreshes the three floats before each replay). */
 int ofb_adamw_step_dev(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, const float* hyper_dev, float beta1,
-                       float beta2, float eps, float weight_decay, void* stream);
+                       float beta2, float eps, float weight_decay, const int32_t* skip, void* stream);
+
+/* dst[i] = src[i] (src != NULL) or 0 for every job, ONE launch: the small gradients (biases, LayerNorm, alpha / score) and the
+ * zero fill of absent ones on their way into a flat all-reduce bucket - the per-parameter copies DistributedDataParallel makes
+ * when it wraps the model (search.py:617-620). */
+typedef struct ofb_copy_job { const float* src; float* dst; int64_t n; } ofb_copy_job;
+int ofb_multi_copy(const ofb_copy_job* jobs_dev, int32_t n_jobs, int64_t max_n, void* stream);
 
 /* Multi-tensor weight EMA (utils.py:430-441 `ema_v.copy_(ema_v * decay + (1 - decay) * model_v)`), one launch for the
  * whole state_dict; products and the sum are rounded separately (no FMA contraction) so the result is bit-identical to
  * the reference's three elementwise ops.  one_minus_decay = (float)(1.0 - (double)decay), as Python computes it. */
 typedef struct ofb_ema_tensor { float* ema; const float* src; int64_t n; } ofb_ema_tensor;
 int ofb_ema_update(const ofb_ema_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float decay, float one_minus_decay,
-                   void* stream);
+                   const int32_t* skip, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Input side of the step.

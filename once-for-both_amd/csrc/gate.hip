@@ -187,24 +187,29 @@ __global__ void spars_finalize_kernel(const ofb_gate_desc* __restrict__ descs, i
 __global__ void flops_loss_kernel(const float* __restrict__ wsum, ofb_flops_cfg c, float* __restrict__ out,
                                   float* __restrict__ dwsum) {
   if (threadIdx.x != 0) return;
-  const double N = c.num_patches, n = c.num_patches, D = c.embed_dim, H = c.num_heads, dh = c.head_dim, hid = c.hidden,
+  // n: the ACTIVE patch count of the searched model (vision_transformer.py:768: weighted_mask.sum() once a patch-cell compress()
+  // has produced it - a probability-weighted count, so a float - else the full patch count)
+  const double N = c.num_patches, n = c.active_patches ? (double)c.active_patches[0] : (double)c.num_patches, D = c.embed_dim, H = c.num_heads, dh = c.head_dim, hid = c.hidden,
                P2 = c.patch_area, ncls = c.num_classes, Dln = c.ln_dim > 0 ? c.ln_dim : c.embed_dim;
   auto slot = [&](int s) { return c.live_slot ? c.live_slot[s] : s; };
   auto W = [&](int s) { const int j = slot(s); return (double)(j >= 0 ? wsum[j] : c.wconst[s]); };
   const double e = W(0);
-  double total = N * D * 3.0 * P2, searched = N * e * 3.0 * P2, de = N * 3.0 * P2;
+  double total = N * D * 3.0 * P2, searched = N * e * 3.0 * P2, de = N * 3.0 * P2, dn = 0.0;
   for (int l = 0; l < c.depth; ++l) {
     const double sd = W(1 + 2 * l), hh = W(2 + 2 * l);
     const double aH = c.active_heads ? (double)c.active_heads[l] : H;
     total += 2.0 * D * N;
     searched += 2.0 * Dln * n;
+    dn += 2.0 * Dln;
     total += N * (H * dh * 3.0 * H * dh) + 3.0 * N * H * dh + H * N * dh * N + H * N * N + 5.0 * H * N * N + H * N * N * dh +
              N * (H * dh * H * dh) + N * H * dh;
     searched += n * (e * 3.0 * sd) + 3.0 * n * sd + n * n * sd + aH * n * n + 5.0 * aH * n * n + n * n * sd + n * (sd * e) + n * e;
     const double dsd = n * e * 3.0 + 3.0 * n + n * n + n * n + n * e;
+    dn += e * 3.0 * sd + 3.0 * sd + 2.0 * n * sd + 2.0 * aH * n + 10.0 * aH * n + 2.0 * n * sd + sd * e + e;
     de += n * 3.0 * sd + n * sd + n;
     total += (2.0 * D * hid + D + hid) * N;
     searched += (e * hh + hh * e + e + hh) * n;
+    dn += e * hh + hh * e + e + hh;
     const double dhh = (2.0 * e + 1.0) * n;
     de += (2.0 * hh + 1.0) * n;
     const int ja = slot(1 + 2 * l), jm = slot(2 + 2 * l);
@@ -221,6 +226,7 @@ __global__ void flops_loss_kernel(const float* __restrict__ wsum, ofb_flops_cfg 
   out[0] = (float)(diff * diff);
   out[1] = (float)total;
   out[2] = (float)searched;
+  out[3] = (float)(k * dn);                       // d loss / d active_patches
   const int je = slot(0);
   for (int j = 0; j < c.n_live; ++j)
     if (j != je) dwsum[j] = (float)(k * (double)dwsum[j]);
@@ -244,11 +250,11 @@ extern "C" int ofb_gates_bwd(const ofb_gate_desc* descs_dev, const ofb_gate_grad
   return ofb_launch_status();
 }
 
-extern "C" int ofb_flops_loss(const float* wsum, const ofb_flops_cfg* cfg, float* out3, float* dwsum, void* stream) {
-  if (!cfg || !out3 || cfg->depth <= 0 || cfg->n_live < 0 || cfg->n_live > 1 + 2 * cfg->depth) return OFB_EINVAL;
+extern "C" int ofb_flops_loss(const float* wsum, const ofb_flops_cfg* cfg, float* out4, float* dwsum, void* stream) {
+  if (!cfg || !out4 || cfg->depth <= 0 || cfg->n_live < 0 || cfg->n_live > 1 + 2 * cfg->depth) return OFB_EINVAL;
   if (cfg->n_live > 0 && (!wsum || !dwsum)) return OFB_EINVAL;
   if ((cfg->live_slot == nullptr) != (cfg->wconst == nullptr)) return OFB_EINVAL;
   if (!cfg->live_slot && cfg->n_live != 1 + 2 * cfg->depth) return OFB_EINVAL;
-  hipLaunchKernelGGL(flops_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, wsum, *cfg, out3, dwsum);
+  hipLaunchKernelGGL(flops_loss_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, wsum, *cfg, out4, dwsum);
   return ofb_launch_status();
 }

@@ -336,7 +336,9 @@ __global__ __launch_bounds__(256) void index_select_kernel(const float* __restri
 // hyper (optional): device copy of {lr, bc1, 1 / sqrt(bc2)} read instead of the by-value arguments: the form a captured hipGraph
 // replays (the host refreshes the three floats before every replay; same values, same arithmetic as the by-value form)
 __global__ __launch_bounds__(256) void adamw_kernel(const ofb_adamw_tensor* __restrict__ tab, float lr, float beta1, float beta2,
-                                                    float eps, float wd, float bc1, float rsqrt_bc2, const float* __restrict__ hyper) {
+                                                    float eps, float wd, float bc1, float rsqrt_bc2, const float* __restrict__ hyper,
+                                                    const int32_t* __restrict__ skip) {
+  if (skip && *skip) return;                            // a non-finite loss was seen (ofb_nonfinite_watch): change nothing
   const ofb_adamw_tensor tt = tab[blockIdx.y];
   if (hyper) { lr = hyper[0]; bc1 = hyper[1]; rsqrt_bc2 = hyper[2]; }
   const float step = lr / bc1, decay = 1.0f - lr * wd;
@@ -457,19 +459,21 @@ extern "C" int ofb_scale_by_scalar(const float* x, const float* scalar_dev, floa
   return ofb_launch_status();
 }
 
-__global__ __launch_bounds__(256) void ema_kernel(const ofb_ema_tensor* __restrict__ tab, float decay, float omd) {
+__global__ __launch_bounds__(256) void ema_kernel(const ofb_ema_tensor* __restrict__ tab, float decay, float omd,
+                                                  const int32_t* __restrict__ skip) {
+  if (skip && *skip) return;
   const ofb_ema_tensor tt = tab[blockIdx.y];
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tt.n; i += (int64_t)gridDim.x * 256)
     tt.ema[i] = __fadd_rn(__fmul_rn(tt.ema[i], decay), __fmul_rn(omd, tt.src[i]));
 }
 
 extern "C" int ofb_ema_update(const ofb_ema_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float decay,
-                              float one_minus_decay, void* stream) {
+                              float one_minus_decay, const int32_t* skip, void* stream) {
   if (!table_dev || n_tensors <= 0 || max_numel <= 0) return OFB_EINVAL;
   int bx = (int)((max_numel + 256 * 8 - 1) / (256 * 8));
   if (bx > 256) bx = 256;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(ema_kernel, dim3(bx, n_tensors), dim3(256), 0, (hipStream_t)stream, table_dev, decay, one_minus_decay);
+  hipLaunchKernelGGL(ema_kernel, dim3(bx, n_tensors), dim3(256), 0, (hipStream_t)stream, table_dev, decay, one_minus_decay, skip);
   return ofb_launch_status();
 }
 
@@ -493,30 +497,78 @@ extern "C" int ofb_upload(void* dst_dev, const void* src_pinned, int64_t nbytes,
 
 namespace {
 int adamw_launch(const ofb_adamw_tensor* table_dev, int n_tensors, int64_t max_numel, float lr, float beta1, float beta2, float eps,
-                 float weight_decay, float bc1, float rsqrt_bc2, const float* hyper, hipStream_t s) {
+                 float weight_decay, float bc1, float rsqrt_bc2, const float* hyper, const int32_t* skip, hipStream_t s) {
   int bx = (int)((max_numel + 256 * 8 - 1) / (256 * 8));
   if (bx > 256) bx = 256;
   if (bx < 1) bx = 1;
   ofb_prof_pre(6, s, 0.0);
   hipLaunchKernelGGL(adamw_kernel, dim3(bx, n_tensors), dim3(256), 0, s, table_dev, lr, beta1, beta2, eps, weight_decay, bc1, rsqrt_bc2,
-                     hyper);
+                     hyper, skip);
   ofb_prof_post(6, s);
   return ofb_launch_status();
 }
 }  // namespace
 
 extern "C" int ofb_adamw_step(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int32_t step, void* stream) {
+                              float beta2, float eps, float weight_decay, int32_t step, const int32_t* skip, void* stream) {
   if (!table_dev || n_tensors <= 0 || max_numel <= 0 || step <= 0) return OFB_EINVAL;
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   return adamw_launch(table_dev, n_tensors, max_numel, lr, beta1, beta2, eps, weight_decay, (float)bc1, (float)(1.0 / sqrt(bc2)), nullptr,
-                      (hipStream_t)stream);
+                      skip, (hipStream_t)stream);
 }
 
 // The same update with {lr, 1 - beta1^step, 1 / sqrt(1 - beta2^step)} read from device memory (hyper_dev[3]): for a step captured
 // in a hipGraph, whose replays must not bake the step count or the learning rate into the launch arguments.
 extern "C" int ofb_adamw_step_dev(const ofb_adamw_tensor* table_dev, int32_t n_tensors, int64_t max_numel, const float* hyper_dev,
-                                  float beta1, float beta2, float eps, float weight_decay, void* stream) {
+                                  float beta1, float beta2, float eps, float weight_decay, const int32_t* skip, void* stream) {
   if (!table_dev || !hyper_dev || n_tensors <= 0 || max_numel <= 0) return OFB_EINVAL;
-  return adamw_launch(table_dev, n_tensors, max_numel, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, hyper_dev, (hipStream_t)stream);
+  return adamw_launch(table_dev, n_tensors, max_numel, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, hyper_dev, skip, (hipStream_t)stream);
+}
+
+// out[i] = sum_s workspace[s * count + i] (+ out[i]): per-chunk partial buffers of the embed assembly, added in chunk order
+namespace {
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t count, float* __restrict__ out,
+                                     int accumulate) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = accumulate ? out[i] : 0.f;
+    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * count + i];
+    out[i] = s;
+  }
+}
+}  // namespace
+
+extern "C" int ofb_splitk_reduce(const float* workspace, int32_t splits, int64_t count, float* out, int32_t accumulate,
+                                 void* stream) {
+  if (!workspace || !out || splits <= 0 || count <= 0) return OFB_EINVAL;
+  const int blocks = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, workspace, splits, count, out,
+                     accumulate);
+  return ofb_launch_status();
+}
+
+namespace {
+__global__ void nonfinite_watch_kernel(const float* __restrict__ v, int n, int32_t* __restrict__ flag) {
+  bool bad = false;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) bad |= !isfinite(v[i]);
+  if (__syncthreads_or(bad) && threadIdx.x == 0) flag[0] += 1;
+}
+__global__ __launch_bounds__(256) void multi_copy_kernel(const ofb_copy_job* __restrict__ jobs) {
+  const ofb_copy_job j = jobs[blockIdx.y];
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < j.n; i += (int64_t)gridDim.x * 256) j.dst[i] = j.src ? j.src[i] : 0.f;
+}
+}  // namespace
+
+extern "C" int ofb_nonfinite_watch(const float* values, int32_t n, int32_t* flag, void* stream) {
+  if (!values || !flag || n <= 0) return OFB_EINVAL;
+  hipLaunchKernelGGL(nonfinite_watch_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, values, n, flag);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_multi_copy(const ofb_copy_job* jobs_dev, int32_t n_jobs, int64_t max_n, void* stream) {
+  if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535 || max_n <= 0) return OFB_EINVAL;
+  int bx = (int)((max_n + 256 * 8 - 1) / (256 * 8));
+  if (bx > 256) bx = 256;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(multi_copy_kernel, dim3(bx, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  return ofb_launch_status();
 }

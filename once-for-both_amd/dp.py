@@ -22,16 +22,20 @@ _active = None        # the reducer whose buckets ops.py may write weight gradie
 
 def grad_slot(param):
     """Slice of the active reducer's flat bucket where `param`'s gradient should be written, or None (no reducer,
-    unknown tensor, or a gradient is already being accumulated in this window)."""
+    unknown tensor, a gradient is already being accumulated in this window, or the slot was already handed out in this
+    backward pass: a weight used twice in one graph - tied weights, a module called twice - gets ONE direct write, the
+    second product goes to a fresh buffer and autograd adds the two)."""
     r = _active
     if r is None or not r.sync:
         return None
-    ent = r._slot_of.get(param.data_ptr())
+    key = param.data_ptr()
+    ent = r._slot_of.get(key)
     if ent is None:
         return None
     p, view = ent
-    if p.grad is not None or p.numel() != param.numel():
+    if p.grad is not None or p.numel() != param.numel() or key in r._handed:
         return None
+    r._handed.add(key)
     return view.view(param.shape)
 
 
@@ -76,6 +80,8 @@ def broadcast_tensors(tensors, src=0, process_group=None):
                     n = t.numel()
                     t.copy_(flat[off:off + n].view_as(t))
                     off += n
+    from . import hip
+    hip.bump_weight_epoch()                              # `.data` was overwritten: P-format copies of the weights are stale
 
 
 class GradAllReducer:
@@ -116,6 +122,7 @@ class GradAllReducer:
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._works = []
+        self._handed = set()                             # data pointers whose bucket slot grad_slot() gave out in this window
         self._handles = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         # averaging: callers scale the loss by `grad_scale` (= 1/world, exact for power-of-two worlds) before backward and
         # the exchange is a plain SUM, so no extra pass over the gradients is needed; prescaled=False divides afterwards.
@@ -149,15 +156,22 @@ class GradAllReducer:
         self._launched[bi] = True
         from . import hip
         hip.join_side()                                  # weight gradients are produced on the side stream (ops.py)
-        flat, live = self._flat[bi], []
+        flat, live, jobs = self._flat[bi], [], []
         for p, v in zip(self.buckets[bi], self._views[bi]):
             if p.grad is None:
-                v.zero_()                                # travels as zeros, is not installed afterwards
+                jobs.append((None, v))                   # travels as zeros, is not installed afterwards
                 continue
-            if p.grad.data_ptr() != v.data_ptr():        # small gradients / accumulated windows: one copy into the bucket
-                v.copy_(p.grad)
+            if p.grad.data_ptr() != v.data_ptr():        # small gradients / accumulated windows: copied into the bucket
+                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                jobs.append((g, v))
                 p.grad = v
             live.append(p)
+        if jobs:
+            if flat.is_cuda:                             # ONE launch for all of them (was ~150 copy_ / zero_ launches per step)
+                self._copy_keep = (hip.multi_copy(jobs, flat.device), [g for g, _ in jobs])
+            else:                                        # CPU tensors exist only in the gloo rehearsal of the launcher / protocol
+                for g, v in jobs:
+                    v.zero_() if g is None else v.copy_(g)
         if not live:
             return
         if self.world > 1 or self.force_collective:
@@ -192,6 +206,7 @@ class GradAllReducer:
         self._works = []
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
+        self._handed.clear()
 
 
 def average_scalars(tensors, process_group=None):

@@ -28,6 +28,11 @@ def search_step(model, criterion, samples, targets, target_flops, optimizers, fi
     outputs, (decoder_loss, _) = model(samples)
     loss = criterion(samples, outputs, targets, model, 'arch', target_flops, finish_search)
     base, arch, total = mix_losses(loss, decoder_loss)
+    if total.is_cuda:
+        # engine.py:146-150 without the per-step host sync: a non-finite loss bumps a device counter that makes every later AdamW /
+        # EMA launch a no-op; the epoch loop reads it at its print points and stops
+        from . import hip
+        hip.watch_nonfinite(total)
     scale = 1.0 / accum_iter
     if reducer is not None:
         reducer.prescaled = True
@@ -154,7 +159,9 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
         if it % print_freq == 0 or it == n_iter - 1:          # the only host syncs of the loop
             lv = float(total.detach())
             host = sums.tolist()
-            if not math.isfinite(lv) or host[4] > 0:         # any micro-step since the last look (reference: every micro-step, engine.py:146-148)
+            # any micro-step since the last look (reference: every micro-step, engine.py:146-148).  No parameter, moment or EMA
+            # update was applied after the first non-finite loss: the device-side watch (search_step) froze the AdamW / EMA kernels
+            if not math.isfinite(lv) or host[4] > 0:
                 print('Loss is {}, stopping training'.format(lv if not math.isfinite(lv) else 'non-finite in an earlier micro-step'))
                 sys.exit(1)
             n_seen = it + 1
@@ -191,6 +198,9 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
         if mixup_fn is not None:
             samples, targets = mixup_fn(samples, targets)
         loss = criterion(samples, model(samples), targets)
+        if loss.is_cuda:
+            from . import hip
+            hip.watch_nonfinite(loss)                    # engine.py:48-50 without a host sync: freezes AdamW / EMA once non-finite
         if reducer is not None:
             reducer.sync = (it + 1) % accum_iter == 0    # one exchange per accumulation window
             reducer.prescaled = False                    # plain SUM, divided by the world size in finalize()

@@ -17,35 +17,16 @@ class OfbError(RuntimeError):
     pass
 
 
-class GemmArgs(C.Structure):
-    _fields_ = [
-        ('A', C.c_void_p), ('B', C.c_void_p), ('C', C.c_void_p),
-        ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
-        ('lda', C.c_int32), ('ldb', C.c_int32), ('ldc', C.c_int32),
-        ('a_kc', C.c_int32), ('b_kc', C.c_int32),
-        ('alpha', C.c_float),
-        ('bias', C.c_void_p), ('colscale', C.c_void_p),
-        ('rowscale', C.c_void_p), ('rs_div', C.c_int32),
-        ('resid', C.c_void_p), ('ldr', C.c_int32),
-        ('aux', C.c_void_p), ('ldaux', C.c_int32),
-        ('act', C.c_int32),
-        ('kscale', C.c_void_p), ('ks_div', C.c_int32),
-        ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('a_colsum', C.c_void_p),
-    ]
-
-
-ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4      # the last two: ofb_gemm_p only
-# 'p': f32-operand GEMM calls convert to P-format and run csrc/gemm_p.hip; 'split': the in-loop split engine of csrc/gemm.hip
-ENGINE = os.environ.get('OFB_GEMM_ENGINE', 'p')
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_f32', 'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_gemm_p_colpart_rows', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_gemm_workspace_bytes', 'ofb_gemm_is_streamed', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_gemm_p_colpart_rows', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_fwd_p', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
-    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
+    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
     'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm', 'ofb_random_erase',
     'ofb_randaug_layer', 'ofb_normalize_u8',
 ]
@@ -120,35 +101,19 @@ def _workspace(device, nbytes):
 
 def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kc, b_kc, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
          resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, kscale=None, ks_div=1, a_colsum=None):
-    """a_colsum (weight-gradient launches only): fused column sums of the stored A; falls back to a separate
-    ofb_colsum launch when the GEMM is not fully streamed."""
-    if ENGINE == 'p' and not (not a_kc and b_kc):
-        # f32 operands through the P-format engine: one conversion pass per operand, then the plane GEMM.  The model path hands
-        # P-format tensors over directly (ops.py); this form serves callers that hold plain f32 matrices.
-        Ap = to_pformat(A, M, K, lda) if a_kc else to_pformat(A, K, M, lda, rowscale=kscale, rs_div=ks_div)
-        Bp = to_pformat(B, N, K, ldb) if b_kc else to_pformat(B, K, N, ldb)
-        gemm_p(Ap, Bp, a_kc, b_kc, M, N, K, C_out=C_out, ldc=ldc, alpha=alpha, bias=bias, colscale=colscale, rowscale=rowscale,
-               rs_div=rs_div, resid=resid, ldr=ldr, aux=aux, ldaux=ldaux, act=act)
-        if a_colsum is not None:
-            colsum(A, lda, K, M, a_colsum, rowscale=kscale, rs_div=ks_div)
-        return
-    g = GemmArgs()
-    g.A, g.B, g.C = ptr(A), ptr(B), ptr(C_out)
-    g.M, g.N, g.K, g.lda, g.ldb, g.ldc = M, N, K, lda, ldb, ldc
-    g.a_kc, g.b_kc, g.alpha = int(a_kc), int(b_kc), alpha
-    g.bias, g.colscale, g.rowscale, g.rs_div = ptr(bias), ptr(colscale), ptr(rowscale), rs_div
-    g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
-    g.kscale, g.ks_div = ptr(kscale), ks_div
-    fused = a_colsum is not None and bool(lib().ofb_gemm_is_streamed(C.byref(g)))
-    if fused:
-        g.a_colsum = ptr(a_colsum)
-    lib().ofb_gemm_workspace_bytes.restype = C.c_int64
-    need = lib().ofb_gemm_workspace_bytes(C.byref(g))
-    if need > 0:
-        ws = _workspace(A.device, need)
-        g.workspace, g.workspace_bytes = ptr(ws), ws.numel() * 4
-    check(lib().ofb_gemm_f32(C.byref(g), stream()), 'ofb_gemm_f32')
-    if a_colsum is not None and not fused:           # A stored [K][M]: column sums over its K rows
+    """Convenience form for callers that hold plain f32 matrices (tests, scripts): one conversion pass per operand, then the
+    plane GEMM.  a_kc / b_kc = 1: operand stored K-contiguous (A[m*lda+k], B[n*ldb+k]); 0: MN-contiguous.  The model path hands
+    P-format tensors over directly (ops.py).  kscale (a_kc == 0): A's reduction rows scaled by kscale[k // ks_div]; a_colsum
+    (a_kc == 0): column sums of the stored (scaled) A, i.e. the bias gradient beside a weight gradient."""
+    if not a_kc and b_kc:
+        raise OfbError('A^T * B^T is not a product of the path (ofb_gemm_p: OFB_ELIMIT)')
+    if kscale is not None and a_kc:
+        raise OfbError('kscale applies to an operand stored along the reduction (a_kc == 0)')
+    Ap = to_pformat(A, M, K, lda) if a_kc else to_pformat(A, K, M, lda, rowscale=kscale, rs_div=ks_div)
+    Bp = to_pformat(B, N, K, ldb) if b_kc else to_pformat(B, K, N, ldb)
+    gemm_p(Ap, Bp, a_kc, b_kc, M, N, K, C_out=C_out, ldc=ldc, alpha=alpha, bias=bias, colscale=colscale, rowscale=rowscale,
+           rs_div=rs_div, resid=resid, ldr=ldr, aux=aux, ldaux=ldaux, act=act)
+    if a_colsum is not None:
         colsum(A, lda, K, M, a_colsum, rowscale=kscale, rs_div=ks_div)
 
 
@@ -211,6 +176,12 @@ def to_pformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1, colsum_out=
     return pm
 
 
+def to_pformat_into(x, R, Cc, ld, pm, rowscale=None, rs_div=1):
+    """the same conversion into existing planes `pm` (persistent weight planes)"""
+    check(lib().ofb_to_pformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), stream()), 'ofb_to_pformat')
+    return pm
+
+
 def colsum_p(pm, out):
     """out[C] = column sums of a P-format matrix (two deterministic stages)."""
     slabs = int(lib().ofb_colsum_p_slabs(_i(pm.R)))
@@ -260,10 +231,15 @@ def join_side():
         _side_keep.clear()
 
 
-# P-format copies of the weights: made once per optimizer step and kept ON the Parameter object (an attribute, so the copy
-# lives and dies with the tensor it mirrors - a table keyed by data_ptr could hand a recycled address someone else's planes).
-# The optimizers / EMA / compress() bump the epoch after they changed parameters through raw pointers; torch in-place edits show
-# up in _version.  One copy feeds the forward, input-gradient and weight-gradient products.
+# P-format copies of the weights.  They live in a registry keyed by id(tensor) with a weak reference (never as attributes of the
+# Parameter: torch pickles a Parameter's __dict__, so `torch.save(model)` - the reference's whole-object checkpoint format,
+# search.py:671-740 - would write the planes into every checkpoint).  An entry dies with its tensor.  A copy is fresh while
+#   * the weight epoch is unchanged: the optimizers / EMA / compress() / load_state_dict / the DP broadcast bump it after they
+#     changed parameters through raw pointers or `.data`, and every model forward bumps it (begin_forward) - so a forward pass
+#     NEVER trusts planes made before it started, whatever wrote the weights in between (`p.data.mul_()`, `p.data.copy_()`, the
+#     reference's compress / resume idiom, moves neither `_version` nor any hook);
+#   * the tensor's `_version`, data pointer and shape are unchanged (direct callers of the ops between two bumps).
+# One copy feeds the forward, input-gradient and weight-gradient products.
 _weight_epoch = 0
 
 
@@ -273,35 +249,73 @@ def bump_weight_epoch():
     _gw_jobs.clear()
 
 
+def begin_forward():
+    """called by the models at the start of every forward pass: all registered weights are re-converted (one multi-tensor launch,
+    ~50 us for DeiT-S) by the first GEMM of the pass.  In a training step this coincides with the refresh the optimizer step
+    asks for anyway."""
+    bump_weight_epoch()
+
+
 class PformatJob(C.Structure):
     _fields_ = [('X', C.c_void_p), ('P', C.c_void_p), ('rowscale', C.c_void_p), ('R', C.c_int32), ('C', C.c_int32), ('ld', C.c_int32),
                 ('pad_', C.c_int32)]
 
 
-# Every weight that has ever been asked for in P-format is registered (weak reference + its persistent plane buffer).  The first
-# request of a new epoch converts ALL registered weights that are stale in ONE multi-tensor launch (ofb_to_pformat_multi): ~70
-# launches per DeiT search step become one.  The job table is re-uploaded only when the set of (pointer, shape) entries changed.
-_wp_reg = {}                 # id(W) -> (weakref(W), (N, K))
+class _WEntry:
+    """registry record of one weight: persistent plane buffers + what they were converted from"""
+    __slots__ = ('ref', 'pm', 'epoch', 'version', 'ptr', 'shape', 'gw')
+
+    def __init__(self, ref):
+        self.ref, self.pm, self.epoch, self.version, self.ptr, self.shape, self.gw = ref, None, -1, -1, 0, None, None
+
+
+# Every weight that has ever been asked for in P-format is registered.  The first request of a new epoch converts ALL registered
+# weights that are stale in ONE multi-tensor launch (ofb_to_pformat_multi): ~70 launches per DeiT search step become one.  The
+# job table is re-uploaded only when the set of (pointer, shape) entries changed.
+_wp_reg = {}                 # id(W) -> _WEntry
 _wp_table = [None, None, 0, 0]   # key tuple, device table (kept alive), max_R, max_C
 
 
-def _wp_fresh(W):
-    ent = getattr(W, '_ofb_wp', None)
-    return ent is not None and ent[0] == _weight_epoch and ent[1] == W._version and ent[3] == tuple(W.shape)
+def _drop_entry(key, r):
+    e = _wp_reg.get(key)
+    if e is not None and e.ref is r:
+        del _wp_reg[key]
+
+
+def _entry(W):
+    """the registry record of tensor W (created on first use); None for objects that take no weak references"""
+    import functools
+    import weakref
+    key = id(W)
+    ent = _wp_reg.get(key)
+    if ent is not None and ent.ref() is W:
+        return ent
+    try:
+        ref = weakref.ref(W, functools.partial(_drop_entry, key))
+    except TypeError:
+        return None
+    ent = _wp_reg[key] = _WEntry(ref)
+    return ent
+
+
+def _wp_fresh(W, ent):
+    return (ent.pm is not None and ent.epoch == _weight_epoch and ent.version == W._version and ent.ptr == W.data_ptr()
+            and ent.shape == tuple(W.shape))
 
 
 def _wp_refresh_all(device):
-    import weakref
     jobs, live = [], []
-    for key, (ref, shape2d) in list(_wp_reg.items()):
-        W = ref()
-        if W is None or getattr(W, '_ofb_wp', None) is None or W._ofb_wp[3] != tuple(W.shape):
-            del _wp_reg[key]
+    for key, ent in list(_wp_reg.items()):
+        W = ent.ref()
+        if W is None:
+            _wp_reg.pop(key, None)
             continue
-        if W.device != device or _wp_fresh(W):
+        if ent.pm is None or ent.shape != tuple(W.shape):
+            continue                                     # no planes yet / re-shaped in place: converted when it is asked for
+        if W.device != device or _wp_fresh(W, ent) or not W.is_contiguous():
             continue
-        live.append(W)
-        jobs.append((W.data_ptr(), W._ofb_wp[2].buf.data_ptr(), shape2d[0], shape2d[1]))
+        live.append((W, ent))
+        jobs.append((W.data_ptr(), ent.pm.buf.data_ptr(), ent.pm.R, ent.pm.C))
     if not jobs:
         return
     key = tuple(jobs)
@@ -313,95 +327,100 @@ def _wp_refresh_all(device):
         _wp_table[:] = [key, (dev_tab, host), max(j[2] for j in jobs), max(j[3] for j in jobs)]
     check(lib().ofb_to_pformat_multi(ptr(_wp_table[1][0]), _i(len(jobs)), _i(_wp_table[2]), _i(_wp_table[3]), stream()),
           'ofb_to_pformat_multi')
-    for W in live:
-        W._ofb_wp = (_weight_epoch, W._version, W._ofb_wp[2], tuple(W.shape))
+    for W, ent in live:
+        ent.epoch, ent.version, ent.ptr = _weight_epoch, W._version, W.data_ptr()
 
 
 _WP_MULTI = os.environ.get('OFB_WP_MULTI', '1') != '0'
+
+
+def _param_of(W):
+    """a reshaping view of a Parameter (decoder / patch-embed weights) is cached under the Parameter itself"""
+    base = W._base
+    if base is not None and base.is_contiguous() and base.numel() == W.numel() and base.data_ptr() == W.data_ptr():
+        return base
+    return W
 
 
 def weight_p(W, shape2d=None):
     """P-format copy of a weight viewed as W[N][K] (shape2d: the 2-D view of a conv weight)."""
     if shape2d is None:
         shape2d = tuple(W.shape)
-    base = W._base
-    if base is not None and base.is_contiguous() and base.numel() == W.numel() and base.data_ptr() == W.data_ptr():
-        W = base                                         # a reshaping view of a Parameter (decoder / patch-embed weights): cache on the Parameter
-    ent = getattr(W, '_ofb_wp', None)
-    if ent is not None and ent[0] == _weight_epoch and ent[1] == W._version and ent[3] == tuple(W.shape) and (ent[2].R, ent[2].C) == tuple(shape2d):
-        return ent[2]
+    W = _param_of(W)
+    N, K = int(shape2d[0]), int(shape2d[1])
+    ent = _entry(W)
+    if ent is not None and _wp_fresh(W, ent) and (ent.pm.R, ent.pm.C) == (N, K):
+        return ent.pm
     if not W.is_contiguous():
         raise OfbError('weight_p needs a contiguous weight')
-    N, K = shape2d
+    if ent is None:
+        return to_pformat(W, N, K, K)                    # an object that takes no weak references: convert in place
     if not _WP_MULTI:
-        pm = to_pformat(W, N, K, K)
-        try:
-            W._ofb_wp = (_weight_epoch, W._version, pm, tuple(W.shape))
-        except AttributeError:
-            pass
-        return pm
-    ent = getattr(W, '_ofb_wp', None)
-    try:
-        if ent is None or ent[3] != tuple(W.shape) or ent[2].R != N or ent[2].C != K:
-            import weakref
-            W._ofb_wp = (-1, -1, PMat(N, K, W.device), tuple(W.shape))        # persistent planes; stale until converted
-            _wp_reg[id(W)] = (weakref.ref(W), (int(N), int(K)))
-    except (AttributeError, TypeError):
-        return to_pformat(W, N, K, K)                    # an object that takes no attributes / weak references: convert in place
+        ent.pm = to_pformat(W, N, K, K)
+        ent.epoch, ent.version, ent.ptr, ent.shape = _weight_epoch, W._version, W.data_ptr(), tuple(W.shape)
+        return ent.pm
+    if ent.pm is None or ent.shape != tuple(W.shape) or (ent.pm.R, ent.pm.C) != (N, K):
+        ent.pm, ent.shape, ent.epoch = PMat(N, K, W.device), tuple(W.shape), -1     # persistent planes; stale until converted
     _wp_refresh_all(W.device)
-    if not _wp_fresh(W):                                 # e.g. registered under another id: fall back to a single conversion
-        pm = to_pformat(W, N, K, K)
-        W._ofb_wp = (_weight_epoch, W._version, pm, tuple(W.shape))
-    return W._ofb_wp[2]
+    if not _wp_fresh(W, ent):                            # e.g. another device's table was current: a single conversion
+        to_pformat_into(W, N, K, K, ent.pm)
+        ent.epoch, ent.version, ent.ptr = _weight_epoch, W._version, W.data_ptr()
+    return ent.pm
+
+
+def weight_registry_size():
+    """number of live weights that hold P-format planes (tests)"""
+    return sum(1 for e in _wp_reg.values() if e.ref() is not None and e.pm is not None)
 
 
 # Gate-scaled weights g[n] * W[n][:] (the B operand of the gated layers' input-gradient products): the forward registers each
 # (W, gate vector) pair, the first request in backward converts ALL pending pairs in one multi-tensor launch into per-weight
-# persistent planes.  Entries live until the next optimizer step (bump_weight_epoch).
+# persistent planes.  Entries live until the next bump of the weight epoch.
 _gw_jobs = []                # (W, gvec, N, K)
 _gw_table = [None, None, 0, 0]
 
 
 def gated_register(W, gvec, N, K):
     if _WP_MULTI:
-        _gw_jobs.append((W, gvec, int(N), int(K)))
+        _gw_jobs.append((_param_of(W), gvec, int(N), int(K)))
 
 
-def _gw_fresh(W, gvec):
-    ent = getattr(W, '_ofb_gwp', None)
-    return (ent is not None and ent[0] == _weight_epoch and ent[1] == W._version and ent[2] == gvec.data_ptr() and
-            ent[3] == gvec._version)
+def _gw_fresh(W, gvec, ent):
+    g = ent.gw if ent is not None else None
+    return (g is not None and g[0] == _weight_epoch and g[1] == W._version and g[2] == gvec.data_ptr() and g[3] == gvec._version
+            and g[5] == W.data_ptr())
 
 
 def gated_weight_p(W, gvec, N, K):
     """P-format planes of gvec[n] * W[n][:] for W viewed as [N][K]"""
-    base = W._base
-    if base is not None and base.is_contiguous() and base.numel() == W.numel() and base.data_ptr() == W.data_ptr():
-        W = base                                         # a reshaping view of the Parameter the forward registered
+    W = _param_of(W)
     if not _WP_MULTI or not W.is_contiguous():
         return to_pformat(W, N, K, K, rowscale=gvec)
-    if _gw_fresh(W, gvec) and (W._ofb_gwp[4].R, W._ofb_gwp[4].C) == (N, K):
-        return W._ofb_gwp[4]
+    ent = _entry(W)
+    if ent is None:
+        return to_pformat(W, N, K, K, rowscale=gvec)
+    if _gw_fresh(W, gvec, ent) and (ent.gw[4].R, ent.gw[4].C) == (N, K):
+        return ent.gw[4]
     todo, seen = [], set()
     for (W_, g_, N_, K_) in _gw_jobs + [(W, gvec, int(N), int(K))]:
-        if id(W_) in seen or W_.device != W.device or _gw_fresh(W_, g_):
+        e_ = _entry(W_)
+        if e_ is None or id(W_) in seen or W_.device != W.device or _gw_fresh(W_, g_, e_):
             continue
         seen.add(id(W_))
-        ent = getattr(W_, '_ofb_gwp', None)
-        pm = ent[4] if ent is not None and (ent[4].R, ent[4].C) == (N_, K_) else PMat(N_, K_, W_.device)
-        todo.append((W_, g_, N_, K_, pm))
-    key = tuple((w_.data_ptr(), g_.data_ptr(), pm.buf.data_ptr(), n_, k_) for (w_, g_, n_, k_, pm) in todo)
+        pm = e_.gw[4] if e_.gw is not None and (e_.gw[4].R, e_.gw[4].C) == (N_, K_) else PMat(N_, K_, W_.device)
+        todo.append((W_, g_, N_, K_, pm, e_))
+    key = tuple((w_.data_ptr(), g_.data_ptr(), pm.buf.data_ptr(), n_, k_) for (w_, g_, n_, k_, pm, _) in todo)
     if _gw_table[0] != key:
         tab = (PformatJob * len(todo))()
-        for t, (w_, g_, n_, k_, pm) in zip(tab, todo):
+        for t, (w_, g_, n_, k_, pm, _) in zip(tab, todo):
             t.X, t.P, t.rowscale, t.R, t.C, t.ld = w_.data_ptr(), pm.buf.data_ptr(), g_.data_ptr(), n_, k_, k_
         dev_tab, host = upload_structs(tab, W.device)
         _gw_table[:] = [key, (dev_tab, host), max(j[2] for j in todo), max(j[3] for j in todo)]
     check(lib().ofb_to_pformat_multi(ptr(_gw_table[1][0]), _i(len(todo)), _i(_gw_table[2]), _i(_gw_table[3]), stream()),
           'ofb_to_pformat_multi')
-    for (w_, g_, n_, k_, pm) in todo:
-        w_._ofb_gwp = (_weight_epoch, w_._version, g_.data_ptr(), g_._version, pm)
-    return W._ofb_gwp[4]
+    for (w_, g_, n_, k_, pm, e_) in todo:
+        e_.gw = (_weight_epoch, w_._version, g_.data_ptr(), g_._version, pm, w_.data_ptr())
+    return ent.gw[4]
 
 
 def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
@@ -551,7 +570,7 @@ class FlopsCfg(C.Structure):
     _fields_ = [('num_patches', C.c_int32), ('embed_dim', C.c_int32), ('num_heads', C.c_int32), ('head_dim', C.c_int32),
                 ('hidden', C.c_int32), ('patch_area', C.c_int32), ('num_classes', C.c_int32), ('depth', C.c_int32),
                 ('target', C.c_float), ('ln_dim', C.c_int32), ('active_heads', C.c_void_p), ('live_slot', C.c_void_p),
-                ('wconst', C.c_void_p), ('n_live', C.c_int32)]
+                ('wconst', C.c_void_p), ('n_live', C.c_int32), ('active_patches', C.c_void_p)]
 
 
 class EmaTensor(C.Structure):
@@ -658,8 +677,62 @@ def scale_by_scalar(x, scalar_dev, out, n):
 
 
 def ema_update(table_dev, n_tensors, max_numel, decay):
-    check(lib().ofb_ema_update(ptr(table_dev), _i(n_tensors), C.c_int64(max_numel), C.c_float(decay), C.c_float(1.0 - decay), stream()),
-          'ofb_ema_update')
+    check(lib().ofb_ema_update(ptr(table_dev), _i(n_tensors), C.c_int64(max_numel), C.c_float(decay), C.c_float(1.0 - decay),
+                               _skip_ptr(table_dev.device), stream()), 'ofb_ema_update')
+
+
+# ---- non-finite loss watch (reference engine.py:146-150 stops before backward when the loss is not finite) -----------------------
+# One int32 counter per device: watch_nonfinite(loss) bumps it on the device when the loss is NaN / inf; from then on the AdamW and
+# EMA kernels (which receive the counter as `skip`) change nothing, so no update is ever applied after a non-finite loss although
+# the host looks at the counter only at its print points.
+_nonfinite = {}
+
+
+def nonfinite_flag(device, create=True):
+    device = torch.device(device)
+    if device.type == 'cuda' and device.index is None:
+        device = torch.device('cuda', torch.cuda.current_device())
+    t = _nonfinite.get(device)
+    if t is None and create:
+        t = _nonfinite[device] = torch.zeros(1, device=device, dtype=torch.int32)
+    return t
+
+
+def _skip_ptr(device):
+    t = nonfinite_flag(device, create=False)
+    return None if t is None else _void_p(t.data_ptr())
+
+
+def watch_nonfinite(values):
+    """values: f32 device tensor (the step's total loss): counts a non-finite entry on the device, no host sync"""
+    v = values.detach().reshape(-1)
+    if v.dtype != torch.float32 or not v.is_contiguous():
+        v = v.float().contiguous()
+    check(lib().ofb_nonfinite_watch(ptr(v), _i(v.numel()), ptr(nonfinite_flag(v.device)), stream()), 'ofb_nonfinite_watch')
+
+
+def reset_nonfinite(device=None):
+    for d, t in _nonfinite.items():
+        if device is None or d == torch.device(device):
+            t.zero_()
+
+
+class CopyJob(C.Structure):
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p), ('n', C.c_int64)]
+
+
+def multi_copy(pairs, device):
+    """pairs: [(src tensor or None, dst tensor)] contiguous f32, same numel: dst <- src (or zeros) in ONE launch"""
+    tab = (CopyJob * len(pairs))()
+    maxn = 0
+    for t, (src, dst) in zip(tab, pairs):
+        if src is not None and (src.dtype != torch.float32 or not src.is_contiguous() or src.numel() != dst.numel()):
+            raise OfbError('multi_copy: sources must be contiguous float32 tensors of the destination size')
+        t.src, t.dst, t.n = (None if src is None else src.data_ptr()), dst.data_ptr(), dst.numel()
+        maxn = max(maxn, dst.numel())
+    dev_tab, host = upload_structs(tab, device)
+    check(lib().ofb_multi_copy(ptr(dev_tab), _i(len(pairs)), C.c_int64(maxn), stream()), 'ofb_multi_copy')
+    return dev_tab, host
 
 
 def index_select(t, index, dim):
@@ -693,12 +766,12 @@ def index_select(t, index, dim):
 
 def adamw_step(table_dev, n_tensors, max_numel, lr, beta1, beta2, eps, wd, step):
     check(lib().ofb_adamw_step(ptr(table_dev), _i(n_tensors), C.c_int64(max_numel), _f(lr), _f(beta1), _f(beta2), _f(eps),
-                               _f(wd), _i(step), stream()), 'ofb_adamw_step')
+                               _f(wd), _i(step), _skip_ptr(table_dev.device), stream()), 'ofb_adamw_step')
 
 
 def adamw_step_dev(table_dev, n_tensors, max_numel, hyper_dev, beta1, beta2, eps, wd):
     check(lib().ofb_adamw_step_dev(ptr(table_dev), _i(n_tensors), C.c_int64(max_numel), ptr(hyper_dev), _f(beta1), _f(beta2), _f(eps),
-                                   _f(wd), stream()), 'ofb_adamw_step_dev')
+                                   _f(wd), _skip_ptr(table_dev.device), stream()), 'ofb_adamw_step_dev')
 
 
 def patch_mask(noise, mask, B, L, len_keep, masked_ids=None):

@@ -453,11 +453,6 @@ class MAESparseAttention(Attention, _Searchable):
             return self._single_gate()
         return None if self.fused else self.score.to(self.qkv.weight.device)
 
-    def _branch(self, x, resid, gate, rowscale, heads):
-        if gate is not None and gate.numel() != heads * self.head_dim and getattr(self, 'space', 'joint') != 'joint':
-            gate = gate.expand(heads, self.head_dim)             # head-only / channel-only gate broadcast over (H, d)
-        return super()._branch(x, resid, gate, rowscale, heads)
-
     def forward(self, x, mask_embed=None, weighted_embed=None):
         self.weighted_mask_embed = mask_embed
         return self._branch(x, torch.zeros_like(x), self.current_gate(), None, self.active_heads())

@@ -21,47 +21,10 @@ def _c(t):
 
 
 # ---------------------------------------------------------------------------------------------------
-# GEMM helpers (nn.Linear forward / input-grad / weight-grad on the f32 MFMA kernel)
-# ---------------------------------------------------------------------------------------------------
-def linear_fwd(x2d, W, b, colscale=None, act=hip.ACT_NONE, aux=None, rowscale=None, rs_div=1, resid=None):
-    M, K = x2d.shape
-    N = W.shape[0]
-    y = _new(x2d, M, N)
-    hip.gemm(x2d, W, y, M, N, K, K, K, N, 1, 1, bias=b, colscale=colscale, act=act, aux=aux, ldaux=N, rowscale=rowscale,
-             rs_div=rs_div, resid=resid, ldr=N)
-    return y
-
-
-def linear_bwd_input(dy2d, W, resid=None, rowscale=None, rs_div=1, act=hip.ACT_NONE, aux=None):
-    """dX[M,K] = dY[M,N] @ W[N,K] (+ fused epilogue)."""
-    M, N = dy2d.shape
-    K = W.shape[1]
-    dx = _new(dy2d, M, K)
-    hip.gemm(dy2d, W, dx, M, K, N, N, K, K, 1, 0, resid=resid, ldr=K, rowscale=rowscale, rs_div=rs_div, act=act, aux=aux,
-             ldaux=K)
-    return dx
-
-
-def linear_bwd_weight(dy2d, x2d, kscale=None, ks_div=1, out=None, want_bias=False):
-    """dW[N,K] = dY[M,N]^T @ X[M,K]: few output tiles, reduction over all tokens -> the GEMM's stream-K tail.
-    want_bias: also return db[N] = colsum(dY (*kscale)), fused into the same launch."""
-    M, N = dy2d.shape
-    K = x2d.shape[1]
-    dW = out if out is not None else _new(dy2d, N, K)
-    db = _new(dy2d, N) if want_bias else None
-    hip.gemm(dy2d, x2d, dW, N, K, M, N, K, K, 0, 0, kscale=kscale, ks_div=ks_div, a_colsum=db)
-    return (dW, db) if want_bias else dW
-
-
-# ---------------------------------------------------------------------------------------------------
 # P-format path (csrc/gemm_p.hip): every GEMM operand is handed over as three pre-split bf16 planes.  Producers on the path
 # (LayerNorm, the GELU epilogue of fc1, ...) attach the P-format copy of their output to the tensor object (`_ofb_p`); anything
 # that arrives without one is converted by one ofb_to_pformat pass.  Weights are converted once per optimizer step (hip.weight_p).
 # ---------------------------------------------------------------------------------------------------
-def _use_p():
-    return hip.ENGINE == 'p'
-
-
 def _P(t, M, K):
     """P-format [M][K] copy of an activation (cached on the tensor object by its producer, else converted now)"""
     pm = getattr(t, '_ofb_p', None)
@@ -106,13 +69,21 @@ _cb_queued = [False]
 _SIDE_MIN_TOKENS = int(os.environ.get('OFB_SIDE_MIN_TOKENS', '12000'))
 
 
+def _grad_of(t):
+    """.grad of a parameter, also when `t` is a fresh reshaping view of it (whose own .grad is always None)"""
+    if t.grad is not None:
+        return t.grad
+    base = t._base
+    return base.grad if base is not None else None
+
+
 def _side_ok(*params, tokens=None):
     """weight-gradient work may go to the side stream unless a gradient is being accumulated into (AccumulateGrad would add on
     the main stream at once), the feature is off, or the step is host bound anyway (few tokens: the fork / join bookkeeping costs
     ~4 ms of host time per step - DeiT-T bs 8: 13.5 vs 9.4 ms per step - and buys nothing while the GPU waits for launches)"""
     if not hip.SIDE_STREAM or (tokens is not None and tokens < _SIDE_MIN_TOKENS):
         return False
-    if any(p is not None and p.grad is not None for p in params):
+    if any(p is not None and _grad_of(p) is not None for p in params):
         return False
     if not _cb_queued[0]:                                 # join at the end of this backward pass
         def _done():
@@ -132,9 +103,9 @@ def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None):
     """P-format backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None): dx (+resid fused), dW, db, dg.
     WP: the forward's P-format copy of W; dy_colsum: callable giving colsum(dY) (the raw bias gradient)."""
     N, K = WP.R, WP.C
+    side = _side_ok(W, b, tokens=M)                      # asked of the Parameter itself: a view's .grad is always None
     W = W.view(N, K)
     slot = grad_slot(W)
-    side = _side_ok(W, b, tokens=M)
     if gvec is None:
         dx, _ = p_linear_bwd_input(dyP, M, N, WP, K, resid=resid)
         dW = slot if slot is not None else _new(W, N, K)
@@ -159,44 +130,9 @@ def bias_grad(dy2d, rowscale=None, rs_div=1):
     return db
 
 
-def _gated_linear_bwd(dy2d, x2d, W, b, gvec, resid=None):
-    """Backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None).
-    Returns dx (+resid fused), dW, db, dg."""
-    N, K = W.shape
-    slot = grad_slot(W)                # data-parallel runs: the weight gradient lands in its all-reduce bucket, no copy
-    if gvec is None:
-        dx = linear_bwd_input(dy2d, W, resid=resid)
-        if b is None:
-            return dx, linear_bwd_weight(dy2d, x2d, out=slot), None, None
-        dW, db = linear_bwd_weight(dy2d, x2d, want_bias=True, out=slot)
-        return dx, dW, db, None
-    Weff = _new(W, N, K)
-    hip.scale_rows(W, gvec, Weff, N, K)
-    dx = linear_bwd_input(dy2d, Weff, resid=resid)
-    if b is not None:
-        dWraw, dbraw = linear_bwd_weight(dy2d, x2d, want_bias=True)
-    else:
-        dWraw, dbraw = linear_bwd_weight(dy2d, x2d), None
-    dW = slot if slot is not None else Weff                                    # else reuse Weff storage for dW
-    db, dg = (_new(W, N) if b is not None else None), _new(W, N)
-    hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K)
-    return dx, dW, db, dg
-
-
 def _rs_div(rowscale, M):
     """rowscale holds one factor per token (M entries) or per sample (B entries: every sample's N tokens share it)"""
     return 1 if rowscale is None else M // rowscale.numel()
-
-
-def _droppath_scaled(d2, rowscale):
-    """d2 * rowscale[token]: one HBM pass instead of a scale lookup inside the three GEMMs that consume it."""
-    if rowscale is None:
-        return d2
-    if rowscale.numel() != d2.shape[0]:
-        rowscale = rowscale.repeat_interleave(d2.shape[0] // rowscale.numel())
-    out = torch.empty_like(d2)
-    hip.scale_rows(d2, rowscale, out, d2.shape[0], d2.shape[1])
-    return out
 
 
 class Linear(torch.autograd.Function):
@@ -205,28 +141,21 @@ class Linear(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x2d, W, b):
         x2d, W = _c(x2d), _c(W)
-        if _use_p():
-            M, K = x2d.shape
-            xP, WP = _P(x2d, M, K), hip.weight_p(W)
-            ctx.save_for_backward(xP.buf, W, b)
-            ctx.mk, ctx.wp = (M, K), WP
-            return p_linear_fwd(xP, M, K, WP, b)[0]
-        ctx.save_for_backward(x2d, W, b)
-        return linear_fwd(x2d, W, b)
+        M, K = x2d.shape
+        xP, WP = _P(x2d, M, K), hip.weight_p(W)
+        ctx.save_for_backward(xP.buf, W, b)
+        ctx.mk, ctx.wp = (M, K), WP
+        return p_linear_fwd(xP, M, K, WP, b)[0]
 
     @staticmethod
     def backward(ctx, dy):
-        if _use_p():
-            xbuf, W, b = ctx.saved_tensors
-            M, K = ctx.mk
-            dy = _c(dy)
-            db = _new(dy, W.shape[0]) if b is not None else None
-            dyP = hip.to_pformat(dy, M, W.shape[0], W.shape[0], colsum_out=db)
-            dx, dW, db, _ = _p_gated_linear_bwd(dyP, lambda: db, _pm(xbuf, M, K), M, W, ctx.wp, b, None)
-            return dx, dW, db
-        x2d, W, b = ctx.saved_tensors
-        dx, dW, db, _ = _gated_linear_bwd(_c(dy), x2d, W, b, None)
-        return dx, dW, db
+        xbuf, W, b = ctx.saved_tensors
+        M, K = ctx.mk
+        dy = _c(dy)
+        db = _new(dy, W.shape[0]) if b is not None else None
+        dyP = hip.to_pformat(dy, M, W.shape[0], W.shape[0], colsum_out=db)
+        dx, dW, db, _ = _p_gated_linear_bwd(dyP, lambda: db, _pm(xbuf, M, K), M, W, ctx.wp, b, None)
+        return dx, dW.view(W.shape), db
 
 
 # Hand-overs around LayerNorm on the P-format path (no extra kernels, no extra passes over the activations):
@@ -268,12 +197,9 @@ class LayerNorm(torch.autograd.Function):
         D = x.shape[-1]
         rows = x.numel() // D
         y, mean, rstd = torch.empty_like(x), _new(x, rows), _new(x, rows)
-        if _use_p() and x.is_cuda:
-            yP = hip.PMat.for_rows_written_by_kernel(rows, D, x.device)
-            hip.layernorm_fwd_p(x, gamma, beta, y, yP, mean, rstd, rows, D, eps)
-            _ln_pending[0] = yP
-        else:
-            hip.layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps)
+        yP = hip.PMat.for_rows_written_by_kernel(rows, D, x.device)
+        hip.layernorm_fwd_p(x, gamma, beta, y, yP, mean, rstd, rows, D, eps)
+        _ln_pending[0] = yP
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.fork = fork
         ctx.up = up
@@ -288,7 +214,7 @@ class LayerNorm(torch.autograd.Function):
         rows = x.numel() // D
         nb = hip.layernorm_bwd_blocks(rows)
         dx = torch.empty_like(x)
-        if ctx.up is not None and _use_p():
+        if ctx.up is not None:
             rowscale = ctx.up[0]
             part = _new(x, nb, 3 * D)
             dxP = hip.PMat.for_rows_written_by_kernel(rows, D, x.device)
@@ -332,7 +258,11 @@ def _att_planes_ok(B, N):
 class AttnBranch(torch.autograd.Function):
     """out = resid + rowscale[token] * proj(attention(g * qkv(x)))   (layers.py:488-517 + residual/DropPath of
     vision_transformer.py:197,203).  If `resid` is None the branch input is also the residual (the search
-    path, where LN output replaces the stream) and its gradient add is fused into the qkv input-grad GEMM."""
+    path, where LN output replaces the stream) and its gradient add is fused into the qkv input-grad GEMM.
+    g: the gate as the module holds it - (H, d) joint space, (H, 1) head-only, (1, d) channel-only (layers.py:424-448).  The
+    broadcast to (H, d) happens HERE and its gradient is reduced back to g's shape inside backward, on the stream that produced
+    it: an `expand` outside this Function would put an autograd reduction kernel on the main stream between the side-stream
+    gate gradient and the join in BiMaskGates.backward (a race)."""
 
     @staticmethod
     def forward(ctx, x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale):
@@ -340,100 +270,82 @@ class AttnBranch(torch.autograd.Function):
         B, N, D = x.shape
         M = B * N
         x2d = x.view(M, D)
-        g3 = None if g is None else g.reshape(-1).repeat(3).contiguous()
-        r2d = x2d if resid is None else _c(resid).view(M, D)
-        if _use_p():
-            xP, wqP, wpP = _P(x, M, D), hip.weight_p(wqkv), hip.weight_p(wproj)
-            ctx.wp = (wqP, wpP)
-            qkv, _ = p_linear_fwd(xP, M, D, wqP, bqkv, colscale=g3)
-            if g3 is not None:
-                hip.gated_register(wqkv, g3, wqkv.shape[0], D)
-            Hd = qkv.shape[1] // 3
-            dh = Hd // heads
-            o, lse = _new(x, M, Hd), _new(x, B * heads, N)
-            if _att_planes_ok(B, N):                       # the attention kernel writes the projection's operand planes too
-                oP = hip.PMat.for_rows_written_by_kernel(M, Hd, x.device)
-                hip.attention_fwd_p(qkv, o, oP, lse, B, N, heads, dh, scale)
-            else:
-                hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
-                oP = hip.to_pformat(o, M, Hd, Hd)
-            out, _ = p_linear_fwd(oP, M, Hd, wpP, bproj, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
-            ctx.save_for_backward(xP.buf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, oP.buf)
-            ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None)
-            return out.view(B, N, D)
-        qkv = linear_fwd(x2d, wqkv, bqkv, colscale=g3)
-        Hd = qkv.shape[1] // 3
+        Hd = wqkv.shape[0] // 3
         dh = Hd // heads
+        g3, gshape = None, None
+        if g is not None:
+            gshape = tuple(g.shape)
+            if g.numel() != Hd:
+                if g.dim() != 2 or gshape[0] not in (1, heads) or gshape[1] not in (1, dh):
+                    raise hip.OfbError(f'attention gate of shape {gshape} does not broadcast to ({heads}, {dh})')
+                g = g.expand(heads, dh)
+            g3 = g.reshape(-1).repeat(3).contiguous()
+        r2d = x2d if resid is None else _c(resid).view(M, D)
+        xP, wqP, wpP = _P(x, M, D), hip.weight_p(wqkv), hip.weight_p(wproj)
+        ctx.wp = (wqP, wpP)
+        qkv, _ = p_linear_fwd(xP, M, D, wqP, bqkv, colscale=g3)
+        if g3 is not None:
+            hip.gated_register(wqkv, g3, wqkv.shape[0], D)
         o, lse = _new(x, M, Hd), _new(x, B * heads, N)
-        hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
-        out = linear_fwd(o, wproj, bproj, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
-        ctx.save_for_backward(x2d, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale)
-        ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None)
+        if _att_planes_ok(B, N):                       # the attention kernel writes the projection's operand planes too
+            oP = hip.PMat.for_rows_written_by_kernel(M, Hd, x.device)
+            hip.attention_fwd_p(qkv, o, oP, lse, B, N, heads, dh, scale)
+        else:
+            hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
+            oP = hip.to_pformat(o, M, Hd, Hd)
+        out, _ = p_linear_fwd(oP, M, Hd, wpP, bproj, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
+        ctx.save_for_backward(xP.buf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, oP.buf)
+        ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None, gshape)
         return out.view(B, N, D)
 
     @staticmethod
     def backward(ctx, dout):
-        if _use_p():
-            return AttnBranch._backward_p(ctx, dout)
-        x2d, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale = ctx.saved_tensors
-        B, N, D, heads, dh, scale, self_resid, has_pb = ctx.meta
-        M = B * N
+        xbuf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, obuf = ctx.saved_tensors
+        B, N, D, heads, dh, scale, self_resid, has_pb, gshape = ctx.meta
+        M, Hd = B * N, heads * dh
+        xP, oP = _pm(xbuf, M, D), _pm(obuf, M, Hd)
         d2 = _c(dout).view(M, D)
-        d2s = _droppath_scaled(d2, rowscale)          # gradient of the branch output (DropPath factor applied once)
-        do = linear_bwd_input(d2s, wproj)
-        if has_pb:
-            dwp, dbp = linear_bwd_weight(d2s, o, want_bias=True, out=grad_slot(wproj))
+        # gradient of the branch output: DropPath factor applied, planes written and the projection's bias gradient summed in ONE pass
+        hit = _take_grad_p(d2, rowscale, M, D)
+        if hit is not None:
+            d2sP, dbp = hit[0], (hit[1] if has_pb else None)
         else:
-            dwp, dbp = linear_bwd_weight(d2s, o, out=grad_slot(wproj)), None
-        dqkv = torch.empty_like(qkv)
-        hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
-        dx, dwq, dbq, dg3 = _gated_linear_bwd(dqkv, x2d, wqkv, bqkv, g3, resid=d2 if self_resid else None)
-        dg = None if dg3 is None else dg3.view(3, heads, dh).sum(0)
+            dbp = _new(d2, D) if has_pb else None
+            d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=dbp)
+        wqP, wpP = ctx.wp
+        do, _ = p_linear_bwd_input(d2sP, M, D, wpP, Hd)
+        dwp = grad_slot(wproj)
+        dwp = dwp if dwp is not None else _new(d2, D, Hd)
+        with (hip.side_work(d2.device, keep=[d2sP.buf, oP.buf]) if _side_ok(wproj, tokens=M) else _nullctx()):
+            p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=dwp)
+        # dq | dk | dv leave the attention kernel as planes, with the per-image column sums the qkv bias gradient is made of
+        dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
+        if _att_planes_ok(B, N):
+            dqkvP = hip.PMat.for_rows_written_by_kernel(M, 3 * Hd, d2.device)
+            colpart = _new(d2, B, 3 * Hd)
+            hip.attention_bwd_p(qkv, o, lse, do, dqkvP, colpart, B, N, heads, dh, scale)
+            if dbq_raw is not None:
+                hip.colsum(colpart, 3 * Hd, B, 3 * Hd, dbq_raw)
+        else:                                                   # sequence too long for the shifted tile origin: f32 rows + a conversion pass
+            dqkv = torch.empty_like(qkv)
+            hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
+            dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw)
+        dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None)
+        dg = None
+        if dg3 is not None:
+            # dg3 may still be in flight on the side stream: the 3-way sum and the reduction to the module's gate shape run there
+            # too; the consumer (BiMaskGates.backward) joins the side stream before it reads any gate gradient
+            with (hip.side_work(d2.device, keep=[dg3]) if hip._side_dirty[0] else _nullctx()):
+                dg = dg3.view(3, heads, dh).sum(0)
+                if gshape != (heads, dh):
+                    if gshape[0] == 1:
+                        dg = dg.sum(0, keepdim=True)
+                    if gshape[1] == 1:
+                        dg = dg.sum(1, keepdim=True)
+                if hip._side_dirty[0]:
+                    hip._side_keep.append(dg)
         dres = None if self_resid else dout
         return dx.view(B, N, D), dres, dwq, dbq, dwp, dbp, dg, None, None, None
-
-
-def _attn_backward_p(ctx, dout):
-    xbuf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, obuf = ctx.saved_tensors
-    B, N, D, heads, dh, scale, self_resid, has_pb = ctx.meta
-    M, Hd = B * N, heads * dh
-    xP, oP = _pm(xbuf, M, D), _pm(obuf, M, Hd)
-    d2 = _c(dout).view(M, D)
-    # gradient of the branch output: DropPath factor applied, planes written and the projection's bias gradient summed in ONE pass
-    hit = _take_grad_p(d2, rowscale, M, D)
-    if hit is not None:
-        d2sP, dbp = hit[0], (hit[1] if has_pb else None)
-    else:
-        dbp = _new(d2, D) if has_pb else None
-        d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=dbp)
-    wqP, wpP = ctx.wp
-    do, _ = p_linear_bwd_input(d2sP, M, D, wpP, Hd)
-    dwp = grad_slot(wproj)
-    dwp = dwp if dwp is not None else _new(d2, D, Hd)
-    with (hip.side_work(d2.device, keep=[d2sP.buf, oP.buf]) if _side_ok(wproj, tokens=M) else _nullctx()):
-        p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=dwp)
-    # dq | dk | dv leave the attention kernel as planes, with the per-image column sums the qkv bias gradient is made of
-    dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
-    if _att_planes_ok(B, N):
-        dqkvP = hip.PMat.for_rows_written_by_kernel(M, 3 * Hd, d2.device)
-        colpart = _new(d2, B, 3 * Hd)
-        hip.attention_bwd_p(qkv, o, lse, do, dqkvP, colpart, B, N, heads, dh, scale)
-        if dbq_raw is not None:
-            hip.colsum(colpart, 3 * Hd, B, 3 * Hd, dbq_raw)
-    else:                                                   # sequence too long for the shifted tile origin: f32 rows + a conversion pass
-        dqkv = torch.empty_like(qkv)
-        hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
-        dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw)
-    dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None)
-    dg = None
-    if dg3 is not None:                                   # dg3 may still be in flight on the side stream: add it up there
-        with (hip.side_work(d2.device, keep=[dg3]) if hip._side_dirty[0] else _nullctx()):
-            dg = dg3.view(3, heads, dh).sum(0)
-    dres = None if self_resid else dout
-    return dx.view(B, N, D), dres, dwq, dbq, dwp, dbp, dg, None, None, None
-
-
-AttnBranch._backward_p = staticmethod(_attn_backward_p)
 
 
 class MlpBranch(torch.autograd.Function):
@@ -450,72 +362,44 @@ class MlpBranch(torch.autograd.Function):
         hid = w1.shape[0]
         hpre = _new(x, M, hid)
         r2d = x2d if resid is None else _c(resid).view(M, D)
-        if _use_p():
-            xP, w1P, w2P = _P(x, M, D), hip.weight_p(w1), hip.weight_p(w2)
-            ctx.wp = (w1P, w2P)
-            # gelu(g * fc1(x)) leaves the kernel as the P-format operand of fc2 (and of the fc2 weight gradient); beside it only
-            # GELU'(pre-activation) is kept in f32 (`hpre` holds the derivative here): the epilogue has Phi and phi in hand, and the
-            # backward epilogue becomes a single multiply
-            _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU_GRAD, aux=hpre, want_f32=False, want_p=True)
-            if gv is not None:
-                hip.gated_register(w1, gv, hid, D)
-            out, _ = p_linear_fwd(hP, M, hid, w2P, b2, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
-            ctx.save_for_backward(xP.buf, hpre, hP.buf, w1, b1, w2, gv, rowscale)
-            ctx.meta = (B, N, D, resid is None, b2 is not None)
-            return out.view(B, N, D)
-        h = linear_fwd(x2d, w1, b1, colscale=gv, act=hip.ACT_GELU, aux=hpre)
-        out = linear_fwd(h, w2, b2, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
-        ctx.save_for_backward(x2d, hpre, h, w1, b1, w2, gv, rowscale)
+        xP, w1P, w2P = _P(x, M, D), hip.weight_p(w1), hip.weight_p(w2)
+        ctx.wp = (w1P, w2P)
+        # gelu(g * fc1(x)) leaves the kernel as the P-format operand of fc2 (and of the fc2 weight gradient); beside it only
+        # GELU'(pre-activation) is kept in f32 (`hpre` holds the derivative here): the epilogue has Phi and phi in hand, and the
+        # backward epilogue becomes a single multiply
+        _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU_GRAD, aux=hpre, want_f32=False, want_p=True)
+        if gv is not None:
+            hip.gated_register(w1, gv, hid, D)
+        out, _ = p_linear_fwd(hP, M, hid, w2P, b2, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
+        ctx.save_for_backward(xP.buf, hpre, hP.buf, w1, b1, w2, gv, rowscale)
         ctx.meta = (B, N, D, resid is None, b2 is not None)
         return out.view(B, N, D)
 
     @staticmethod
     def backward(ctx, dout):
-        if _use_p():
-            return MlpBranch._backward_p(ctx, dout)
-        x2d, hpre, h, w1, b1, w2, gv, rowscale = ctx.saved_tensors
+        xbuf, hpre, hbuf, w1, b1, w2, gv, rowscale = ctx.saved_tensors
         B, N, D, self_resid, has_b2 = ctx.meta
-        M = B * N
+        M, hid = B * N, w1.shape[0]
+        xP, hP = _pm(xbuf, M, D), _pm(hbuf, M, hid)
         d2 = _c(dout).view(M, D)
-        d2s = _droppath_scaled(d2, rowscale)
-        dhpre = linear_bwd_input(d2s, w2, act=hip.ACT_DGELU, aux=hpre)
-        if has_b2:
-            dw2, db2 = linear_bwd_weight(d2s, h, want_bias=True, out=grad_slot(w2))
+        hit = _take_grad_p(d2, rowscale, M, D)
+        if hit is not None:
+            d2sP, db2 = hit[0], (hit[1] if has_b2 else None)
         else:
-            dw2, db2 = linear_bwd_weight(d2s, h, out=grad_slot(w2)), None
-        dx, dw1, db1, dg = _gated_linear_bwd(dhpre, x2d, w1, b1, gv, resid=d2 if self_resid else None)
+            db2 = _new(d2, D) if has_b2 else None
+            d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=db2)
+        # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> P-format only
+        w1P, w2P = ctx.wp
+        # the fc1 bias gradient (column sums of this P-format-only result) rides on the epilogue
+        db1_raw = _new(hpre, hid) if b1 is not None else None
+        _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True, colsum_out=db1_raw)
+        dw2 = grad_slot(w2)
+        dw2 = dw2 if dw2 is not None else _new(d2, D, hid)
+        with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2, tokens=M) else _nullctx()):
+            p_linear_bwd_weight(d2sP, hP, M, D, hid, out=dw2)
+        dx, dw1, db1, dg = _p_gated_linear_bwd(dhP, lambda: db1_raw, xP, M, w1, w1P, b1, gv, resid=d2 if self_resid else None)
         dres = None if self_resid else dout
         return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None
-
-
-def _mlp_backward_p(ctx, dout):
-    xbuf, hpre, hbuf, w1, b1, w2, gv, rowscale = ctx.saved_tensors
-    B, N, D, self_resid, has_b2 = ctx.meta
-    M, hid = B * N, w1.shape[0]
-    xP, hP = _pm(xbuf, M, D), _pm(hbuf, M, hid)
-    d2 = _c(dout).view(M, D)
-    hit = _take_grad_p(d2, rowscale, M, D)
-    if hit is not None:
-        d2sP, db2 = hit[0], (hit[1] if has_b2 else None)
-    else:
-        db2 = _new(d2, D) if has_b2 else None
-        d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=db2)
-    # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> P-format only
-    w1P, w2P = ctx.wp
-    # the fc1 bias gradient (column sums of this P-format-only result) rides on the epilogue
-    db1_raw = _new(hpre, hid) if b1 is not None else None
-    _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True, colsum_out=db1_raw)
-    dw2 = grad_slot(w2)
-    dw2 = dw2 if dw2 is not None else _new(d2, D, hid)
-    with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2, tokens=M) else _nullctx()):
-        p_linear_bwd_weight(d2sP, hP, M, D, hid, out=dw2)
-
-    dx, dw1, db1, dg = _p_gated_linear_bwd(dhP, lambda: db1_raw, xP, M, w1, w1P, b1, gv, resid=d2 if self_resid else None)
-    dres = None if self_resid else dout
-    return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None
-
-
-MlpBranch._backward_p = staticmethod(_mlp_backward_p)
 
 
 def attn_branch(x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale):
@@ -543,12 +427,9 @@ class PatchEmbedTokens(torch.autograd.Function):
         patches = imgs.reshape(B, Cin, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * L, Cin * patch * patch)
         patches = _c(patches)
         w2d = wconv.reshape(D, -1)
-        if _use_p():
-            patchesP = hip.to_pformat(patches, B * L, w2d.shape[1], w2d.shape[1])
-            conv, _ = p_linear_fwd(patchesP, B * L, w2d.shape[1], hip.weight_p(wconv, (D, w2d.shape[1])), bconv)
-            patches = patchesP.buf                       # the backward needs the patches only as a weight-gradient operand
-        else:
-            conv = linear_fwd(patches, w2d, bconv)
+        patchesP = hip.to_pformat(patches, B * L, w2d.shape[1], w2d.shape[1])
+        conv, _ = p_linear_fwd(patchesP, B * L, w2d.shape[1], hip.weight_p(wconv, (D, w2d.shape[1])), bconv)
+        patches = patchesP.buf                           # the backward needs the patches only as a weight-gradient operand
         tok = _new(imgs, B, L + 1, D)
         gv = None if g is None else _c(g.reshape(-1))
         posv, clsv = _c(pos.reshape(L + 1, D)), _c(cls.reshape(-1))
@@ -573,12 +454,9 @@ class PatchEmbedTokens(torch.autograd.Function):
         dgm = _new(conv, 2, D)
         hip.colsum(part[1], D, chunks * (L + 1), D, dgm[0])
         hip.colsum(part[2], D, chunks * (L + 1), D, dgm[1])
-        if _use_p():
-            Kp = w2d.shape[1]
-            db = _new(dconv, D)
-            dw = p_linear_bwd_weight(hip.to_pformat(dconv, B * L, D, D, colsum_out=db), _pm(patches, B * L, Kp), B * L, D, Kp, out=grad_slot(w2d))
-        else:
-            dw, db = linear_bwd_weight(dconv, patches, want_bias=True, out=grad_slot(w2d))
+        Kp = w2d.shape[1]
+        db = _new(dconv, D)
+        dw = p_linear_bwd_weight(hip.to_pformat(dconv, B * L, D, D, colsum_out=db), _pm(patches, B * L, Kp), B * L, D, Kp, out=grad_slot(w2d))
         dcls = dpos[0].reshape(cshape)
         return (None, dw.view(wshape), db, None if gshape is None else dgm[0].view(gshape), dpos.view(pshape), dcls,
                 None if mshape is None else dgm[1].view(mshape), None, None)
@@ -647,22 +525,28 @@ class LabelSmoothingCE(torch.autograd.Function):
 
 
 class FlopsLoss(torch.autograd.Function):
-    """((searched - target) / total)^2 over the MAC model of vision_transformer.py:759-783 (base_model.py:31-35)."""
+    """((searched - target) / total)^2 over the MAC model of vision_transformer.py:759-783 (base_model.py:31-35).
+    n_active: None, or the 0-dim device tensor of the searched model's patch count (vision_transformer.py:768; differentiable
+    w.r.t. alpha_patch while more than one patch cell is live)."""
 
     @staticmethod
-    def forward(ctx, wsum, cfg):
-        out3, dws = _new(wsum, 3), torch.empty_like(wsum)
-        hip.flops_loss(wsum, cfg, out3, dws)
-        ctx.save_for_backward(dws)
-        ctx.mark_non_differentiable(out3)
-        return out3[0].clone(), out3
+    def forward(ctx, wsum, cfg, n_active=None):
+        out4, dws = _new(wsum, 4), torch.empty_like(wsum)
+        if n_active is not None:
+            n_active = n_active.detach().float().contiguous()
+            cfg.active_patches = n_active.data_ptr()
+        hip.flops_loss(wsum, cfg, out4, dws)
+        ctx.save_for_backward(dws, out4)
+        ctx.has_n = n_active is not None
+        ctx.mark_non_differentiable(out4)
+        return out4[0].clone(), out4
 
     @staticmethod
     def backward(ctx, up, _unused):
-        (dws,) = ctx.saved_tensors
+        dws, out4 = ctx.saved_tensors
         out = torch.empty_like(dws)
         hip.scale_by_scalar(dws, _c(up).reshape(1), out, dws.numel())
-        return out, None
+        return out, None, ((out4[3] * up) if ctx.has_n else None)
 
 
 class BiMaskGates(torch.autograd.Function):

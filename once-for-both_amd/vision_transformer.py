@@ -165,6 +165,7 @@ class VisionTransformer(nn.Module):
         return ['pos_embed', 'cls_token', 'dist_token']
 
     def forward_features(self, x):
+        hip.begin_forward()                                  # planes of the weights are re-made by the first GEMM of this pass
         pe = self.patch_embed
         x = ops.PatchEmbedTokens.apply(x, pe.proj.weight, pe.proj.bias, None, self.pos_embed, self.cls_token, None, None,
                                        pe.patch_size[0])
@@ -342,6 +343,7 @@ class MIMVisionTransformer(MAEBaseModel):
     def forward_features(self, x):
         B = x.shape[0]
         dev = x.device
+        hip.begin_forward()                                  # planes of the weights are re-made by the first GEMM of this pass
         self._compute_gates()
         pe = self.patch_embed
         g_e = self._module_gate(pe)
@@ -445,11 +447,29 @@ class MIMVisionTransformer(MAEBaseModel):
         if self._gate_out is None:
             self._compute_gates()
         cfg = self._flops_cfg(target)
+        n_act = self._active_patches()
         if cfg.n_live == 0:                                   # search finished: every slot is a constant
-            out3 = torch.empty(3, device=self.pos_embed.device)
-            hip.flops_loss(None, cfg, out3, None)
-            return out3[0].clone(), out3
-        return ops.FlopsLoss.apply(self._gate_out['wsum'], cfg)
+            out4 = torch.empty(4, device=self.pos_embed.device)
+            if n_act is not None:
+                n_act = n_act.detach().float().contiguous()
+                cfg.active_patches = n_act.data_ptr()
+            hip.flops_loss(None, cfg, out4, None)
+            return out4[0].clone(), out4
+        return ops.FlopsLoss.apply(self._gate_out['wsum'], cfg, n_act)
+
+    def _active_patches(self):
+        """`active_patches` of the FLOPs model (reference :768): self.weighted_mask.sum() once a patch-cell compress() has
+        produced the probability-weighted keep mask (:811-813), else None (= num_patches).  While more than one patch cell
+        is live it is a function of alpha_patch (the reference keeps the graph it built inside compress())."""
+        if getattr(self, 'weighted_mask', None) is None:
+            return None
+        dev = self.alpha_patch.device
+        sw = self.switch_cell_patch.reshape(-1).to(dev)
+        counts = self.patch_search_mask.sum((1, 2, 3)).to(dev)
+        if int(self.switch_cell_patch.sum()) == 1:
+            return counts[sw].sum()
+        pr = torch.softmax(self.alpha_patch.reshape(-1)[sw], 0)
+        return (pr * counts[sw]).sum()
 
     def get_flops(self):
         _, out3 = self._flops_eval(0.0)

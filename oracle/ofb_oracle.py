@@ -141,6 +141,7 @@ class SearchState:
     heads: Dict[str, int] = field(default_factory=dict)             # attention head_num after a compress
     frozen: set = field(default_factory=set)                        # parameter names whose requires_grad went False
     fused: bool = False
+    patch_weighted_mask: Optional[torch.Tensor] = None             # model.weighted_mask, set by a patch-cell compress() (:811-813)
 
     def cell_mask(self, name, alpha):
         sw = self.switch.get(name)
@@ -381,12 +382,25 @@ def sparsity_losses(cfg: Config, p, st: SearchState, gates, entropy=True, var=Tr
     return acc['attn'], acc['mlp'], l_patch, acc['embed']
 
 
-def flops_G(cfg: Config, gates, st: SearchState = None):
+def active_patches(cfg: Config, p, st: SearchState):
+    """`active_patches` of the FLOPs model (vision_transformer.py:768): the sum of the probability-weighted keep mask that a
+    patch-cell compress() leaves behind (:811-813), differentiable w.r.t. alpha_patch; None (= num_patches) before any."""
+    if st is None or getattr(st, 'patch_weighted_mask', None) is None or p is None:
+        return None
+    a = p['alpha_patch']
+    on = st.cell_mask('patch', a)
+    pr = masked_softmax(a, on)
+    L = cfg.num_patches
+    return sum(pr[0, j] * float(int(L * r)) for j, r in enumerate(cfg.patch_ratios()) if bool(on[0, j]))
+
+
+def flops_G(cfg: Config, gates, st: SearchState = None, p=None):
     """(total, searched) MACs/1e9 (vision_transformer.py:759-783, :207-220; layers.py:345-360,747-766,1032-1044).
     After compress() the LayerNorm term uses the cut embedding width (norm1.normalized_shape[0]) and the softmax /
     q@k terms the surviving head count (head_num); `total` keeps the original architecture."""
     N = cfg.num_patches
-    n = N                                   # active_patches: model has no weighted_mask attr -> num_patch
+    n = active_patches(cfg, p, st)          # model.weighted_mask exists only after a patch-cell compress(), else num_patch
+    n = N if n is None else n
     D, H, d, hid, P2 = cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden, cfg.patch_size ** 2
     e = gates['patch_embed'][2].sum()
     D_act = gates['patch_embed'][2].shape[-1]
@@ -416,7 +430,7 @@ def search_step_loss(cfg: Config, p, st: SearchState, imgs, labels, patch_noise,
     out = search_forward(cfg, p, st, imgs, patch_noise, droppath_u, training=True)
     base = label_smoothing_ce(out['logits'], labels)
     l_attn, l_mlp, l_patch, l_emb = sparsity_losses(cfg, p, st, out['gates'])
-    tot_f, sea_f = flops_G(cfg, out['gates'], st)
+    tot_f, sea_f = flops_G(cfg, out['gates'], st, p)
     l_flops = ((sea_f - target_flops) / tot_f) ** 2
     arch = w[0] * l_attn + w[1] * l_mlp + w[2] * l_patch + w[3] * l_emb + w[4] * l_flops
     if finish_search:
@@ -623,11 +637,57 @@ def compress_module(cfg: Config, p, st: SearchState, opt: OptimState, name: str,
     return None
 
 
+def compress_patch_cells(cfg: Config, p, st: SearchState, thresh: float):
+    """Patch-number part of MIMVisionTransformer.compress (vision_transformer.py:789-820).  Returns (finished, executed).
+    Live patch cells whose softmax probability is <= thresh / n_live are switched off and their alpha zeroed; alpha_patch is
+    replaced by a NEW tensor that no optimizer knows (the reference builds a fresh nn.Parameter and never re-registers it, so it
+    stops moving); one live cell left -> the patch search is finished and alpha_patch frozen.  `st.patch_weighted_mask` receives
+    the probability-weighted sum of the live cells' keep masks (:811-813)."""
+    a = p['alpha_patch']
+    on = st.cell_mask('patch', a)
+    if int(on.sum()) == 1:
+        st.frozen.add('alpha_patch')
+        return True, False
+    thr = thresh / int(on.sum())
+    pr = masked_softmax(a.detach(), on)
+    if float(pr[on].min()) > thr:
+        return False, False
+    on = pr > thr
+    a = torch.where(on, a.detach(), torch.zeros_like(a))
+    p['alpha_patch'], st.switch['patch'] = a, on
+    pr = masked_softmax(a, on)
+    L = cfg.num_patches
+    wm = torch.zeros(1, L, 1, dtype=a.dtype)
+    for j, r in enumerate(cfg.patch_ratios()):
+        if bool(on[0, j]):
+            m = torch.zeros(1, L, 1, dtype=a.dtype)
+            m[:, :int(L * r)] = 1
+            wm = wm + pr[0, j] * m
+    st.patch_weighted_mask = wm
+    finished = int(on.sum()) == 1
+    if finished:
+        st.frozen.add('alpha_patch')
+    return finished, True
+
+
+def patch_keep_ratio(cfg: Config, st: SearchState):
+    """keep ratio the forward uses under the patch-number search: the FIRST live cell's (vision_transformer.py:593)"""
+    on = st.switch.get('patch')
+    ratios = cfg.patch_ratios()
+    return ratios[0] if on is None else next(r for j, r in enumerate(ratios) if bool(on.reshape(-1)[j]))
+
+
 def compress_model(cfg: Config, p, st: SearchState, opt: OptimState = None, thresh=0.2):
-    """MIMVisionTransformer.compress (vision_transformer.py:785-950) for the one-patch-cell configuration.
-    Returns (finish_search, execute_prune)."""
+    """MIMVisionTransformer.compress (vision_transformer.py:785-950).  Returns (finish_search, execute_prune)."""
+    finish_patch, execute_patch = compress_patch_cells(cfg, p, st, thresh) if cfg.patch_search else (True, False)
+    if execute_patch and opt is not None:                                       # the replaced alpha_patch is unknown to the optimizer
+        for names in opt.groups.values():
+            if 'alpha_patch' in names:
+                names.remove('alpha_patch')
+        opt.state.pop('alpha_patch', None)
     keep = compress_module(cfg, p, st, opt, 'patch_embed', thresh)
     finish, execute = st.finished.get('patch_embed', False), st.execute.get('patch_embed', False)
+    finish, execute = finish and finish_patch, execute or execute_patch
     if keep is not None:                                                        # every consumer of the embedding width
         for k in ['mask_token', 'cls_token', 'pos_embed', 'norm.weight', 'norm.bias']:
             _slice_param(p, opt, k, keep, -1)

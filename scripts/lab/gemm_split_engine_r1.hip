@@ -1,3 +1,27 @@
+// LAB ONLY (not part of libofb_hip.so since round 3): the round-1 in-loop split engine (f32 operands split into three bf16 planes
+// while a tile is staged), kept as the A/B reference for the P-format engine (csrc/gemm_p.hip).  Build on its own:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -I once-for-both_amd/csrc scripts/lab/gemm_split_engine_r1.hip \
+//         once-for-both_amd/csrc/prof.hip -o scripts/lab/bin/libofb_split.so
+#include "ofb_common.h"
+typedef struct ofb_gemm_args {
+  const float* A; const float* B; float* C;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  int32_t a_kc, b_kc;
+  float alpha;
+  const float* bias;
+  const float* colscale;
+  const float* rowscale; int32_t rs_div;
+  const float* resid; int32_t ldr;
+  float* aux; int32_t ldaux;
+  int32_t act;
+  const float* kscale; int32_t ks_div;
+  float* workspace; int64_t workspace_bytes;
+  float* a_colsum;
+} ofb_gemm_args;
+extern "C" int64_t ofb_gemm_workspace_bytes(const ofb_gemm_args* args);
+extern "C" int32_t ofb_gemm_is_streamed(const ofb_gemm_args* args);
+extern "C" int ofb_gemm_f32(const ofb_gemm_args* args, void* stream);
 // f32 GEMM with fused epilogues on the bf16 matrix pipe at fp32 accuracy.
 //
 // f32 operands are split EXACTLY into three bf16 values (x = hi + mid + lo, round-to-nearest residual chain) while they are
@@ -547,15 +571,6 @@ __global__ __launch_bounds__(TC::BN) void gemm_fixup_kernel(const ofb_gemm_args 
   }
 }
 
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, int splits, int64_t count, float* __restrict__ out,
-                                     int accumulate) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = accumulate ? out[i] : 0.f;
-    for (int z = 0; z < splits; ++z) s += ws[(size_t)z * count + i];
-    out[i] = s;
-  }
-}
-
 template <class TC, bool A_KC, bool B_KC, bool VEC, bool GUARD>
 void launch2(const ofb_gemm_args& g, const Plan& p, bool full, hipStream_t s) {
   const dim3 grid(p.W), block(TC::NT);
@@ -712,11 +727,3 @@ extern "C" int ofb_diag_gemm_stamps(unsigned long long* out_host) {      /* lab 
 }
 #endif
 
-extern "C" int ofb_splitk_reduce(const float* workspace, int32_t splits, int64_t count, float* out, int32_t accumulate,
-                                 void* stream) {
-  if (!workspace || !out || splits <= 0 || count <= 0) return OFB_EINVAL;
-  const int blocks = (int)((count + 255) / 256 < 2048 ? (count + 255) / 256 : 2048);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, workspace, splits, count, out,
-                     accumulate);
-  return ofb_launch_status();
-}

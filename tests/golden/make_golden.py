@@ -362,6 +362,115 @@ def run_compress_case(tag='mini_c', batch=2, w_p=0.7, keep_ratio=0.9, drop_path=
     print(f'   -> {os.path.getsize(path) / 1024:.0f} KiB')
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# patch-cell compress() (vision_transformer.py:789-820): the patch-number search driven through compress.
+# step -> crafted alpha_patch -> compress (two cells die) -> step -> crafted alpha_patch -> compress (one cell left: the patch
+# search finishes, alpha_patch frozen) -> step.  The reference calls reduce_tensor(alpha_patch) without the try/except its module
+# compress()es have (Appendix C note 4): in this one-process run it is replaced by the identity it is for a world of one.
+# ----------------------------------------------------------------------------------------------------------------
+def craft_alpha_patch(stage):
+    if stage == 1:
+        return np.array([[0.30, -6.0, 0.10, -6.0, 0.20]], np.float32)          # cells 1 and 3 die (p <= 0.2 / 5)
+    return np.array([[-6.0, 0.0, 0.50, 0.0, -6.0]], np.float32)                # of the live {0, 2, 4} only cell 2 survives -> finished
+
+
+def run_patch_compress_case(tag='micro_pc', batch=2, w_p=0.8, drop_path=0.0, lr=1e-3, thresh=0.2):
+    cfg = O.Config(**dict(O.MICRO, patch_search=True), drop_path_rate=drop_path)
+    model = build_reference(cfg, drop_path)
+    names = O.module_names(cfg)
+    by_name = dict(zip(names, model.searchable_modules))
+    for mod in model.searchable_modules:
+        mod.w_p = w_p
+    imgs = torch.from_numpy(fill.images(batch))
+    labels = torch.from_numpy(fill.labels(batch, cfg.num_classes))
+    pnoise = torch.from_numpy(fill.patch_noise(batch, cfg.num_patches))
+
+    def fake_rand(*shape, **kw):
+        shape = shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape
+        if tuple(shape) == (batch, cfg.num_patches):
+            return pnoise.clone()
+        raise RuntimeError(f'unexpected rand shape {shape}')
+
+    groups = {'nodecay': [], 'decay': [], 'decoder_nodecay': [], 'decoder_decay': [], 'arch': []}
+    gnames = {k: [] for k in groups}
+    for k, p in model.named_parameters():
+        if p.requires_grad:
+            grp = O.optimizer_group(k, tuple(p.shape))
+            groups[grp].append(p)
+            gnames[grp].append(k)
+    opt_p = ROPT.AdamW([{'params': groups['nodecay'], 'weight_decay': 0.}, {'params': groups['decay'], 'weight_decay': 1e-3}],
+                       {0: gnames['nodecay'], 1: gnames['decay']}, lr=lr, eps=1e-8, betas=(0.9, 0.999))
+    opt_d = ROPT.AdamW([{'params': groups['decoder_nodecay'], 'weight_decay': 0.}, {'params': groups['decoder_decay'], 'weight_decay': 1e-3}],
+                       {0: gnames['decoder_nodecay'], 1: gnames['decoder_decay']}, lr=lr, eps=1e-8, betas=(0.9, 0.999))
+    opt_a = ROPT.AdamW(groups['arch'], {0: gnames['arch']}, lr=lr, eps=1e-8, betas=(0.5, 0.999), weight_decay=1e-3)
+    opts = {'p': opt_p, 'd': opt_d, 'a': opt_a}
+    crit = RLOSS.OFBSearchLOSS(RLOSS.DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0),
+                                torch.device('cpu'), attn_w=0.5, mlp_w=0.5, patch_w=0.5, embedding_w=0.5, flops_w=5.0)
+    wrapped = _Wrap(model)
+    out = dict(meta=np.array([batch, w_p, drop_path, lr, thresh], np.float64))
+    real_rand, real_sync, real_reduce = torch.rand, torch.cuda.synchronize, RVT.reduce_tensor
+    torch.cuda.synchronize = lambda *a, **k: None
+    RVT.reduce_tensor = lambda t: t.clone()                   # world of one: the average over ranks is the tensor itself
+
+    def step(pre):
+        model.train()
+        for p in model.parameters():
+            p.grad = None
+        torch.rand = fake_rand
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                logits, (dec_loss, _) = wrapped(imgs)
+                base, arch = crit(imgs, logits, labels, wrapped, 'arch', 1.0, False)
+                l_attn, l_mlp, l_patch, l_emb = model.get_sparsity_loss(torch.device('cpu'))
+            total = base + arch + (base / dec_loss).data.clone() * dec_loss
+            total.backward()
+        finally:
+            torch.rand = real_rand
+        out.update({f'{pre}.logits': logits.detach().numpy(), f'{pre}.decoder_loss': dec_loss.item(), f'{pre}.base': base.item(),
+                    f'{pre}.arch': arch.item(), f'{pre}.loss_total': total.item(), f'{pre}.loss_patch': float(l_patch)})
+        for k, p in model.named_parameters():
+            if p.grad is None:
+                continue
+            out[f'{pre}.gnorm.{k}'] = np.float64(p.grad.double().norm().item())
+            if 'alpha' in k or 'score' in k:
+                out[f'{pre}.grad.{k}'] = p.grad.numpy().copy()
+        for o in opts.values():
+            o.step()
+        out[f'{pre}.after.alpha_patch'] = model.alpha_patch.detach().numpy().copy()
+
+    def snapshot(pre, fin, ex):
+        out[f'{pre}.model_flags'] = np.array([fin, ex], np.int64)
+        out[f'{pre}.switch_patch'] = model.switch_cell_patch.numpy().copy()
+        out[f'{pre}.alpha_patch'] = model.alpha_patch.detach().numpy().copy()
+        out[f'{pre}.alpha_patch_rg'] = np.array(bool(model.alpha_patch.requires_grad))
+        out[f'{pre}.weighted_mask_patch'] = model.weighted_mask.detach().numpy().copy()
+        for name, mod in by_name.items():
+            out[f'{pre}.switch.{name}'] = mod.switch_cell.numpy().copy()
+            out[f'{pre}.flags.{name}'] = np.array([mod.finish_search, mod.execute_prune], np.int64)
+        for k, p in model.named_parameters():
+            out[f'{pre}.shape.{k}'] = np.array(p.shape, np.int64)
+
+    try:
+        step('s0')
+        for stage in (1, 2):
+            a = craft_alpha_patch(stage)
+            model.alpha_patch.data.copy_(torch.from_numpy(a))
+            out[f'craft{stage}.alpha_patch'] = a
+            with contextlib.redirect_stdout(io.StringIO()):
+                fin, ex, opts['p'], opts['d'], opts['a'] = model.compress(thresh, opts['p'], opts['d'], opts['a'])
+            snapshot(f'c{stage}', fin, ex)
+            step(f's{stage}')
+    finally:
+        torch.cuda.synchronize = real_sync
+        RVT.reduce_tensor = real_reduce
+    assert int(model.switch_cell_patch.sum()) == 1 and not model.alpha_patch.requires_grad
+    path = os.path.join(HERE, f'{tag}.npz')
+    np.savez_compressed(path, **out)
+    print(f'{tag}: ' + ' '.join(f's{i}: total={out[f"s{i}.loss_total"]:.5f} patch={out[f"s{i}.loss_patch"]:.5f}' for i in range(3)),
+          '| switches', out['c1.switch_patch'].astype(int).tolist(), out['c2.switch_patch'].astype(int).tolist(),
+          f'-> {os.path.getsize(path) / 1024:.0f} KiB')
+
+
 def kernel_goldens():
     """Piece-level vectors straight from reference functions."""
     imgs = torch.from_numpy(fill.images(1, tag='nt'))
@@ -378,6 +487,9 @@ if __name__ == '__main__':
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == 'compress':
         run_compress_case()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == 'patch_compress':  # only the patch-cell life cycle (round 3)
+        run_patch_compress_case()
         sys.exit(0)
     micro = O.MICRO
     if len(sys.argv) > 1 and sys.argv[1] == 'ctor':          # only the constructor-surface cases (round 2)
@@ -406,3 +518,4 @@ if __name__ == '__main__':
     run_case('small_a', dict(O.DEIT_SMALL, num_classes=1000), batch=2, w_p=0.7, keep_ratio=0.9, drop_path=0.1, switches=sw_s)
     kernel_goldens()
     run_compress_case()
+    run_patch_compress_case()

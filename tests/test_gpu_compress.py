@@ -192,3 +192,50 @@ def test_model_ema_fused_update_and_reshape():
     assert torch.equal(esd['blocks.0.mlp.fc1.weight'], m.blocks[0].mlp.fc1.weight.data)
     assert ema.ema.blocks[0].mlp.fc1.out_features == 128
     ema.update(m)
+
+
+def test_patch_cell_compress_lifecycle_matches_reference():
+    """patch-number search driven through compress() (reference vision_transformer.py:789-820; tests/golden/micro_pc.npz from the
+    reference's own run): two patch cells die, then one is left (finished, alpha_patch frozen).  After the first patch-cell cut
+    the FLOPs model counts the probability-weighted patch number (:768) and alpha_patch receives its gradient."""
+    from ofb_amd.engine import build_optimizers
+    from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
+    from tests.patch_compress_util import load, check_step as pc_step, check_snapshot as pc_snap
+    z, cfg, c = load()
+    st = O.SearchState(w_p=c['w_p'])
+    inputs = dict(patch_noise=c['pnoise'], droppath_u=torch.zeros(2 * cfg.depth, c['batch']))
+    m = build_product(cfg, st, inputs)
+    opt_p, opt_a, opt_d = build_optimizers(m, lr=c['lr'], weight_decay=1e-3)
+    opts = {'p': opt_p, 'd': opt_d, 'a': opt_a}
+    crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), torch.device('cuda'),
+                         attn_w=0.5, mlp_w=0.5, patch_w=0.5, embedding_w=0.5, flops_w=5.0)
+    imgs, labels = c['imgs'].cuda(), c['labels'].cuda()
+
+    def step():
+        m.train()
+        for p in m.parameters():
+            p.grad = None
+        logits, (dec, _) = m(imgs)
+        base, arch = crit(imgs, logits, labels, m, 'arch', 1.0, False)
+        total = base + arch + (base / dec).detach() * dec
+        total.backward()
+        lp = m.get_sparsity_loss(torch.device('cuda'))[2]
+        grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in m.named_parameters()}
+        for o in opts.values():
+            if o is not None:
+                o.step()
+        torch.cuda.synchronize()
+        return dict(logits=logits, decoder_loss=dec.detach(), base=base.detach(), arch=arch.detach(), loss_total=total.detach(),
+                    loss_patch=lp.detach()), grads
+
+    out, grads = step()
+    pc_step(z, 's0', out, grads, m.alpha_patch, tol=1e-4)
+    names = O.module_names(cfg)
+    for stage in (1, 2):
+        m.alpha_patch.data.copy_(torch.from_numpy(z[f'craft{stage}.alpha_patch']))
+        fin, ex, opts['p'], opts['d'], opts['a'] = m.compress(c['thresh'], opts['p'], opts['d'], opts['a'])
+        pc_snap(z, f'c{stage}', fin, ex, m.switch_cell_patch, m.alpha_patch, m.alpha_patch.requires_grad, m.weighted_mask,
+                {n: mod.switch_cell for n, mod in zip(names, m.searchable_modules)}, {k: tuple(p.shape) for k, p in m.named_parameters()})
+        out, grads = step()
+        pc_step(z, f's{stage}', out, grads, m.alpha_patch, tol=1e-4)
+    assert int(m.switch_cell_patch.sum()) == 1 and not m.alpha_patch.requires_grad

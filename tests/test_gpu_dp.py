@@ -1,0 +1,114 @@
+"""The data-parallel exchange on the device (configs[2]; reference search.py:617-620 wraps the model in DistributedDataParallel):
+ONE process, one MI355X, a one-rank RCCL group.  `GradAllReducer(force_collective=True)` then really all-reduces its flat buckets
+through RCCL, the weight-gradient GEMMs write straight into their bucket slices from the side stream, small gradients are gathered
+by one multi-tensor launch, `.grad` is re-pointed at the bucket - and the parameters must come out BIT-IDENTICAL to a run without
+any reducer (world size 1: the average is the gradient itself)."""
+import os
+import socket
+
+import pytest
+import torch
+
+from oracle import ofb_oracle as O
+from tests.golden_util import load_case
+from tests.test_gpu_model import build_product
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def rccl_world_of_one():
+    import torch.distributed as dist
+    if dist.is_initialized():
+        yield
+        return
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', world_size=1, rank=0, device_id=torch.device('cuda', 0))
+    yield
+    dist.destroy_process_group()
+
+
+def _crit():
+    from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
+    return OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), torch.device('cuda'),
+                         attn_w=0.5, mlp_w=0.5, patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+
+
+def _run(tag, use_reducer, accum_iter, side_stream, compress_after=None, steps=3):
+    """`steps` optimizer steps (each `accum_iter` micro-steps) of engine.search_step on the golden case's model; optionally a
+    forced compress() + reducer.rebuild() after optimizer step `compress_after`.  Returns the final state_dict."""
+    import ofb_amd
+    from ofb_amd import engine, hip, ops
+    z, cfg, st, inputs, lr = load_case(tag)
+    m = build_product(cfg, st, inputs)
+    opts = engine.build_optimizers(m, 1e-3)
+    red = ofb_amd.dp.GradAllReducer(list(m.parameters()), bucket_bytes=256 * 1024, force_collective=True) if use_reducer else None
+    crit = _crit()
+    imgs, labels = inputs['imgs'].cuda(), inputs['labels'].cuda()
+    old_min, old_side = ops._SIDE_MIN_TOKENS, hip.SIDE_STREAM
+    ops._SIDE_MIN_TOKENS, hip.SIDE_STREAM = 0, side_stream          # micro models are far below the 12k-token switch-on point
+    try:
+        if red is not None:
+            assert red.force_collective and len(red.buckets) >= 2
+        opts = list(opts)
+        for k in range(steps):
+            for a in range(accum_iter):
+                engine.search_step(m, crit, imgs, labels, 1.0, opts, accum_iter=accum_iter, do_step=(a == accum_iter - 1), reducer=red)
+            if compress_after is not None and k == compress_after:
+                mods = dict(zip(O.module_names(cfg), m.searchable_modules))
+                a7 = torch.full((1, 7), -6.0)
+                a7[0, 2] = 0.0
+                mods['blocks.0.mlp'].alpha.data.copy_(a7)          # one cell survives: fc1 / fc2 are cut, alpha leaves the optimizer
+                fin, ex, opts[0], opts[2], opts[1] = m.compress(0.2, opts[0], opts[2], opts[1])
+                assert ex
+                if red is not None:
+                    red.rebuild(list(m.parameters()))
+        torch.cuda.synchronize()
+        if red is not None:                                         # gradients of the last window live in the buckets
+            owners = {v.data_ptr() for views in red._views for v in views}
+            live = [p for p in m.parameters() if p.grad is not None]
+            assert live and all(p.grad.data_ptr() in owners for p in live)
+        return {k: v.detach().clone() for k, v in m.state_dict().items()}
+    finally:
+        ops._SIDE_MIN_TOKENS, hip.SIDE_STREAM = old_min, old_side
+        if red is not None:
+            red.close()
+
+
+@pytest.mark.parametrize('accum_iter,side', [(1, True), (2, True), (1, False)])
+def test_rccl_bucket_exchange_is_bit_identical_to_no_reducer(rccl_world_of_one, accum_iter, side):
+    ref = _run('micro_b', False, accum_iter, side)
+    got = _run('micro_b', True, accum_iter, side)
+    bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+    assert not bad, bad
+
+
+def test_rccl_exchange_survives_compress_and_rebuild(rccl_world_of_one):
+    ref = _run('micro_a', False, 1, True, compress_after=0)
+    got = _run('micro_a', True, 1, True, compress_after=0)
+    assert tuple(got['blocks.0.mlp.fc1.weight'].shape) == (128, 64)
+    bad = [k for k in ref if not torch.equal(ref[k], got[k])]
+    assert not bad, bad
+
+
+def test_rccl_all_reduce_moves_bytes(rccl_world_of_one):
+    """the forced collective really runs on RCCL: the returned work handles are real and a bucket all-reduced in a group of one
+    comes back unchanged"""
+    import torch.distributed as dist
+    import ofb_amd
+    ps = [torch.nn.Parameter(torch.randn(n, device='cuda')) for n in (70000, 33, 4096)]
+    red = ofb_amd.dp.GradAllReducer(ps, bucket_bytes=64 * 1024, force_collective=True)
+    try:
+        (sum((p * (i + 1)).sum() for i, p in enumerate(ps))).backward()
+        assert red._works and all(w is not None for _, w in red._works)
+        red.prescaled = True
+        red.finalize()
+        for i, p in enumerate(ps):
+            assert torch.equal(p.grad, torch.full_like(p, float(i + 1)))
+        assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
+    finally:
+        red.close()

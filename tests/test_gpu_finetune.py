@@ -58,3 +58,11 @@ def test_pruned_vit_forward_backward(D, heads, dhs, hids):
         worst = max(worst, err)
         assert err < 1e-3, (k, err)
     print(f'worst grad rel err {worst:.2e}')
+
+
+def test_pruned_vit_bench_config4_shapes():
+    """the shape set `bench.py --mode finetune` reports (configs[4]: FT_EMBED = 264, blocks (heads, head dim, hidden) of
+    bench.FT_BLOCKS) against the fp64 oracle, forward + backward: N = 264 is 1.375 GEMM column tiles, head dims 48 / 40 / 32 / 56."""
+    import bench
+    blocks = bench.FT_BLOCKS[:4]
+    test_pruned_vit_forward_backward(bench.FT_EMBED, [h for h, _, _ in blocks], [dh for _, dh, _ in blocks], [hid for _, _, hid in blocks])
