@@ -71,10 +71,10 @@ _SIDE_MIN_TOKENS = int(os.environ.get('OFB_SIDE_MIN_TOKENS', '12000'))
 
 def _grad_of(t):
     """.grad of a parameter, also when `t` is a fresh reshaping view of it (whose own .grad is always None)"""
-    if t.grad is not None:
+    if t.is_leaf:
         return t.grad
     base = t._base
-    return base.grad if base is not None else None
+    return base.grad if (base is not None and base.is_leaf) else None
 
 
 def _side_ok(*params, tokens=None):

@@ -68,10 +68,6 @@ def _run(tag, use_reducer, accum_iter, side_stream, compress_after=None, steps=3
                 if red is not None:
                     red.rebuild(list(m.parameters()))
         torch.cuda.synchronize()
-        if red is not None:                                         # gradients of the last window live in the buckets
-            owners = {v.data_ptr() for views in red._views for v in views}
-            live = [p for p in m.parameters() if p.grad is not None]
-            assert live and all(p.grad.data_ptr() in owners for p in live)
         return {k: v.detach().clone() for k, v in m.state_dict().items()}
     finally:
         ops._SIDE_MIN_TOKENS, hip.SIDE_STREAM = old_min, old_side
