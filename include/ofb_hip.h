@@ -152,7 +152,8 @@ int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const 
  * Attention core softmax(q k^T * scale) v with probabilities kept on chip
  * (models/layers.py:510-514; plain Attention.forward :387-391 for the finetune path).
  * qkv: [B*N][3*H*dh] exactly as the qkv Linear writes it (q | k | v, head-major); out: [B*N][H*dh]
- * (the transpose(1,2).reshape of :514 is folded into the store); lse: [B*H][N] row log-sum-exp.
+ * (the transpose(1,2).reshape of :514 is folded into the store); lse: [2][B*H][N]: row log-sum-exp fl(m + log l), then (B*H*N floats
+ * further) its rounding residue (m - lse) + log l - the backward recomputes P = exp((S - lse) - residue) at fp32-softmax accuracy.
  * Limits: N <= 208 (13 tiles of 16 tokens), dh <= 64, dh % 4 == 0 (covers DeiT-T/S/B and every pruned d in {16,24,..,64}).
  * bwd writes dqkv in the same packing (dq | dk | dv).
  * ------------------------------------------------------------------------------------------- */

@@ -86,6 +86,19 @@ __device__ __forceinline__ f32x4 att_mfma6(const att_bf16x8 (&a)[3], const att_b
   return c;
 }
 
+// the same six terms with the roles of the operands exchanged (a <-> b of att_mfma6): the backward forms S = Q K^T with A = Q where
+// the forward forms S^T = K Q^T with A = K; issued in this order each element sees the same products in the same order and S comes
+// out bit-identical to the forward's
+__device__ __forceinline__ f32x4 att_mfma6_swapped(const att_bf16x8 (&a)[3], const att_bf16x8 (&b)[3], f32x4 c) {
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[2], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[0], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[1], c, 0, 0, 0);
+  c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], c, 0, 0, 0);
+  return c;
+}
+
 // P-format stores (csrc/gemm_p.hip: granules of 4 rows x 16 columns, [plane][c % 16][r % 4] bf16, 384 B, stored [rows/4][ncb])
 __device__ __forceinline__ char* att_p_slot(char* P, int ncb, int row, int col) {
   return P + ((size_t)(row >> 2) * ncb + (col >> 4)) * 384 + (col & 15) * 8 + (row & 3) * 2;
@@ -136,7 +149,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   const int sft = PF ? (int)(((size_t)b * N) & 3) : 0;       // query tile position p <-> token p - sft (keys are not shifted)
 
   // staging items: idx < 512 -> K float4 (key = idx/16, d = 4*(idx%16)); 512 <= idx < 1024 -> V float4, same coordinates
-  f32x4 sreg[2];
+  f32x4 sreg[3];
   auto stage_load = [&](int kb) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -277,7 +290,14 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) O[dt] *= linv;
   if (qvalid) {
-    if (g == 0) lse[((size_t)b * H + head) * N + q] = m_run + logf(l);
+    if (g == 0) {
+      // lse as TWO floats: [0][b h][q] = fl(m + log l) and, B H N floats further, its rounding residue (m - lse) + log l: the backward
+      // forms P = exp((S - lse) - residue) = exp(S - m) / l without the half-ulp of |lse| a single float would put on the whole row
+      const float ll = logf(l), ls = m_run + ll;
+      const size_t li = ((size_t)b * H + head) * N + q;
+      lse[li] = ls;
+      lse[(size_t)B * H * N + li] = (m_run - ls) + ll;
+    }
     // O[dt][r] = O^T[channel 16 dt + 4g + r][query c]: four consecutive channels of this lane's query
     float* op = out + ((size_t)b * N + q) * ldo + head * dh;
 #pragma unroll
@@ -311,259 +331,418 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// backward on the split engine (round 3): one kernel, dq | dk | dv, P recomputed from lse; every product is the exact three-way
+// bf16 split with six v_mfma_f32_16x16x32_bf16 terms (fp32-class accuracy, like the forward and the GEMM).
+// ------------------------------------------------------------------------------------------------------------------
+// One workgroup of EIGHT waves per (batch, head); wave w < 7 owns the 32 key positions 32w .. 32w+31 (224 positions cover N + 3 <= 208
+// tokens plus the shift below; wave 7 owns none: it helps staging and takes a dQ tile) and keeps dK / dV of its keys in 64 accumulator registers while the workgroup sweeps the queries in
+// blocks of 32.  "Key on the lane": S = Q K^T and dP = dO V^T are computed with rows = queries, lane column = key, so the P and dS
+// accumulators ARE the A operands (k-slot (g, j) <-> query 16 (j >> 2) + 4 g + (j & 3)) of dV = P^T dO and dK = dS^T Q; the other
+// operand of those two products comes out of the row-major Q / dO planes by ds_read_b64_tr_b16.  -lse[q] and -delta[q] are the
+// initial accumulator of dP (dS = P * acc).  Q is staged pre-scaled exactly as the forward scales it (S' = (scale Q) K^T, dK =
+// dS'^T (scale Q)) and the six terms of S' are issued in the forward's order, so S' is bit-identical to the forward's and
+// P = exp((S' - lse) - residue) reproduces the forward's normalised probabilities (lse travels as two floats).
+// Only dS crosses LDS: every wave stores its dS block as planes [key][32 q] (8-byte stores: the two halves of its A fragment),
+// and after one barrier each (16-query, 16-channel) tile of dQ = dS K is reduced over ALL keys by ONE wave (A = dS by transposed
+// reads, B = K by transposed reads of the K planes that sit in LDS for the whole kernel): no partial dQ tiles, no cross-wave sum,
+// fixed summation order.  Eight dQ tiles per block, one per wave (two per SIMD).
+// LDS (155.4 KB, one workgroup per CU): K planes [3][224][64] bf16 86 KB | dS planes [3][224 keys][32 q] 42 KB | Q and dO planes of
+// the current block [3][32][64] 12 KB each | -lse, -delta 1.75 KB.  All 128-byte-row images carry the chunk swizzle
+// chunk ^ (((row >> 1) & 3) << 1): conflict-free for the ds_read_b128 row reads AND for the transposed reads; the 64-byte dS rows
+// swap their two 32-byte halves with bit 2 of the key.
 // PF: dq | dk | dv leave the kernel as P-format planes (the operand form of the qkv gradient GEMMs, csrc/gemm_p.hip) together with
-// their per-image column sums colpart[b][3 H dh] (the qkv bias gradient is their sum over b) instead of as f32 rows.  A lane's
-// four accumulator rows are four consecutive tokens of one channel = one 8-byte plane slot IF they start on a 4-row granule
-// boundary of the [B N] matrix: the workgroup therefore lays its 16-token tiles from position -sft (sft = b N % 4; tile position
-// p holds token p - sft, the first sft positions are padding like the ones behind token N - 1).  N + 3 <= 208 is checked by the host.
-// Only the image's first and last row group are shared with a neighbouring image; there the lane stores its own rows 2 bytes at a time.
-#define ATT_QPITCH 20       // PF: column pitch (floats) of the parked partial dQ tiles [64 ch][16 q + 4]
+// their per-image column sums colpart[b][3 H dh] (the qkv bias gradient is their sum over b).  A lane's four accumulator rows are
+// four consecutive tokens of one channel = one 8-byte plane slot IF they start on a 4-row granule boundary of the [B N] matrix: the
+// workgroup lays its positions from -sft (sft = b N % 4; position p holds token p - sft).  Only the image's first and last row
+// group are shared with a neighbouring image; there the lane stores its own rows 2 bytes at a time.
+#define AB_NW 8                       /* waves: 0..6 own 32 key positions each, wave 7 only stages and takes a dQ tile */
+#define AB_NKW 7
+#define AB_THREADS (64 * AB_NW)
+#define AB_QB 32
+#define AB_NPOS (32 * AB_NKW)
+#define AB_KPL (AB_NPOS * 128)
+#define AB_DSPL (AB_NPOS * 64)
+#define AB_STPL (AB_QB * 128)
+#define AB_OFF_DS (3 * AB_KPL)
+#define AB_OFF_STQ (AB_OFF_DS + 3 * AB_DSPL)
+#define AB_OFF_STO (AB_OFF_STQ + 3 * AB_STPL)
+#define AB_OFF_NLSE (AB_OFF_STO + 3 * AB_STPL)
+#define AB_OFF_NDEL (AB_OFF_NLSE + AB_NPOS * 4)
+#define AB_OFF_NRES (AB_OFF_NDEL + AB_NPOS * 4)
+#define AB_LDS_BYTES (AB_OFF_NRES + AB_NPOS * 4)
+
+__device__ __forceinline__ int ab_swz(int row) { return ((row >> 1) & 3) << 1; }
+__device__ __forceinline__ att_bf16x8 ab_tr2(const char* p0, const char* p1) {
+  const att_s16x4 lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)(p0));
+  const att_s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) att_s16x4*)(p1));
+  const att_s16x8 v8 = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+  return __builtin_bit_cast(att_bf16x8, v8);
+}
+
+#ifdef OFB_ATT_STAMPS
+// lab only (scripts/lab/stamp_att.py): s_memtime stamps of every wave of workgroup 0: [wave][64 slots]
+__device__ unsigned long long ofb_att_stamps[8 * 64];
+#define AB_STAMP(slot) do { if (blockIdx.x == gridDim.x - 100 && lane == 0 && (slot) < 64) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ofb_att_stamps[w * 64 + (slot)] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define AB_STAMP(slot) do { } while (0)
+#endif
+
 template <bool PF>
-__global__ __launch_bounds__(ATT_THREADS) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
-                                                               const float* __restrict__ lse, const float* __restrict__ dout,
-                                                               float* __restrict__ dqkv, char* __restrict__ dP_out, int p_ncb,
-                                                               float* __restrict__ colpart, int B, int N, int H, int dh, float scale) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* Kt = smem;                                   // [208][68]  unscaled K, row-major (B operand of dQ = dS K)
-  float* Qs = Kt + ATT_NMAX * ATT_LD;                 // [2][16][68]
-  float* dOs = Qs + 2 * ATT_T * ATT_LD;               // [2][16][68]
-  float* dSs = dOs + 2 * ATT_T * ATT_LD;              // [16][212]  dS of the current query tile, [q][key]
-  float* lse_s = dSs + ATT_T * ATT_DSLD;              // [208]
-  float* del_s = lse_s + ATT_NMAX;                    // [208]
-  float* dQp = del_s + ATT_NMAX;                      // per-wave partial dQ of the current query tile: [13][16][64], PF: [13][64][20]
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = lane & 15, g = lane >> 4;
+__global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
+                                                                 const float* __restrict__ lse, const float* __restrict__ dout,
+                                                                 float* __restrict__ dqkv, char* __restrict__ dP_out, int p_ncb,
+                                                                 float* __restrict__ colpart, int B, int N, int H, int dh, float scale) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* Kpl = smem;
+  char* dSpl = smem + AB_OFF_DS;
+#ifdef OFB_ATT_STAMPS
+  { const int lane = threadIdx.x & 63, w = threadIdx.x >> 6; AB_STAMP(0); }
+#endif
+  char* stQ = smem + AB_OFF_STQ;
+  char* stO = smem + AB_OFF_STO;
+  float* nlse = reinterpret_cast<float*>(smem + AB_OFF_NLSE);
+  float* ndel = reinterpret_cast<float*>(smem + AB_OFF_NDEL);
+  float* nres = reinterpret_cast<float*>(smem + AB_OFF_NRES);
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), c = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, head = blockIdx.x % H;
   const int ldq = 3 * H * dh, ldo = H * dh;
   const size_t tok0 = (size_t)b * N;
-  const int sft = PF ? (int)(tok0 & 3) : 0;           // tile position p <-> token p - sft
+  const int sft = PF ? (int)(tok0 & 3) : 0;           // position p <-> token p - sft
+  const int npos = N + sft, nqb = (npos + AB_QB - 1) / AB_QB, nct = (dh + 15) >> 4, nks = (dh + 31) >> 5;
   const float* qbase = qkv + tok0 * ldq + head * dh;
   const float* kbase = qbase + H * dh;
   const float* vbase = qbase + 2 * H * dh;
   const float* obase = out + tok0 * ldo + head * dh;
   const float* dobase = dout + tok0 * ldo + head * dh;
-  float* dqbase = dqkv + tok0 * ldq + head * dh;
-  float* dkbase = dqbase + H * dh;
-  float* dvbase = dqbase + 2 * H * dh;
-  auto valid = [&](int pos) { return pos >= sft && pos - sft < N; };
+  auto valid = [&](int pos) { return pos >= sft && pos < npos; };
 
-  // ---- prologue: K -> LDS; delta[q] = rowsum(dO * O) and lse -> LDS; stage query tile 0 ----
-  for (int idx = t; idx < ATT_NMAX * 16; idx += ATT_THREADS) {
-    const int row = idx >> 4, c4 = (idx & 15) << 2, tok = row - sft;
-    f32x4 kv = zero4(), dv = zero4(), ov = zero4();
-    if (valid(row) && c4 < dh) {
-      kv = *reinterpret_cast<const f32x4*>(kbase + (size_t)tok * ldq + c4);
-      dv = *reinterpret_cast<const f32x4*>(dobase + (size_t)tok * ldo + c4);
-      ov = *reinterpret_cast<const f32x4*>(obase + (size_t)tok * ldo + c4);
+  // ---- prologue: K planes (all positions; zeros outside the image) and -lse -> LDS; -delta[q] = -rowsum(dO * O) is formed block by
+  // block in the staging pass (dO and O are then read once).  3584 (position, 4-channel) items, 7 per thread, all loads issued first
+  // staging of a 32-position query block: thread t carries the Q, dO and O float4 of (row t / 16, d = 4 (t % 16))
+  f32x4 sreg[3];
+  // (scalar base pointer + one 32-bit per-lane offset: nothing 64-bit per lane that hipcc would hoist out of the block loop and spill)
+  auto stage_load = [&](int qb) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {                           // i = 0: Q, 1: dO, 2: O (512 threads = 512 items each)
+      const float* base = i == 0 ? qbase : (i == 1 ? dobase : obase);
+      const int ld = i == 0 ? ldq : ldo;
+      const int pos = qb * AB_QB + (t >> 4), d4 = (t & 15) << 2;
+      sreg[i] = zero4();
+      if (valid(pos) && d4 < dh) sreg[i] = *reinterpret_cast<const f32x4*>(base + (unsigned)((pos - sft) * ld + d4));
     }
-    *reinterpret_cast<f32x4*>(&Kt[row * ATT_LD + c4]) = kv;
-    float d = dv[0] * ov[0] + dv[1] * ov[1] + dv[2] * ov[2] + dv[3] * ov[3];
-    d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
-    if ((idx & 15) == 0) del_s[row] = d;
+  };
+  auto stage_store = [&](int qb) {
+    {                                                       // -delta of the row: 16 lanes hold its 64 channels
+      float d = sreg[1][0] * sreg[2][0] + sreg[1][1] * sreg[2][1] + sreg[1][2] * sreg[2][2] + sreg[1][3] * sreg[2][3];
+      d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
+      if ((t & 15) == 0) ndel[qb * AB_QB + (t >> 4)] = -d;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = t >> 4, c4 = t & 15;
+      unsigned h0, m0, l0, h1, m1, l1;
+      const float qsc = (i == 0) ? scale : 1.0f;            // Q is staged pre-scaled: S' = (scale Q) K^T and dK = dS'^T (scale Q)
+      att_split_pair(sreg[i][0] * qsc, sreg[i][1] * qsc, h0, m0, l0);
+      att_split_pair(sreg[i][2] * qsc, sreg[i][3] * qsc, h1, m1, l1);
+      char* p = ((i == 0) ? stQ : stO) + row * 128 + (((c4 >> 1) ^ ab_swz(row)) << 4) + ((c4 & 1) << 3);
+      *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+      *reinterpret_cast<uint2*>(p + AB_STPL) = make_uint2(m0, m1);
+      *reinterpret_cast<uint2*>(p + 2 * AB_STPL) = make_uint2(l0, l1);
+    }
+  };
+
+  // EVERY global load of the prologue is issued before the first one is consumed (one memory round trip instead of four: the
+  // workgroup is alone on its CU, nothing else hides them): K rows, lse, query block 0, this wave's V rows
+  constexpr int NIT = AB_NPOS * 16 / AB_THREADS;
+  static_assert(NIT * AB_THREADS == AB_NPOS * 16 && AB_NPOS <= AB_THREADS, "prologue items");
+  const bool has_keys = w < AB_NKW && 32 * w < npos;
+  f32x4 kv[NIT], vraw[2][2][2];
+  float lse_a = 0.f, lse_b = 0.f;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = t + AB_THREADS * i, pos = idx >> 4, c4 = idx & 15, tok = pos - sft;
+    kv[i] = zero4();
+    if (valid(pos) && 4 * c4 < dh) kv[i] = *reinterpret_cast<const f32x4*>(kbase + (unsigned)(tok * ldq + 4 * c4));
   }
-  for (int i = t; i < ATT_NMAX; i += ATT_THREADS) lse_s[i] = valid(i) ? lse[((size_t)b * H + head) * N + i - sft] : 0.f;
-  // staging of a 16-row query tile: threads 0..255 carry Q, 256..511 carry dO (one float4 each)
-  const bool stager = t < 512;
-  const int srow = (t & 255) >> 4, sc4 = (t & 15) << 2;
-  f32x4 sreg = zero4();
-  auto stage_load = [&](int qt) {
-    sreg = zero4();
-    const int qq = qt * ATT_T + srow;
-    if (stager && valid(qq) && sc4 < dh)
-      sreg = (t < 256) ? *reinterpret_cast<const f32x4*>(qbase + (size_t)(qq - sft) * ldq + sc4)
-                       : *reinterpret_cast<const f32x4*>(dobase + (size_t)(qq - sft) * ldo + sc4);
-  };
-  auto stage_store = [&](int buf) {
-    if (stager) *reinterpret_cast<f32x4*>(&((t < 256) ? Qs : dOs)[buf * ATT_T * ATT_LD + srow * ATT_LD + sc4]) = sreg;
-  };
+  if (t < AB_NPOS && valid(t)) {
+    const size_t li = ((size_t)b * H + head) * N + t - sft;
+    lse_a = lse[li];
+    lse_b = lse[(size_t)B * H * N + li];                    // the forward's second float of lse (rounding residue)
+  }
   stage_load(0);
+#pragma unroll
+  for (int kt = 0; kt < 2; ++kt) {
+    const int pos = 32 * w + 16 * kt + c;
+    const bool kv_ok = valid(pos);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int d0 = 32 * ks + 8 * g + 4 * u;
+        vraw[kt][ks][u] = zero4();
+        if (kv_ok && d0 < dh) vraw[kt][ks][u] = *reinterpret_cast<const f32x4*>(vbase + (unsigned)((pos - sft) * ldq + d0));
+      }
+  }
+  AB_STAMP(58);
+  // K planes
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int idx = t + AB_THREADS * i, pos = idx >> 4, c4 = idx & 15;
+    unsigned h0, m0, l0, h1, m1, l1;
+    att_split_pair(kv[i][0], kv[i][1], h0, m0, l0);
+    att_split_pair(kv[i][2], kv[i][3], h1, m1, l1);
+    char* p = Kpl + pos * 128 + ((((c4 >> 1) ^ ab_swz(pos))) << 4) + ((c4 & 1) << 3);
+    *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(p + AB_KPL) = make_uint2(m0, m1);
+    *reinterpret_cast<uint2*>(p + 2 * AB_KPL) = make_uint2(l0, l1);
+  }
+  AB_STAMP(59);
+  if (t < AB_NPOS) { nlse[t] = -lse_a; nres[t] = -lse_b; }
   stage_store(0);
-
-  // this wave's key rows as B operands: K (scaled) for S = Q K^T, V for dP = dO V^T
-  const int key = w * ATT_T + c;
-  const bool kvalid = valid(key);
-  float kr[16], vr[16];
+  AB_STAMP(61);
+  // this wave's V rows as B operand of dP = dO V^T (lane: key 32 w + 16 kt + c, d = 32 ks + 8 g ..); the B operand of S' = (scale Q) K^T
+  // is read from the K planes every block (row reads: the registers are needed for the accumulators)
+  att_bf16x8 Vb[2][2][3];
 #pragma unroll
-  for (int u = 0; u < 4; ++u) {
-    const int cc = 16 * g + 4 * u;
-    f32x4 kv = zero4(), vv = zero4();
-    if (kvalid && cc < dh) {
-      kv = *reinterpret_cast<const f32x4*>(kbase + (size_t)(key - sft) * ldq + cc);
-      vv = *reinterpret_cast<const f32x4*>(vbase + (size_t)(key - sft) * ldq + cc);
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      float xv[8];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xv[4 * u + j] = vraw[kt][ks][u][j];
+      att_split8(xv, Vb[kt][ks]);
     }
+  AB_STAMP(62);
+  bool kval[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { kr[4 * u + j] = kv[j] * scale; vr[4 * u + j] = vv[j]; }
-  }
-  f32x4 dK[4], dV[4];
+  for (int kt = 0; kt < 2; ++kt) kval[kt] = valid(32 * w + 16 * kt + c);
+
+  f32x4 dKa[2][4], dVa[2][4];
 #pragma unroll
-  for (int dt = 0; dt < 4; ++dt) { dK[dt] = zero4(); dV[dt] = zero4(); }
+  for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+    for (int ct = 0; ct < 4; ++ct) { dKa[kt][ct] = zero4(); dVa[kt][ct] = zero4(); }
+
+  // dQ tiles of a block: tile i = (qt = i / nct, ct = i % nct), owned by wave i (eight tiles at dh = 64: one per wave, two per SIMD)
+  const int ntile = 2 * nct;
+  float dqs[2] = {0.f, 0.f};                               // PF: column sum of this wave's dQ tile, this lane's channel, rows 4g..
+
   __syncthreads();
+  AB_STAMP(1);
 
-  const int nqt = (N + sft + ATT_T - 1) / ATT_T;
-  float dq_sum = 0.f;                                      // PF: column sum of this thread's dQ column (4-row quad rq) over the query tiles
-  for (int qt = 0; qt < nqt; ++qt) {
-    const int buf = qt & 1;
-    const float* Qb = Qs + buf * ATT_T * ATT_LD;
-    const float* dOb = dOs + buf * ATT_T * ATT_LD;
-#ifndef LAB_ATT_NOSTAGE
-    if (qt + 1 < nqt) stage_load(qt + 1);                  // next tile's global loads in flight during this tile's math
-#endif
-    // ---- S' = scale Q K^T and dP = dO V^T: rows = queries (A from LDS), lane column = this wave's keys; 2 chains ----
-    f32x4 S = zero4(), dP = zero4();
-    {
-      const float* qp = &Qb[c * ATT_LD + 16 * g];
-      const float* dp = &dOb[c * ATT_LD + 16 * g];
+  const bool has_tile = w < ntile;                        // this wave's dQ tile: (qt, ct) = (w / nct, w % nct)
+  const int tq = has_tile ? w / nct : 0, tc = has_tile ? w - tq * nct : 0;
+  for (int qb = 0; qb < nqb; ++qb) {
+    AB_STAMP(2 + 8 * qb);
+    // fragment addresses (bytes inside a plane), re-derived every block from "laundered" lane ids: left to itself hipcc hoists the
+    // ~40 block-invariant LDS addresses of the body out of the loop and then spills them around it
+    int cl = c, gl = g;
+    asm volatile("" : "+v"(cl), "+v"(gl));
+    const int a_row = cl * 128, a_sw = ab_swz(cl);          // row reads: row 16 qt + c (same swizzle for both qt: 16 is a multiple of 8)
+    const int tr_row = 4 * gl + (cl >> 2), tr_sw = ab_swz(tr_row), tr_p = cl & 3;   // transposed reads: row (+16 for the second read)
+    if (has_keys) {
+      // ---- S' and dP - delta for the block's 32 queries x this wave's 32 keys ----
+      f32x4 S[2][2], dPa[2][2];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const f32x4 qv = *reinterpret_cast<const f32x4*>(qp + 4 * u);
-        const f32x4 dv = *reinterpret_cast<const f32x4*>(dp + 4 * u);
+      for (int qt = 0; qt < 2; ++qt) {
+        const f32x4 nd = *reinterpret_cast<const f32x4*>(&ndel[qb * AB_QB + 16 * qt + 4 * gl]);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          S = mfma16(qv[j], kr[4 * u + j], S);
-          dP = mfma16(dv[j], vr[4 * u + j], dP);
+        for (int kt = 0; kt < 2; ++kt) { S[qt][kt] = zero4(); dPa[qt][kt] = nd; }
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        if (ks < nks) {
+          const int off = a_row + ((((4 * ks + gl)) ^ a_sw) << 4);
+#pragma unroll
+          for (int qt = 0; qt < 2; ++qt) {
+            // (the fences keep hipcc from hoisting every group's fragment reads to the top of the block: 140 registers of operands)
+            __builtin_amdgcn_sched_barrier(0);
+            att_bf16x8 qa[3], oa[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+              qa[pl] = *reinterpret_cast<const att_bf16x8*>(stQ + pl * AB_STPL + 16 * qt * 128 + off);
+              oa[pl] = *reinterpret_cast<const att_bf16x8*>(stO + pl * AB_STPL + 16 * qt * 128 + off);
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+              att_bf16x8 kb[3];
+#pragma unroll
+              for (int pl = 0; pl < 3; ++pl) kb[pl] = *reinterpret_cast<const att_bf16x8*>(Kpl + pl * AB_KPL + (32 * w + 16 * kt) * 128 + off);
+              S[qt][kt] = att_mfma6_swapped(qa, kb, S[qt][kt]);              // bit-identical to the forward's S
+              dPa[qt][kt] = att_mfma6(oa, Vb[kt][ks], dPa[qt][kt]);
+            }
+          }
+        }
+      }
+      AB_STAMP(3 + 8 * qb);
+      // ---- P = exp((S' - lse) - residue), dS' = P (dP - delta); as A fragments (k-slot (g, 4 qt + r) = query 16 qt + 4 g + r) ----
+      att_bf16x8 pf[2][3], dsf[2][3];
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        __builtin_amdgcn_sched_barrier(0);
+        float p8[8], d8[8];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+          const f32x4 nl = *reinterpret_cast<const f32x4*>(&nlse[qb * AB_QB + 16 * qt + 4 * gl]);
+          const f32x4 nr = *reinterpret_cast<const f32x4*>(&nres[qb * AB_QB + 16 * qt + 4 * gl]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = kval[kt] ? __expf((S[qt][kt][r] + nl[r]) + nr[r]) : 0.f;
+            p8[4 * qt + r] = pv;
+            d8[4 * qt + r] = pv * dPa[qt][kt][r];
+          }
+        }
+        att_split8(p8, pf[kt]);
+        att_split8(d8, dsf[kt]);
+        // dS planes [key][32 q]: the fragment's two halves are the 8-byte (4 q) slots of q tile 0 / 1
+        const int key = 32 * w + 16 * kt + cl, hsw = (key >> 2) & 1;
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+          const uint4 v = __builtin_bit_cast(uint4, dsf[kt][pl]);
+          char* p = dSpl + pl * AB_DSPL + key * 64 + 8 * gl;
+          *reinterpret_cast<uint2*>(p + 32 * (0 ^ hsw)) = make_uint2(v.x, v.y);
+          *reinterpret_cast<uint2*>(p + 32 * (1 ^ hsw)) = make_uint2(v.z, v.w);
+        }
+      }
+      AB_STAMP(4 + 8 * qb);
+      // ---- dV += P^T dO, dK += dS'^T Q: B = dO / Q [query slots][channel] by transposed reads ----
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) {
+        if (ct < nct) {
+          __builtin_amdgcn_sched_barrier(0);
+          att_bf16x8 bo[3], bq[3];
+          const int off = tr_row * 128 + (((2 * ct + (tr_p >> 1)) ^ tr_sw) << 4) + ((tr_p & 1) << 3);
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) {
+            bo[pl] = ab_tr2(stO + pl * AB_STPL + off, stO + pl * AB_STPL + off + 16 * 128);
+            bq[pl] = ab_tr2(stQ + pl * AB_STPL + off, stQ + pl * AB_STPL + off + 16 * 128);
+          }
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt) {
+            dVa[kt][ct] = att_mfma6(pf[kt], bo, dVa[kt][ct]);
+            dKa[kt][ct] = att_mfma6(dsf[kt], bq, dKa[kt][ct]);
+          }
         }
       }
     }
-    // P = exp(S' - lse[q]), dS' = P (dP - delta[q]);  query = 4g + r of the tile, key = this lane's column.
-    // Padded query rows hold Q = dO = 0, lse = delta = 0 (P = 1, dS = 0, dO = 0): they add nothing.
-    f32x4 P, dS;
+    AB_STAMP(5 + 8 * qb);
+    __syncthreads();                                        // (Y) dS planes of this block complete; nobody reads the Q / dO planes any more
+    AB_STAMP(6 + 8 * qb);
+    // next block's Q / dO / O rows: the global loads fly under this wave's dQ tile (the registers they occupy are free in this phase only)
+    if (qb + 1 < nqb) stage_load(qb + 1);
+    // ---- dQ tile of this wave (16 q x 16 ch), reduced over ALL keys: A = dS, B = K, both by transposed reads.  A chain of up to
+    // seven 6-MFMA steps, each behind an LDS round trip: the fragments of key block kb + 1 are requested before block kb multiplies ----
+    if (has_tile) {
+      const int offa_q = 8 * tr_p, offb_c = (((2 * tc + (tr_p >> 1)) ^ tr_sw) << 4) + ((tr_p & 1) << 3);
+      att_bf16x8 af[2][3], bk[2][3];
+      auto rd = [&](int kb, int slot) __attribute__((always_inline)) {
+        const int k0 = 32 * kb + tr_row;                    // second read: + 16 keys (same half-swap bit: 16 is a multiple of 8)
+        const int offa = k0 * 64 + 32 * (tq ^ ((k0 >> 2) & 1)) + offa_q, offb = k0 * 128 + offb_c;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qrow = qt * ATT_T + 4 * g + r;
-      const float pv = kvalid ? __expf(S[r] - lse_s[qrow]) : 0.f;
-      P[r] = pv;
-      dS[r] = pv * (dP[r] - del_s[qrow]);
-    }
-    // dV += P^T dO, dK += dS'^T Q: the accumulators are the A operand (reduction over their row index = query)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const float* dop = &dOb[(4 * g + r) * ATT_LD + c];
-      const float* qp2 = &Qb[(4 * g + r) * ATT_LD + c];
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) {
-        dV[dt] = mfma16(P[r], dop[16 * dt], dV[dt]);
-        dK[dt] = mfma16(dS[r], qp2[16 * dt], dK[dt]);
-      }
-    }
-    // dS' -> LDS [q][key]: the one transposition of the backward pass
-#pragma unroll
-    for (int r = 0; r < 4; ++r) dSs[(4 * g + r) * ATT_DSLD + key] = dS[r];
-    __syncthreads();                                                                   // (A) dS tile complete
-    // dQ partial over this wave's 16 keys: A[q][kslot g] = dS[q = c][16w + 4g + s], B = K[16w + 4g + s][16 dt + c]
-    f32x4 dq[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) dq[dt] = zero4();
-    {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(&dSs[c * ATT_DSLD + w * ATT_T + 4 * g]);
-#pragma unroll
-      for (int s = 0; s < 4; ++s) {
-        const float* kp = &Kt[(w * ATT_T + 4 * g + s) * ATT_LD + c];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) dq[dt] = mfma16(av[s], kp[16 * dt], dq[dt]);
-      }
-    }
-    // dq[dt][r] = partial dQ[query 4g + r][channel 16 dt + c]: each wave parks its partial tile in its own LDS slot and
-    // 256 threads sum the 13 slots after the barrier (LDS float atomics cost ~180 cycles per wave-instruction here).
-    // f32 output: slot [16 q][64 ch], a thread sums 4 channels of one query.  PF: slot [64 ch][16 q (+4)], a thread sums the 4
-    // queries of one row group for one channel = one plane slot.
-    if (PF) {
-      float* mine = dQp + w * (ATT_DMAX * ATT_QPITCH);
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&mine[(16 * dt + c) * ATT_QPITCH + 4 * g]) = dq[dt];
-    } else {
-      float* mine = dQp + w * ATT_T * ATT_DMAX;
-#pragma unroll
-      for (int dt = 0; dt < 4; ++dt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) mine[(4 * g + r) * ATT_DMAX + 16 * dt + c] = dq[dt][r];
-    }
-    if (qt + 1 < nqt) stage_store(buf ^ 1);
-    __syncthreads();                                                                   // (B) partial dQ tiles parked, next Q/dO staged
-    if (t < 256) {
-      if (PF) {
-        const int ch = t & 63, rq = t >> 6, p0 = qt * ATT_T + 4 * rq;                  // tile positions p0 .. p0 + 3
-        f32x4 v = zero4();
-#pragma unroll
-        for (int ww = 0; ww < ATT_NT; ++ww) v += *reinterpret_cast<const f32x4*>(&dQp[ww * (ATT_DMAX * ATT_QPITCH) + ch * ATT_QPITCH + 4 * rq]);
-        const int rlo = max(0, sft - p0), rhi = min(4, N + sft - p0);
-        if (ch < dh && rlo < rhi) {
-          v *= scale;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) dq_sum += (r >= rlo && r < rhi) ? v[r] : 0.f;
-          att_store_p_col4(dP_out, p_ncb, (int)tok0 - sft + p0, head * dh + ch, v, rlo, rhi);
+        for (int pl = 0; pl < 3; ++pl) {
+          af[slot][pl] = ab_tr2(dSpl + pl * AB_DSPL + offa, dSpl + pl * AB_DSPL + offa + 16 * 64);
+          bk[slot][pl] = ab_tr2(Kpl + pl * AB_KPL + offb, Kpl + pl * AB_KPL + offb + 16 * 128);
         }
-      } else {
-        const int qq = qt * ATT_T + srow;
-        f32x4 v = zero4();
+      };
+      f32x4 acc = zero4(), acc1 = zero4();                  // even / odd key blocks on two chains, added once at the end (fixed order)
+      rd(0, 0);
 #pragma unroll
-        for (int ww = 0; ww < ATT_NT; ++ww) v += *reinterpret_cast<const f32x4*>(&dQp[ww * ATT_T * ATT_DMAX + srow * ATT_DMAX + sc4]);
-        if (qq < N && sc4 < dh) {
-          v *= scale;
-          *reinterpret_cast<f32x4*>(dqbase + (size_t)qq * ldq + sc4) = v;
+      for (int kb = 0; kb < AB_NKW; ++kb) {
+        if (kb < nqb) {
+          __builtin_amdgcn_sched_barrier(0);
+          if (kb + 1 < nqb) rd(kb + 1, (kb + 1) & 1);
+          if (kb & 1) acc1 = att_mfma6(af[kb & 1], bk[kb & 1], acc1);
+          else acc = att_mfma6(af[kb & 1], bk[kb & 1], acc);
+        }
+      }
+      acc += acc1;
+      // acc[r] = dQ'[position 32 qb + 16 qt + 4 g + r][channel 16 ct + c]
+      const int p0 = qb * AB_QB + 16 * tq + 4 * gl, ch = 16 * tc + cl;
+      const int rlo = max(0, sft - p0), rhi = min(4, npos - p0);
+      if (ch < dh && rlo < rhi) {
+        acc *= scale;
+        if (PF) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dqs[0] += (r >= rlo && r < rhi) ? acc[r] : 0.f;
+          att_store_p_col4(dP_out, p_ncb, (int)tok0 - sft + p0, head * dh + ch, acc, rlo, rhi);
+        } else {
+          float* dqp = dqkv + (tok0 + p0) * ldq + head * dh + ch;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r >= rlo && r < rhi) dqp[(size_t)r * ldq] = acc[r];
         }
       }
     }
-    // no third barrier: the next partial-dQ writes come after the next (A), the next dS writes after this (B)
+    AB_STAMP(7 + 8 * qb);
+    __builtin_amdgcn_sched_barrier(0);
+    if (qb + 1 < nqb) stage_store(qb + 1);
+    AB_STAMP(8 + 8 * qb);
+    __syncthreads();                                        // (X) next block's Q / dO planes visible; the dS planes may be rewritten
+    AB_STAMP(9 + 8 * qb);
   }
-  // ---- dK (x scale), dV: dK[dt][r] = dK[key 16w + 4g + r][channel 16 dt + c] ----
-  if (!PF) {
+
+  // ---- dK, dV: acc[kt][ct][r] = d[position 32 w + 16 kt + 4 g + r][channel 16 ct + c] ----
+  float* cs = reinterpret_cast<float*>(stQ);               // [7 key waves][2][64] column sums of the waves' dK / dV rows, then [8 tiles][16] of dQ
+  float* qs = cs + AB_NKW * 2 * 64;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int kk = w * ATT_T + 4 * g + r;
-      if (kk < N) {
-        float* dkp = dkbase + (size_t)kk * ldq + c;
-        float* dvp = dvbase + (size_t)kk * ldq + c;
+  for (int ct = 0; ct < 4; ++ct) {
+    const int ch = 16 * ct + c;
+    float sk = 0.f, sv = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt)
-          if (16 * dt + c < dh) { dkp[16 * dt] = dK[dt][r] * scale; dvp[16 * dt] = dV[dt][r]; }
-      }
-    }
-    return;
-  }
-  {
-    const int k0 = w * ATT_T + 4 * g, row0 = (int)tok0 - sft + k0;                     // row0 % 4 == 0
-    const int rlo = max(0, sft - k0), rhi = min(4, N + sft - k0);                      // this image's rows of the slot
-    float* cs = dQp;                                       // [13 waves][2][64] column sums of this wave's dK / dV rows (dQp is free now)
-    __syncthreads();
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const int ch = 16 * dt + c;
-      f32x4 kq = dK[dt] * scale, vq = dV[dt];
-      float sk = 0.f, sv = 0.f;
+    for (int kt = 0; kt < 2; ++kt) {
+      const int p0 = 32 * w + 16 * kt + 4 * g;
+      const int rlo = max(0, sft - p0), rhi = min(4, npos - p0);
+      f32x4 kq = dKa[kt][ct], vq = dVa[kt][ct];           // dK accumulated against the pre-scaled Q
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         if (r < rlo || r >= rhi) { kq[r] = 0.f; vq[r] = 0.f; }
         sk += kq[r]; sv += vq[r];
       }
+      if (ch < dh && rlo < rhi) {
+        if (PF) {
+          att_store_p_col4(dP_out, p_ncb, (int)tok0 - sft + p0, H * dh + head * dh + ch, kq, rlo, rhi);
+          att_store_p_col4(dP_out, p_ncb, (int)tok0 - sft + p0, 2 * H * dh + head * dh + ch, vq, rlo, rhi);
+        } else {
+          float* dkp = dqkv + (tok0 + p0) * ldq + H * dh + head * dh + ch;
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (r >= rlo && r < rhi) { dkp[(size_t)r * ldq] = kq[r]; dkp[(size_t)r * ldq + H * dh] = vq[r]; }
+        }
+      }
+    }
+    if (PF) {
       sk += __shfl_xor(sk, 16, 64); sk += __shfl_xor(sk, 32, 64);
       sv += __shfl_xor(sv, 16, 64); sv += __shfl_xor(sv, 32, 64);
-      if (g == 0) { cs[(w * 2 + 0) * 64 + ch] = sk; cs[(w * 2 + 1) * 64 + ch] = sv; }
-      if (ch < dh && rlo < rhi) {
-        att_store_p_col4(dP_out, p_ncb, row0, H * dh + head * dh + ch, kq, rlo, rhi);
-        att_store_p_col4(dP_out, p_ncb, row0, 2 * H * dh + head * dh + ch, vq, rlo, rhi);
-      }
+      if (g == 0 && w < AB_NKW) { cs[(w * 2 + 0) * 64 + ch] = sk; cs[(w * 2 + 1) * 64 + ch] = sv; }
     }
-    // dQ column sums: thread (channel t & 63, row quad t >> 6) holds its sum over the query tiles; the four quads are added in order
-    float* qs = cs + ATT_NT * 2 * 64;
-    if (t < 256) qs[(t >> 6) * 64 + (t & 63)] = dq_sum;
-    __syncthreads();
-    if (t < 192) {
-      const int part = t >> 6, ch = t & 63;
-      float sum = 0.f;
-      if (part == 0) {
+  }
+  AB_STAMP(60);
+  if (!PF) return;
+  if (has_tile) {
+    float v = dqs[0];
+    v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 32, 64);
+    if (g == 0) qs[w * 16 + c] = v;
+  }
+  __syncthreads();
+  if (t < 192) {
+    const int part = t >> 6, ch = t & 63;
+    float sum = 0.f;
+    if (part == 0) {
+      const int ct = ch >> 4;
+      if (ct < nct) sum = qs[ct * 16 + (ch & 15)] + qs[(nct + ct) * 16 + (ch & 15)];
+    } else {
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) sum += qs[rr * 64 + ch];
-      } else {
-#pragma unroll
-        for (int ww = 0; ww < ATT_NT; ++ww) sum += cs[(ww * 2 + (part - 1)) * 64 + ch];
-      }
-      if (ch < dh) colpart[(size_t)b * (3 * H * dh) + part * (H * dh) + head * dh + ch] = sum;
+      for (int ww = 0; ww < AB_NKW; ++ww) sum += cs[(ww * 2 + (part - 1)) * 64 + ch];
     }
+    if (ch < dh) colpart[(size_t)b * (3 * H * dh) + part * (H * dh) + head * dh + ch] = sum;
   }
 }
 
-constexpr size_t BWD_LDS_BASE = (size_t)(ATT_NMAX * ATT_LD + 4 * ATT_T * ATT_LD + ATT_T * ATT_DSLD + 2 * ATT_NMAX) * sizeof(float);
-constexpr size_t BWD_LDS = BWD_LDS_BASE + (size_t)(ATT_NT * ATT_T * ATT_DMAX) * sizeof(float);
-constexpr size_t BWD_LDS_P = BWD_LDS_BASE + (size_t)(ATT_NT * ATT_DMAX * ATT_QPITCH) * sizeof(float);
+constexpr size_t BWD_LDS = AB_LDS_BYTES;
+constexpr size_t BWD_LDS_P = AB_LDS_BYTES;
 
 int check_shape(int B, int N, int H, int dh) {
   if (B <= 0 || N <= 0 || H <= 0 || dh <= 0) return OFB_EINVAL;
@@ -574,7 +753,7 @@ int check_shape(int B, int N, int H, int dh) {
 }  // namespace
 
 // qkv: [B*N][3*H*dh] packed as the qkv Linear writes it (q | k | v, each H*dh, head-major); out: [B*N][H*dh];
-// lse: [B*H][N].  N <= 208, dh <= 64, dh % 4 == 0.
+// lse: [2][B*H][N] (row log-sum-exp, then its rounding residue: see the forward kernel).  N <= 208, dh <= 64, dh % 4 == 0.
 extern "C" int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t H, int32_t dh,
                                  float scale, void* stream) {
   if (!qkv || !out || !lse) return OFB_EINVAL;
@@ -616,10 +795,10 @@ int attention_bwd_launch(const float* qkv, const float* out, const float* lse, c
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) return (int)hipGetLastError();
   ofb_prof_pre(4, s, 10.0 * B * H * (double)N * N * dh);
   if (dP_out)
-    hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B * H), dim3(ATT_THREADS), ldsb, s, qkv, out, lse, dout, dqkv, dP_out, p_ncb, colpart,
+    hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B * H), dim3(AB_THREADS), ldsb, s, qkv, out, lse, dout, dqkv, dP_out, p_ncb, colpart,
                        B, N, H, dh, scale);
   else
-    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * H), dim3(ATT_THREADS), ldsb, s, qkv, out, lse, dout, dqkv, dP_out, p_ncb, colpart,
+    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * H), dim3(AB_THREADS), ldsb, s, qkv, out, lse, dout, dqkv, dP_out, p_ncb, colpart,
                        B, N, H, dh, scale);
   ofb_prof_post(4, s);
   return ofb_launch_status();
@@ -649,3 +828,9 @@ extern "C" int ofb_attention_bwd_p(const float* qkv, const float* out, const flo
   return attention_bwd_launch(qkv, out, lse, dout, nullptr, (char*)dqkv_p, (3 * H * dh + 15) / 16, colpart, B, N, H, dh, scale,
                               (hipStream_t)stream);
 }
+
+#ifdef OFB_ATT_STAMPS
+extern "C" int ofb_diag_att_stamps(unsigned long long* out_host) {      /* lab only, not part of the ABI */
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(ofb_att_stamps), sizeof(unsigned long long) * 8 * 64);
+}
+#endif

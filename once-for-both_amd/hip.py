@@ -523,7 +523,13 @@ def gate_fold_bwd(dWraw, W, g, dbraw, b, dW, db, dg, N, K):
                                   stream()), 'ofb_gate_fold_bwd')
 
 
+def _check_lse(lse, B, N, H):
+    if lse.numel() < 2 * B * H * N:
+        raise OfbError('lse must hold 2 * B * H * N floats (log-sum-exp and its rounding residue)')
+
+
 def attention_fwd(qkv, out, lse, B, N, H, dh, scale):
+    _check_lse(lse, B, N, H)
     check(lib().ofb_attention_fwd(ptr(qkv), ptr(out), ptr(lse), _i(B), _i(N), _i(H), _i(dh), _f(scale), stream()),
           'ofb_attention_fwd')
 
@@ -532,11 +538,13 @@ def attention_fwd_p(qkv, out, outP, lse, B, N, H, dh, scale):
     """forward that also writes the output as P-format planes (PMat [B*N][H*dh])"""
     if outP.R != B * N or outP.C != H * dh:
         raise OfbError('attention_fwd_p: output shapes')
+    _check_lse(lse, B, N, H)
     check(lib().ofb_attention_fwd_p(ptr(qkv), ptr(out), ptr(outP.buf), ptr(lse), _i(B), _i(N), _i(H), _i(dh), _f(scale), stream()),
           'ofb_attention_fwd_p')
 
 
 def attention_bwd(qkv, out, lse, dout, dqkv, B, N, H, dh, scale):
+    _check_lse(lse, B, N, H)
     check(lib().ofb_attention_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), _i(B), _i(N), _i(H), _i(dh),
                                   _f(scale), stream()), 'ofb_attention_bwd')
 
@@ -545,6 +553,7 @@ def attention_bwd_p(qkv, out, lse, dout, dqkvP, colpart, B, N, H, dh, scale):
     """dq | dk | dv as P-format planes (PMat [B*N][3*H*dh]) + per-image column sums colpart [B][3*H*dh]."""
     if dqkvP.R != B * N or dqkvP.C != 3 * H * dh or colpart.numel() < B * 3 * H * dh:
         raise OfbError('attention_bwd_p: output shapes')
+    _check_lse(lse, B, N, H)
     check(lib().ofb_attention_bwd_p(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkvP.buf), ptr(colpart), _i(B), _i(N), _i(H),
                                     _i(dh), _f(scale), stream()), 'ofb_attention_bwd_p')
 

@@ -286,7 +286,7 @@ class AttnBranch(torch.autograd.Function):
         qkv, _ = p_linear_fwd(xP, M, D, wqP, bqkv, colscale=g3)
         if g3 is not None:
             hip.gated_register(wqkv, g3, wqkv.shape[0], D)
-        o, lse = _new(x, M, Hd), _new(x, B * heads, N)
+        o, lse = _new(x, M, Hd), _new(x, 2 * B * heads, N)          # lse travels as two floats (hip.attention_fwd)
         if _att_planes_ok(B, N):                       # the attention kernel writes the projection's operand planes too
             oP = hip.PMat.for_rows_written_by_kernel(M, Hd, x.device)
             hip.attention_fwd_p(qkv, o, oP, lse, B, N, heads, dh, scale)

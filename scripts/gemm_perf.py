@@ -25,7 +25,7 @@ for N, K in [(1152, 384), (384, 384), (1536, 384), (384, 1536), (768, 384)]:
     run(f'TN  {N}x{K}x{M}', lambda: hip.gemm(dy, x, dw, N, K, M, N, K, K, 0, 0), 2.0 * M * N * K)
 B, N, H, dh = 128, 197, 6, 64
 qkv = torch.randn(B * N, 3 * H * dh, device='cuda'); o = torch.empty(B * N, H * dh, device='cuda')
-lse = torch.empty(B * H, N, device='cuda'); do = torch.randn_like(o); dqkv = torch.empty_like(qkv)
+lse = torch.empty(2 * B * H, N, device="cuda"); do = torch.randn_like(o); dqkv = torch.empty_like(qkv)
 run('attn fwd', lambda: hip.attention_fwd(qkv, o, lse, B, N, H, dh, 0.125), 4.0 * B * H * N * N * dh)
 run('attn bwd', lambda: hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, H, dh, 0.125), 10.0 * B * H * N * N * dh)
 xx = torch.randn(M, D, device='cuda'); g = torch.ones(D, device='cuda'); bb = torch.zeros(D, device='cuda')

@@ -6,7 +6,7 @@ from ofb_amd import hip, ops
 what = sys.argv[1]
 dev = 'cuda'
 B, N, H, dh = 8, 197, 3, 64
-qkv = torch.randn(B * N, 3 * H * dh, device=dev); o = torch.empty(B * N, H * dh, device=dev); lse = torch.empty(B * H, N, device=dev)
+qkv = torch.randn(B * N, 3 * H * dh, device=dev); o = torch.empty(B * N, H * dh, device=dev); lse = torch.empty(2 * B * H, N, device=dev)
 do = torch.randn(B * N, H * dh, device=dev); dqkv = torch.empty_like(qkv)
 x = torch.randn(B * N, 192, device=dev); w = torch.randn(576, 192, device=dev); dy = torch.randn(B * N, 576, device=dev)
 def attn_fwd(): hip.attention_fwd(qkv, o, lse, B, N, H, dh, 0.125)

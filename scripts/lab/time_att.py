@@ -2,7 +2,7 @@ import ctypes as C, sys, torch
 lib = C.CDLL(sys.argv[1])
 B, N, H, dh = 128, 197, 6, 64
 qkv = torch.randn(B * N, 3 * H * dh, device='cuda'); o = torch.empty(B * N, H * dh, device='cuda')
-lse = torch.empty(B * H, N, device='cuda'); do = torch.randn_like(o); dqkv = torch.empty_like(qkv)
+lse = torch.empty(2 * B * H, N, device="cuda"); do = torch.randn_like(o); dqkv = torch.empty_like(qkv)
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 P = lambda t: C.c_void_p(t.data_ptr())
 def fwd(): lib.ofb_attention_fwd(P(qkv), P(o), P(lse), B, N, H, dh, C.c_float(0.125), st)

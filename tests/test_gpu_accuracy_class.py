@@ -158,7 +158,7 @@ def test_attention_forward_is_fp32_class(kind):
     qkv = qkv.contiguous()
     scale = d ** -0.5
     dev = qkv.reshape(B * N, 3 * H * d).contiguous().cuda()
-    out, lse = torch.empty(B * N, H * d, device='cuda'), torch.empty(B * H, N, device='cuda')
+    out, lse = torch.empty(B * N, H * d, device='cuda'), torch.empty(2 * B * H, N, device='cuda')
     hip.attention_fwd(dev, out, lse, B, N, H, d, scale)
 
     def ref(t):
@@ -176,3 +176,51 @@ def test_attention_forward_is_fp32_class(kind):
     assert _rms(e_16bit) > 16 * _rms(e_f32), 'the criterion must be able to see a reduced-precision engine'
     assert _rms(e_kernel) <= 4 * _rms(e_f32), 'attention forward RMS error is not fp32-class'
     assert e_kernel.abs().max().item() <= 4 * e_f32.abs().max().item() + 1e-7, 'attention forward worst-case error is not fp32-class'
+
+
+@pytest.mark.parametrize('kind', ['normal', 'sharp', 'low_planes'])
+def test_attention_backward_is_fp32_class(kind):
+    """dq | dk | dv of o = softmax(q k^T * scale) v (reference models/layers.py:510-514 under autograd) from the split-engine
+    backward kernel (six bf16 MFMA terms per product) against fp64: per gradient the RMS error may be at most 4x that of an
+    ordinary fp32 evaluation (torch CPU autograd in fp32), and a 16-significant-bit engine must be visible to the criterion."""
+    from ofb_amd import hip
+    B, H, N, d = 2, 3, 197, 64
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B, N, 3, H, d, generator=g)
+    if kind == 'sharp':
+        qkv[:, :, :2] *= 3.0
+    if kind == 'low_planes':
+        qkv = torch.sign(qkv) * (1.0 + qkv * 2.0 ** -9)
+    qkv = qkv.contiguous()
+    dout = torch.randn(B * N, H * d, generator=g)
+    scale = d ** -0.5
+
+    def grads(t, do):
+        t = t.detach().clone().requires_grad_(True)
+        q, k, v = (t[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+        p = torch.softmax(q @ k.transpose(-1, -2) * scale, -1)
+        o = (p @ v).permute(0, 2, 1, 3).reshape(B * N, H * d)
+        o.backward(do)
+        return t.grad.reshape(B * N, 3, H * d)
+
+    exact = grads(qkv.double(), dout.double())
+    e_f32 = grads(qkv, dout).double() - exact
+    trunc = (qkv.view(torch.int32) & ~0xff).view(torch.float32)
+    e_16 = grads(trunc.double(), dout.double()) - exact
+    dev = qkv.reshape(B * N, 3 * H * d).contiguous().cuda()
+    out, lse = torch.empty(B * N, H * d, device='cuda'), torch.empty(2 * B * H, N, device='cuda')
+    hip.attention_fwd(dev, out, lse, B, N, H, d, scale)
+    for form in ('f32', 'planes'):
+        if form == 'f32':
+            dq = torch.empty(B * N, 3 * H * d, device='cuda')
+            hip.attention_bwd(dev, out, lse, dout.cuda(), dq, B, N, H, d, scale)
+        else:
+            dP = hip.PMat.for_rows_written_by_kernel(B * N, 3 * H * d, 'cuda')
+            hip.attention_bwd_p(dev, out, lse, dout.cuda(), dP, torch.empty(B, 3 * H * d, device='cuda'), B, N, H, d, scale)
+            dq = dP.to_f32()
+        e_k = dq.cpu().double().reshape(B * N, 3, H * d) - exact
+        for i, name in enumerate(('dq', 'dk', 'dv')):
+            rk, rf, r16 = _rms(e_k[:, i]), _rms(e_f32[:, i]), _rms(e_16[:, i])
+            print(f'attention bwd {kind} {form} {name}: rms error kernel {rk:.2e}  fp32 cpu {rf:.2e}  16-bit operands {r16:.2e}')
+            assert r16 > 16 * rf, 'the criterion must be able to see a reduced-precision engine'
+            assert rk <= 4 * rf, f'attention backward {name} RMS error is not fp32-class'
