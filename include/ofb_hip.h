@@ -140,13 +140,19 @@ int ofb_layernorm_bwd_p(const float* dy, const float* x, const float* gamma, con
 int32_t ofb_colsum_slabs(int32_t M, int32_t N);
 int ofb_colsum(const float* x, int32_t ld, int32_t M, int32_t N, const float* rowscale, int32_t rs_div, float* out,
                float* scratch, void* stream);
+/* Many such sums in ONE launch: out[N] = column sums of x[M][ld] per job (jobs_dev[n_jobs] in device memory; max_N = the widest).
+ * The LayerNorm parameter gradients of a whole backward pass (25 x [1024 partial rows][3 D]) are reduced together after it. */
+typedef struct ofb_colsum_job { const float* x; float* out; int32_t ld, M, N, pad_; } ofb_colsum_job;
+int ofb_colsum_multi(const ofb_colsum_job* jobs_dev, int32_t n_jobs, int32_t max_N, void* stream);
 
 /* Bi-mask gate folded into a Linear layer (q,k,v *= g: models/layers.py:507-509; fc1 out *= g: :858;
  * conv out *= g: :191).  out = g[n] * W[n][:]; and the matching backward: from the UNGATED raw gradients
- * dWraw = dY^T x, dbraw = colsum(dY): dW = g*dWraw, db = g*dbraw, dg[n] = <dWraw[n], W[n]> + dbraw[n]*b[n]. */
+ * dWraw = dY^T x, dbraw = colsum(dY): dW = g*dWraw, db = g*dbraw, dg[n] = <dWraw[n], W[n]> + dbraw[n]*b[n].
+ * dbraw: [dbraw_rows][N]; with dbraw_rows > 1 the rows are partial column sums (per image from the attention backward, per
+ * tile from a GEMM epilogue) that this kernel adds up itself. */
 int ofb_scale_rows(const float* W, const float* g, float* out, int32_t N, int32_t K, void* stream);
-int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const float* dbraw, const float* b, float* dW,
-                      float* db, float* dg, int32_t N, int32_t K, void* stream);
+int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const float* dbraw, int32_t dbraw_rows, const float* b,
+                      float* dW, float* db, float* dg, int32_t N, int32_t K, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention core softmax(q k^T * scale) v with probabilities kept on chip

@@ -367,6 +367,22 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
   if (w == 0 && col < N) out[(size_t)blockIdx.y * N + col] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
 }
 
+// Many column-sum jobs in ONE launch (the LayerNorm parameter gradients of a whole backward pass: 25 x [1024 partial rows][3 D]):
+// block (column block, job); wave w adds the job's rows w, w + 4, ... in order, the four waves' sums are added in wave order.
+__global__ __launch_bounds__(256) void colsum_multi_kernel(const ofb_colsum_job* __restrict__ jobs) {
+  __shared__ float red[4][64];
+  const ofb_colsum_job j = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  if (blockIdx.x * 64 >= j.N) return;
+  float s = 0.f;
+  if (col < j.N)
+    for (int r = w; r < j.M; r += 4) s += j.x[(size_t)r * j.ld + col];
+  red[w][lane] = s;
+  __syncthreads();
+  if (w == 0 && col < j.N) j.out[col] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+}
+
 __global__ void scale_rows_kernel(const float* __restrict__ W, const float* __restrict__ g, float* __restrict__ out, int N,
                                   int K) {
   // one float4 per thread when rows are 16-B multiples (token matrices), scalar otherwise
@@ -390,10 +406,18 @@ __global__ void scale_rows_kernel(const float* __restrict__ W, const float* __re
 __global__ __launch_bounds__(256) void gate_fold_bwd_kernel(const float* __restrict__ dWraw, const float* __restrict__ W,
                                                             const float* __restrict__ g, const float* __restrict__ dbraw,
                                                             const float* __restrict__ b, float* __restrict__ dW,
-                                                            float* __restrict__ db, float* __restrict__ dg, int N, int K) {
+                                                            float* __restrict__ db, float* __restrict__ dg, int N, int K,
+                                                            int dbraw_rows) {
   const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (n >= N) return;
   const float gn = g[n];
+  // dbraw may arrive as dbraw_rows partial rows [rows][N] (per-image / per-tile column sums straight from the producing kernel):
+  // they are added here (lane r, r + 64, ... in order, then the fixed wave tree) instead of by a reduction launch of their own
+  float dbr = 0.f;
+  if (dbraw) {
+    for (int r = lane; r < dbraw_rows; r += 64) dbr += dbraw[(size_t)r * N + n];
+    dbr = dbraw_rows > 1 ? ofb_wave_sum(dbr) : __shfl(dbr, 0, 64);
+  }
   float s = 0.f;
   for (int k = lane; k < K; k += 64) {
     const float d = dWraw[(size_t)n * K + k];
@@ -402,7 +426,6 @@ __global__ __launch_bounds__(256) void gate_fold_bwd_kernel(const float* __restr
   }
   s = ofb_wave_sum(s);
   if (lane == 0) {
-    const float dbr = dbraw ? dbraw[n] : 0.f;
     dg[n] = s + (b ? dbr * b[n] : 0.f);
     if (db) db[n] = dbr * gn;
   }
@@ -527,10 +550,18 @@ extern "C" int ofb_scale_rows(const float* W, const float* g, float* out, int32_
   return ofb_launch_status();
 }
 
-extern "C" int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const float* dbraw, const float* b,
-                                 float* dW, float* db, float* dg, int32_t N, int32_t K, void* stream) {
-  if (!dWraw || !W || !g || !dW || !dg || N <= 0 || K <= 0) return OFB_EINVAL;
+extern "C" int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const float* dbraw, int32_t dbraw_rows,
+                                 const float* b, float* dW, float* db, float* dg, int32_t N, int32_t K, void* stream) {
+  if (!dWraw || !W || !g || !dW || !dg || N <= 0 || K <= 0 || (dbraw && dbraw_rows <= 0)) return OFB_EINVAL;
   hipLaunchKernelGGL(gate_fold_bwd_kernel, dim3(ofb_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, dWraw, W, g, dbraw, b,
-                     dW, db, dg, N, K);
+                     dW, db, dg, N, K, dbraw_rows);
+  return ofb_launch_status();
+}
+
+
+// out[N] = column sums of x[M][ld] for every job, one launch; max_N = the widest job
+extern "C" int ofb_colsum_multi(const ofb_colsum_job* jobs_dev, int32_t n_jobs, int32_t max_N, void* stream) {
+  if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535 || max_N <= 0) return OFB_EINVAL;
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3(ofb_cdiv(max_N, 64), n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
   return ofb_launch_status();
 }

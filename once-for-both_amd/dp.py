@@ -155,7 +155,10 @@ class GradAllReducer:
     def _launch(self, bi):
         self._launched[bi] = True
         from . import hip
+        flat_is_cuda = self._flat[bi].is_cuda
         hip.join_side()                                  # weight gradients are produced on the side stream (ops.py)
+        if flat_is_cuda:
+            hip.flush_deferred()                         # LayerNorm / bias gradients whose reduction was queued (ops._ln_colsum)
         flat, live, jobs = self._flat[bi], [], []
         for p, v in zip(self.buckets[bi], self._views[bi]):
             if p.grad is None:

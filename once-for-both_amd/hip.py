@@ -22,7 +22,7 @@ ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
     'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_gemm_p_colpart_rows', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
-    'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum',
+    'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_fwd_p', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
@@ -424,9 +424,10 @@ def gated_weight_p(W, gvec, N, K):
 
 
 def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
-           resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, colsum_out=None):
+           resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, colsum_out=None, want_colpart=False):
     """C[M][N] (f32 and / or P-format) = A * B on P-format operands (PMat); a_kc / b_kc: reduction along the operand's columns.
-    colsum_out [N]: also receives the column sums of the output (fused per-tile partial sums + one small reduction)."""
+    colsum_out [N]: also receives the column sums of the output (fused per-tile partial sums + one small reduction).
+    want_colpart: return the per-tile partial column sums [rows][N] themselves (the consumer adds them up)."""
     g = GemmPArgs()
     g.A, g.B, g.a_kc, g.b_kc, g.a_ncb, g.b_ncb = ptr(A.buf), ptr(B.buf), int(a_kc), int(b_kc), A.ncb, B.ncb
     g.M, g.N, g.K = M, N, K
@@ -438,7 +439,7 @@ def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bia
     g.alpha, g.bias, g.colscale, g.rowscale, g.rs_div = alpha, ptr(bias), ptr(colscale), ptr(rowscale), rs_div
     g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
     part = None
-    if colsum_out is not None:
+    if colsum_out is not None or want_colpart:
         rows = int(lib().ofb_gemm_p_colpart_rows(C.byref(g)))
         part = torch.empty(rows, N, device=A.buf.device, dtype=torch.float32)
         g.colpart = ptr(part)
@@ -448,6 +449,8 @@ def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bia
         ws = _workspace(A.buf.device, need)
         g.workspace, g.workspace_bytes = ptr(ws), ws.numel() * 4
     check(lib().ofb_gemm_p(C.byref(g), stream()), 'ofb_gemm_p')
+    if want_colpart:
+        return part
     if part is not None:
         colsum(part, N, part.shape[0], N, colsum_out)
 
@@ -514,13 +517,45 @@ def colsum(x, ld, M, N, out, rowscale=None, rs_div=1):
           'ofb_colsum')
 
 
+# Column sums whose result only the optimizer (or the gradient exchange) reads - the LayerNorm weight / bias gradients and the
+# output-bias gradients that ride on LayerNorm's backward partials - are not reduced one by one (two launches each) but queued and
+# reduced together by ONE multi-job launch: at the end of backward (ops.py queues the callback), before a bucket of the
+# data-parallel exchange leaves, before an optimizer step.
+class ColsumJob(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('out', C.c_void_p), ('ld', C.c_int32), ('M', C.c_int32), ('N', C.c_int32), ('pad_', C.c_int32)]
+
+
+_deferred = []               # (partials tensor, ld, M, N, out tensor)
+_deferred_keep = [None]
+
+
+def colsum_deferred(x, ld, M, N, out):
+    _deferred.append((x, int(ld), int(M), int(N), out))
+
+
+def flush_deferred():
+    if not _deferred:
+        return
+    tab = (ColsumJob * len(_deferred))()
+    for t, (x, ld, M, N, out) in zip(tab, _deferred):
+        t.x, t.out, t.ld, t.M, t.N = x.data_ptr(), out.data_ptr(), ld, M, N
+    dev = _deferred[0][0].device
+    dev_tab, host = upload_structs(tab, dev)
+    check(lib().ofb_colsum_multi(ptr(dev_tab), _i(len(_deferred)), _i(max(j[3] for j in _deferred)), stream()), 'ofb_colsum_multi')
+    _deferred_keep[0] = (dev_tab, host, list(_deferred))       # inputs stay referenced until the next flush (stream order frees them)
+    _deferred.clear()
+
+
 def scale_rows(W, g, out, N, K):
     check(lib().ofb_scale_rows(ptr(W), ptr(g), ptr(out), _i(N), _i(K), stream()), 'ofb_scale_rows')
 
 
-def gate_fold_bwd(dWraw, W, g, dbraw, b, dW, db, dg, N, K):
-    check(lib().ofb_gate_fold_bwd(ptr(dWraw), ptr(W), ptr(g), ptr(dbraw), ptr(b), ptr(dW), ptr(db), ptr(dg), _i(N), _i(K),
-                                  stream()), 'ofb_gate_fold_bwd')
+def gate_fold_bwd(dWraw, W, g, dbraw, b, dW, db, dg, N, K, dbraw_rows=1):
+    """dbraw: [dbraw_rows][N]; rows > 1: partial column sums (per image / per tile) that the kernel adds up itself"""
+    if dbraw is not None and dbraw.numel() < dbraw_rows * N:
+        raise OfbError('gate_fold_bwd: dbraw must hold dbraw_rows * N floats')
+    check(lib().ofb_gate_fold_bwd(ptr(dWraw), ptr(W), ptr(g), ptr(dbraw), _i(dbraw_rows), ptr(b), ptr(dW), ptr(db), ptr(dg), _i(N),
+                                  _i(K), stream()), 'ofb_gate_fold_bwd')
 
 
 def _check_lse(lse, B, N, H):

@@ -48,12 +48,15 @@ def p_linear_fwd(xP, M, K, WP, b, colscale=None, act=hip.ACT_NONE, aux=None, row
     return y, yP
 
 
-def p_linear_bwd_input(dyP, M, N, WP, K, resid=None, act=hip.ACT_NONE, aux=None, want_f32=True, want_p=False, colsum_out=None):
-    """dX[M,K] = dY[M,N] @ W[N,K]: dY reduced along its columns (KC), W along its rows (KR): the SAME P-format copy of W as forward"""
+def p_linear_bwd_input(dyP, M, N, WP, K, resid=None, act=hip.ACT_NONE, aux=None, want_f32=True, want_p=False, colsum_out=None,
+                       want_colpart=False):
+    """dX[M,K] = dY[M,N] @ W[N,K]: dY reduced along its columns (KC), W along its rows (KR): the SAME P-format copy of W as forward.
+    want_colpart: third return value = the per-tile partial column sums of dX [rows][K]"""
     dx = torch.empty(M, K, device=dyP.buf.device, dtype=torch.float32) if want_f32 else None
     dxP = hip.PMat(M, K, dyP.buf.device) if want_p else None
-    hip.gemm_p(dyP, WP, 1, 0, M, K, N, C_out=dx, ldc=K, Cp=dxP, resid=resid, ldr=K, act=act, aux=aux, ldaux=K, colsum_out=colsum_out)
-    return dx, dxP
+    part = hip.gemm_p(dyP, WP, 1, 0, M, K, N, C_out=dx, ldc=K, Cp=dxP, resid=resid, ldr=K, act=act, aux=aux, ldaux=K, colsum_out=colsum_out,
+                      want_colpart=want_colpart)
+    return (dx, dxP, part) if want_colpart else (dx, dxP)
 
 
 def p_linear_bwd_weight(dyP, xP, M, N, K, out=None):
@@ -85,13 +88,19 @@ def _side_ok(*params, tokens=None):
         return False
     if any(p is not None and _grad_of(p) is not None for p in params):
         return False
-    if not _cb_queued[0]:                                 # join at the end of this backward pass
+    _end_of_backward_callback()                           # join at the end of this backward pass
+    return True
+
+
+def _end_of_backward_callback():
+    """once per backward pass: the side stream is joined and the queued column sums (hip.colsum_deferred) are reduced"""
+    if not _cb_queued[0]:
         def _done():
             _cb_queued[0] = False
             hip.join_side()
+            hip.flush_deferred()
         torch.autograd.Variable._execution_engine.queue_callback(_done)
         _cb_queued[0] = True
-    return True
 
 
 class _nullctx:
@@ -101,7 +110,8 @@ class _nullctx:
 
 def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None):
     """P-format backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None): dx (+resid fused), dW, db, dg.
-    WP: the forward's P-format copy of W; dy_colsum: callable giving colsum(dY) (the raw bias gradient)."""
+    WP: the forward's P-format copy of W; dy_colsum: callable giving colsum(dY) (the raw bias gradient) as a vector [N] or as
+    (partials [rows][N], rows) straight from the producing kernel - the gate-fold kernel adds partial rows up itself."""
     N, K = WP.R, WP.C
     side = _side_ok(W, b, tokens=M)                      # asked of the Parameter itself: a view's .grad is always None
     W = W.view(N, K)
@@ -111,16 +121,30 @@ def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None):
         dW = slot if slot is not None else _new(W, N, K)
         with (hip.side_work(W.device, keep=[dyP.buf, xP.buf]) if side else _nullctx()):
             p_linear_bwd_weight(dyP, xP, M, N, K, out=dW)
-        return dx, dW, (dy_colsum() if b is not None else None), None
+        return dx, dW, (_reduced(dy_colsum(), N) if b is not None else None), None
     WeffP = hip.gated_weight_p(W, gvec, N, K)                            # g[n] * W[n][:] as planes (all gated layers in one launch)
     dx, _ = p_linear_bwd_input(dyP, M, N, WeffP, K, resid=resid)
-    dbraw = dy_colsum() if b is not None else None
+    dbraw, rows = None, 1
+    if b is not None:
+        dbraw = dy_colsum()
+        if isinstance(dbraw, tuple):
+            dbraw, rows = dbraw
     dW = slot if slot is not None else _new(W, N, K)
     db, dg, dWraw = (_new(W, N) if b is not None else None), _new(W, N), _new(W, N, K)
     with (hip.side_work(W.device, keep=[dyP.buf, xP.buf, dWraw, dbraw, gvec]) if side else _nullctx()):
         p_linear_bwd_weight(dyP, xP, M, N, K, out=dWraw)
-        hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K)
+        hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K, dbraw_rows=rows)
     return dx, dW, db, dg
+
+
+def _reduced(db, N):
+    """a bias gradient handed over as (partials, rows) summed to a vector"""
+    if not isinstance(db, tuple):
+        return db
+    part, rows = db
+    out = _new(part, N)
+    hip.colsum(part, N, rows, N, out)
+    return out
 
 
 def bias_grad(dy2d, rowscale=None, rs_div=1):
@@ -203,6 +227,8 @@ class LayerNorm(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.fork = fork
         ctx.up = up
+        # deferred parameter-gradient reductions need leaves that are not being accumulated into (see _ln_colsum)
+        ctx.defer_ok = gamma.is_leaf and beta.is_leaf and gamma.grad is None and beta.grad is None
         if fork:
             return y, x.view_as(x)
         return y
@@ -221,14 +247,29 @@ class LayerNorm(torch.autograd.Function):
             hip.layernorm_bwd_p(_c(dy), x, gamma, mean, rstd, _c(dres) if dres is not None else None, dx, part, dxP, rowscale,
                                 _rs_div(rowscale, rows), rows, D)
             dgb = _new(x, 3 * D)
-            hip.colsum(part, 3 * D, nb, 3 * D, dgb)
+            _ln_colsum(part, 3 * D, nb, dgb, ctx)
             _put_grad_p(dx, dxP, dgb[2 * D:], rowscale)
             return dx, dgb[:D], dgb[D:2 * D], None, None, None
         part = _new(x, nb, 2 * D)
         hip.layernorm_bwd(_c(dy), x, gamma, mean, rstd, _c(dres) if dres is not None else None, dx, part, rows, D)
         dgb = _new(x, 2 * D)
-        hip.colsum(part, 2 * D, nb, 2 * D, dgb)
+        _ln_colsum(part, 2 * D, nb, dgb, ctx)
         return dx, dgb[:D], dgb[D:], None, None, None
+
+
+_DEFER_COLSUM = os.environ.get('OFB_DEFER_COLSUM', '1') != '0'
+
+
+def _ln_colsum(part, width, nb, dgb, ctx):
+    """dgamma | dbeta (| the upstream branch's output-bias gradient) = column sums of LayerNorm's per-block partials.  Their only
+    readers are the optimizer and the gradient exchange, so the reduction is queued and runs with all the others of this backward
+    pass in ONE launch (hip.flush_deferred) - unless a gradient is being accumulated into right now (AccumulateGrad adds at once)
+    or the consumer of the bias part is not a leaf (then ctx.defer_ok is False)."""
+    if _DEFER_COLSUM and ctx.defer_ok:
+        hip.colsum_deferred(part, width, nb, width, dgb)
+        _end_of_backward_callback()
+    else:
+        hip.colsum(part, width, nb, width, dgb)
 
 
 def _ln_apply(x, gamma, beta, eps, fork):
@@ -319,14 +360,13 @@ class AttnBranch(torch.autograd.Function):
         with (hip.side_work(d2.device, keep=[d2sP.buf, oP.buf]) if _side_ok(wproj, tokens=M) else _nullctx()):
             p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=dwp)
         # dq | dk | dv leave the attention kernel as planes, with the per-image column sums the qkv bias gradient is made of
-        dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
         if _att_planes_ok(B, N):
             dqkvP = hip.PMat.for_rows_written_by_kernel(M, 3 * Hd, d2.device)
             colpart = _new(d2, B, 3 * Hd)
             hip.attention_bwd_p(qkv, o, lse, do, dqkvP, colpart, B, N, heads, dh, scale)
-            if dbq_raw is not None:
-                hip.colsum(colpart, 3 * Hd, B, 3 * Hd, dbq_raw)
+            dbq_raw = (colpart, B)                          # per-image partial sums: added up by their consumer (gate fold / colsum)
         else:                                                   # sequence too long for the shifted tile origin: f32 rows + a conversion pass
+            dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
             dqkv = torch.empty_like(qkv)
             hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
             dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw)
@@ -391,8 +431,13 @@ class MlpBranch(torch.autograd.Function):
         # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> P-format only
         w1P, w2P = ctx.wp
         # the fc1 bias gradient (column sums of this P-format-only result) rides on the epilogue
-        db1_raw = _new(hpre, hid) if b1 is not None else None
-        _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True, colsum_out=db1_raw)
+        if b1 is not None:
+            _, dhP, part = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True,
+                                              want_colpart=True)
+            db1_raw = (part, part.shape[0])                  # per-tile partial sums: added up by their consumer
+        else:
+            db1_raw = None
+            _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True)
         dw2 = grad_slot(w2)
         dw2 = dw2 if dw2 is not None else _new(d2, D, hid)
         with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2, tokens=M) else _nullctx()):

@@ -51,6 +51,7 @@ class AdamW(Optimizer):
             with torch.enable_grad():
                 loss = closure()
         hip.join_side()                          # weight gradients are produced on the side stream (ops.py)
+        hip.flush_deferred()                     # queued LayerNorm / bias gradient reductions (normally done at the end of backward)
         for group in self.param_groups:
             by_step = {}
             for p in group['params']:
