@@ -30,12 +30,13 @@ PROF_TAGS = ['gemm_f32', 'attention_fwd', 'layernorm_fwd', 'layernorm_bwd', 'att
 
 
 def gemm_traffic_per_launch(launches_per_step):
-    """HBM-side bytes per ofb_gemm_f32 call from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    passes over this same bench command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; scripts/pmc_bench.sh).
-    Counters cannot be read from inside the process, so the figure is the last profiled one for configs[1]."""
+    """HBM-side bytes per ofb_gemm_p call from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes over this same bench command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; scripts/round_profiles.sh
+    -> scripts/profile_summaries.py).  Hardware counters cannot be read from inside the process, so the figure is the newest
+    profiled one for configs[1]; `traffic_source` names the file."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc_traffic_summary_v*.txt')),
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*pmc_traffic_summary*.txt')),
                    key=lambda f: [int(x) for x in re.findall(r'\d+', os.path.basename(f))])
     for f in reversed(files):
         m = re.search(r'GEMM_BYTES_PER_STEP (\d+)', open(f).read())

@@ -1,12 +1,28 @@
 #!/bin/bash
-# Round deliverables on one GPU box: (1) the default bench line (with cpu_baseline), (2) rocprofv3 --kernel-trace --stats of that
-# same command, (3) the serialised (side stream off) kernel summary, (4) PMC traffic.  usage: scripts/round_profiles.sh <tag>
-R=$GRAFT_REPO_ROOT; tag=${1:-v2}
-cd $R && python3 bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.log || exit 1
+# Round deliverables on one GPU box, every output under a ROUND-UNIQUE directory gpurun_out/<tag>/ (so a stale file of an earlier
+# round can never be picked up): (1) the default bench line (with cpu_baseline), (2) rocprofv3 --kernel-trace --stats of that same
+# command, (3) the serialised (side stream off) kernel stats, (4) PMC traffic (FETCH_SIZE / WRITE_SIZE, separate passes),
+# (5) SQ counters (matrix-pipe busy cycles, wave cycles, clock).  scripts/profile_summaries.py turns them into the text summaries
+# that are committed under profiles/.          usage (GPU box): bash scripts/round_profiles.sh r03_v1 [quick]
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+tag=${1:?usage: round_profiles.sh <round tag, e.g. r03_v1> [quick]}
+O=$R/gpurun_out/$tag
+rm -rf $O; mkdir -p $O
+cd $R
+if [ "$2" != "quick" ]; then python3 bench.py > $O/bench.json 2> $O/bench.log || exit 1; else python3 bench.py --no-cpu-baseline > $O/bench.json 2> $O/bench.log || exit 1; fi
+echo "bench done: $(cut -c1-160 $O/bench.json)"
 cd /tmp && export TMPDIR=/tmp
-rm -rf $R/gpurun_out/stats_$tag
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/stats_$tag -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/stats_$tag.log 2>&1 || exit 1
-cp $(ls $R/gpurun_out/stats_$tag/*/*kernel_stats.csv | head -1) $R/gpurun_out/kernel_stats_default_$tag.csv
-cd $R && scripts/prof_bench.sh $tag > /dev/null 2>&1 || exit 1
-bash scripts/pmc_bench.sh > gpurun_out/pmc_$tag.log 2>&1 || exit 1
-tail -3 gpurun_out/pmc_$tag.log; tail -1 gpurun_out/bench_$tag.json | cut -c1-400
+# the program itself goes directly after `--` (no env / bash -c hop under rocprofv3)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_default -- python3 $R/bench.py --no-cpu-baseline > $O/stats_default.log 2>&1 || exit 1
+echo "stats (default command) done"
+export OFB_SIDE_STREAM=0      # one stream: per-kernel durations / counters are attributable
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sideoff -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prof > $O/stats_sideoff.log 2>&1 || exit 1
+echo "stats (side stream off) done"
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $O/pmc_$c.log 2>&1 || exit 1
+  echo "pmc $c done"
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $O/pmc_sq.log 2>&1 || exit 1
+echo "pmc SQ done"
+unset OFB_SIDE_STREAM
+cd $R && python3 scripts/profile_summaries.py $O $tag
