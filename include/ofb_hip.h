@@ -398,6 +398,40 @@ int ofb_randaug_layer(const uint8_t* in, uint8_t* out, const ofb_aug_op* ops_dev
                       uint64_t* lsum_scratch, void* stream);
 int ofb_normalize_u8(const uint8_t* in, float* out, int32_t B, int32_t H, int32_t W, const float* mean3, const float* std3, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * JPEG decode in front of the input pipeline (reference datasets.py:90-125: torchvision ImageFolder + PIL default_loader, i.e.
+ * libjpeg-turbo).  HOST stage (plain C++, re-entrant: call it from the loader's threads): ofb_jpeg_parse reads the frame header;
+ * ofb_jpeg_decode_coefficients Huffman-decodes every scan into int16 coefficient blocks, de-zigzagged, component c at
+ * coef_off[c] as [blocks_h][blocks_w][64].  DEVICE stage: ofb_jpeg_decode_pixels turns the coefficients of a batch of images into
+ * uint8 HWC RGB pixels in two launches (dequantise + 8x8 inverse DCT per block; chroma upsampling + YCbCr -> RGB per pixel),
+ * restating libjpeg's default path bit for bit: jidctint.c (JDCT_ISLOW), jdsample.c fancy upsampling (h2v1 / h2v2 / h1v2),
+ * jdcolor.c.  Baseline / extended-sequential Huffman files with 1 or 3 components; progressive, arithmetic-coded, CMYK and
+ * 12-bit files return OFB_ELIMIT.  Buffers of ofb_jpeg_decode_pixels per image i: planes at plane_off[c] (blocks_h*8 rows of
+ * blocks_w*8 bytes), pixels at out_off (height*width*3 bytes).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ofb_jpeg_info {
+  int32_t width, height, ncomp;
+  int32_t hs[3], vs[3];              /* sampling factors */
+  int32_t hmax, vmax, mcu_x, mcu_y;
+  int32_t blocks_w[3], blocks_h[3];  /* blocks per component (whole MCUs) */
+  int32_t pad_;
+  int64_t coef_off[3], coef_count;   /* in int16 elements */
+  uint16_t quant[3][64];             /* natural order */
+} ofb_jpeg_info;
+typedef struct ofb_jpeg_job {
+  int32_t width, height, ncomp;
+  int32_t hs[3], vs[3];
+  int32_t hmax, vmax;
+  int32_t blocks_w[3], blocks_h[3];
+  int32_t pad_;
+  int64_t coef_off[3], plane_off[3], out_off;
+  uint16_t quant[3][64];
+} ofb_jpeg_job;
+int ofb_jpeg_parse(const uint8_t* data, int64_t nbytes, ofb_jpeg_info* info);
+int ofb_jpeg_decode_coefficients(const uint8_t* data, int64_t nbytes, const ofb_jpeg_info* info, int16_t* coef);
+int ofb_jpeg_decode_pixels(const ofb_jpeg_job* jobs_dev, int32_t n_images, int32_t max_blocks, int32_t max_w, int32_t max_h,
+                           const int16_t* coef_dev, uint8_t* planes_dev, uint8_t* out_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
