@@ -12,4 +12,5 @@ from .vision_transformer import (MIMVisionTransformer, VisionTransformerSearched
                                  norm_targets)
 from .model import create_model  # noqa: F401
 
-from .data import Mixup, SoftTargetCrossEntropy, RASampler, RandomErasing, RandAugment, DeviceTransform, DeviceLoader  # noqa: F401
+from .data import (Mixup, SoftTargetCrossEntropy, RASampler, RandomErasing, RandAugment, DeviceTransform, DeviceLoader,  # noqa: F401
+                   JpegDecoder)

@@ -466,12 +466,22 @@ class DeviceTransform:
         return out
 
     def __call__(self, images, plan=None, want_u8=False):
+        """images: list of HxWx3 uint8 arrays / tensors, OR list of JPEG files as `bytes` (decoded on the way by JpegDecoder:
+        host Huffman stage on worker threads, IDCT / upsampling / colour on the device - the pixels never visit the host)"""
+        if len(images) and isinstance(images[0], (bytes, bytearray, memoryview)):
+            if getattr(self, 'jpeg', None) is None:
+                self.jpeg = JpegDecoder(self.device)
+            src, offs, sizes = self.jpeg.decode(images)
+            keep = (src,)
+        else:
+            src, offs, sizes, keep = self._pack_host(images)
+        return self._run(src, offs, sizes, plan, want_u8, keep)
+
+    def _pack_host(self, images):
         # pack the decoded images into ONE pinned staging buffer (two of them, used alternately, so the copy of the previous batch may
         # still be in flight) with plain numpy copies, then one asynchronous H2D transfer
         arrs = [im.numpy() if torch.is_tensor(im) else np.asarray(im) for im in images]
         sizes = [(int(a.shape[0]), int(a.shape[1])) for a in arrs]
-        plan = self.plan(sizes) if plan is None else plan
-        B = len(arrs)
         offs, total = [], 0
         for a in arrs:
             if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
@@ -494,6 +504,13 @@ class DeviceTransform:
             flat_np[o:o + a.size] = a.reshape(-1)
         src = flat[:total].to(self.device, non_blocking=True)
         done.record()
+        return src, offs, sizes, (flat, src)
+
+    def _run(self, src, offs, sizes, plan, want_u8, keep):
+        if self.device.type != 'cuda':
+            raise hip.OfbError('once-for-both_amd kernels need device tensors (no CPU fallback); DeviceTransform was built for ' + str(self.device))
+        plan = self.plan(sizes) if plan is None else plan
+        B = len(sizes)
         tab = (hip.CropParam * B)()
         for b, ((h, w), o, (top, left, ch, cw, flip)) in enumerate(zip(sizes, offs, plan)):
             t = tab[b]
@@ -514,8 +531,70 @@ class DeviceTransform:
             hip.crop_resize_norm(src, dev_tab, B, self.S, max_h, self.mean, self.std, out, out_u8, scratch)
         if self.erase is not None:
             self.erase(out)
-        self._keep = (dev_tab, host, flat, src, scratch)
+        self._keep = (dev_tab, host, keep, scratch)
         return (out, out_u8) if want_u8 else out
+
+
+class JpegDecoder:
+    """JPEG files (bytes) -> decoded uint8 HWC RGB pixels in ONE device buffer: what PIL's default_loader hands the reference's
+    transforms (datasets.py:90-125), produced without the pixels ever visiting the host.  Per batch: the frame headers are parsed,
+    the Huffman stage of every file runs on a pool of host threads (csrc/jpeg.hip ofb_jpeg_decode_coefficients: plain C++, the
+    ctypes call releases the GIL) straight into one pinned int16 staging buffer, ONE H2D copy moves the coefficients, two launches
+    (IDCT per 8x8 block; chroma upsampling + YCbCr -> RGB per pixel) produce the pixels of the whole batch.  Arithmetic = libjpeg's
+    default path (JDCT_ISLOW, fancy upsampling), bit-exact with Pillow on the committed fixtures.  Scope: baseline / extended-
+    sequential Huffman files with 1 or 3 components; a progressive / CMYK / arithmetic-coded file raises hip.OfbError."""
+
+    def __init__(self, device='cuda', threads=8):
+        from concurrent.futures import ThreadPoolExecutor
+        self.device = torch.device(device)
+        self.pool = ThreadPoolExecutor(max_workers=max(1, int(threads)))
+        self._pins, self._slot = [None, None], 0
+
+    def decode(self, blobs):
+        """-> (flat uint8 device tensor, byte offset of each image's [H][W][3] pixels, [(H, W)])"""
+        if self.device.type != 'cuda':
+            raise hip.OfbError('once-for-both_amd kernels need device tensors (no CPU fallback); JpegDecoder was built for ' + str(self.device))
+        metas = [hip.jpeg_parse(bytes(b)) for b in blobs]
+        n = len(metas)
+        coef_offs, total = [], 0
+        for info, _ in metas:
+            coef_offs.append(total)
+            total += (int(info.coef_count) + 7) // 8 * 8
+        self._slot ^= 1
+        pin = self._pins[self._slot]
+        if pin is None or pin[0].numel() < total:
+            t = torch.empty(int(total * 1.25) + 4096, dtype=torch.int16).pin_memory()
+            pin = self._pins[self._slot] = (t, torch.cuda.Event())
+        stage, done = pin
+        done.synchronize()
+        base = stage.data_ptr()
+        list(self.pool.map(lambda a: hip.jpeg_decode_coefficients(a[0][1], len(a[0][1]), a[0][0], base + 2 * a[1]), zip(metas, coef_offs)))
+        coef = stage[:total].to(self.device, non_blocking=True)
+        done.record()
+        jobs = (hip.JpegJob * n)()
+        plane_total, out_total, max_blocks, max_w, max_h = 0, 0, 1, 1, 1
+        offs, sizes = [], []
+        for j, ((info, _), co) in zip(jobs, zip(metas, coef_offs)):
+            j.width, j.height, j.ncomp, j.hmax, j.vmax = info.width, info.height, info.ncomp, info.hmax, info.vmax
+            for c in range(info.ncomp):
+                j.hs[c], j.vs[c], j.blocks_w[c], j.blocks_h[c] = info.hs[c], info.vs[c], info.blocks_w[c], info.blocks_h[c]
+                j.coef_off[c] = co + info.coef_off[c]
+                j.plane_off[c] = plane_total
+                plane_total += (info.blocks_w[c] * info.blocks_h[c] * 64 + 15) // 16 * 16
+                max_blocks = max(max_blocks, info.blocks_w[c] * info.blocks_h[c])
+                for k in range(64):
+                    j.quant[c][k] = info.quant[c][k]
+            j.out_off = out_total
+            offs.append(out_total)
+            sizes.append((int(info.height), int(info.width)))
+            out_total += (info.height * info.width * 3 + 15) // 16 * 16
+            max_w, max_h = max(max_w, info.width), max(max_h, info.height)
+        jobs_dev, host = hip.upload_structs(jobs, self.device)
+        planes = torch.empty(plane_total, device=self.device, dtype=torch.uint8)
+        out = torch.empty(out_total, device=self.device, dtype=torch.uint8)
+        hip.jpeg_decode_pixels(jobs_dev, n, max_blocks, max_w, max_h, coef, planes, out)
+        self._keep = (jobs_dev, host, coef, planes)
+        return out, offs, sizes
 
 
 class DeviceLoader:

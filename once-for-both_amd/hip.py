@@ -28,7 +28,7 @@ SYMBOLS = [
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
     'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
     'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm', 'ofb_random_erase',
-    'ofb_randaug_layer', 'ofb_normalize_u8',
+    'ofb_randaug_layer', 'ofb_normalize_u8', 'ofb_jpeg_parse', 'ofb_jpeg_decode_coefficients', 'ofb_jpeg_decode_pixels',
 ]
 
 
@@ -888,3 +888,37 @@ def randaug_layer(src_u8, dst_u8, ops_dev, B, H, W, hist, lsum):
 def normalize_u8(src_u8, out, B, H, W, mean, std):
     m3, s3 = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
     check(lib().ofb_normalize_u8(ptr(src_u8), ptr(_f32c(out, 'out')), _i(B), _i(H), _i(W), m3, s3, stream()), 'ofb_normalize_u8')
+
+
+# ---- JPEG decode (csrc/jpeg.hip): host entropy stage + device IDCT / upsampling / colour -------------------------------------
+class JpegInfo(C.Structure):
+    _fields_ = [('width', C.c_int32), ('height', C.c_int32), ('ncomp', C.c_int32), ('hs', C.c_int32 * 3), ('vs', C.c_int32 * 3),
+                ('hmax', C.c_int32), ('vmax', C.c_int32), ('mcu_x', C.c_int32), ('mcu_y', C.c_int32), ('blocks_w', C.c_int32 * 3),
+                ('blocks_h', C.c_int32 * 3), ('pad_', C.c_int32), ('coef_off', C.c_int64 * 3), ('coef_count', C.c_int64),
+                ('quant', (C.c_uint16 * 64) * 3)]
+
+
+class JpegJob(C.Structure):
+    _fields_ = [('width', C.c_int32), ('height', C.c_int32), ('ncomp', C.c_int32), ('hs', C.c_int32 * 3), ('vs', C.c_int32 * 3),
+                ('hmax', C.c_int32), ('vmax', C.c_int32), ('blocks_w', C.c_int32 * 3), ('blocks_h', C.c_int32 * 3), ('pad_', C.c_int32),
+                ('coef_off', C.c_int64 * 3), ('plane_off', C.c_int64 * 3), ('out_off', C.c_int64), ('quant', (C.c_uint16 * 64) * 3)]
+
+
+def jpeg_parse(data):
+    """frame header of a JPEG file (bytes) -> JpegInfo; OfbError for files outside the decoder's scope (progressive, CMYK, ...)"""
+    info = JpegInfo()
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    check(lib().ofb_jpeg_parse(buf, C.c_int64(len(data)), C.byref(info)), 'ofb_jpeg_parse')
+    return info, buf
+
+
+def jpeg_decode_coefficients(buf, nbytes, info, out_ptr):
+    """host Huffman stage: writes info.coef_count int16 at out_ptr (the ctypes call releases the GIL: run it on worker threads)"""
+    check(lib().ofb_jpeg_decode_coefficients(buf, C.c_int64(nbytes), C.byref(info), C.c_void_p(out_ptr)), 'ofb_jpeg_decode_coefficients')
+
+
+def jpeg_decode_pixels(jobs_dev, n, max_blocks, max_w, max_h, coef_dev, planes_dev, out_dev):
+    if coef_dev.dtype != torch.int16 or planes_dev.dtype != torch.uint8 or out_dev.dtype != torch.uint8:
+        raise OfbError('jpeg_decode_pixels: int16 coefficients, uint8 planes / pixels')
+    check(lib().ofb_jpeg_decode_pixels(ptr(jobs_dev), _i(n), _i(max_blocks), _i(max_w), _i(max_h), _void_p(coef_dev.data_ptr()),
+                                       ptr(planes_dev), ptr(out_dev), stream()), 'ofb_jpeg_decode_pixels')
