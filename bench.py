@@ -209,7 +209,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true', help='skip per-kernel HIP-event timing')
     ap.add_argument('--prof-all', action='store_true', help='bracket every tagged kernel family in the sampled steps (default: the GEMM only)')
-    ap.add_argument('--graph', action='store_true', help='search mode, one rank: capture the whole step into a hipGraph and replay it '
+    ap.add_argument('--graph', action='store_true', help='search mode: capture the whole step (with N > 1: incl. the RCCL exchange) into a hipGraph and replay it '
                     '(engine.GraphedStep); for launch-bound sizes (small batches); the sampled profile steps stay eager')
     ap.add_argument('--force-dp', action='store_true', help='exercise the DP bucket path even with one rank (debug)')
     args = ap.parse_args()
@@ -244,9 +244,11 @@ def main():
     from ofb_amd import engine, hip
     from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
 
-    use_graph = args.graph and args.mode == 'search' and world == 1
+    use_graph = args.graph and args.mode == 'search'
     if use_graph:
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))     # the whole job on ONE non-default stream: capturable (GraphedStep)
+    elif os.environ.get('OFB_MAIN_STREAM_PRIORITY'):             # lab: the critical path on a high-priority stream, dW on the normal side stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=int(os.environ['OFB_MAIN_STREAM_PRIORITY'])))
     torch.manual_seed(0 + rank)                              # per-rank init streams (search.py:381); the reducer broadcasts rank 0's replica
     ncls = 1000
     eff_bs = args.batch * world
@@ -313,7 +315,7 @@ def main():
         step()
     eager_step = step
     if use_graph:
-        gstep = engine.GraphedStep(eager_step, (opt_p, opt_a, opt_d))
+        gstep = engine.GraphedStep(eager_step, (opt_p, opt_a, opt_d), reducer=reducer)   # with a reducer the RCCL exchange is captured too
         gstep.capture()                                      # two more eager steps on the capture stream, then the capture
         step = gstep
     for _ in range(args.warmup):

@@ -80,6 +80,9 @@ int64_t ofb_pformat_bytes(int32_t R, int32_t C);
 /* X[R][C] (row-major, ld), optionally * rowscale[r / rs_div]  ->  P-format (zero padded).  Used for tensors whose producer is
  * not one of the kernels below (weights once per optimizer step, DropPath-scaled gradients, patchified pixels). */
 int ofb_to_pformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div, void* stream);
+/* The patch matrix of the patch-embedding conv (models/layers.py:177: Conv2d with kernel = stride = patch is patchify + Linear) written
+ * as planes straight from the images: P[(b, py, px)][(c, i, j)] = img[b][c][py*patch + i][px*patch + j]; no f32 copy of it exists. */
+int ofb_patchify_pformat(const float* img, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* P, void* stream);
 /* Many conversions in one launch (the model's weights, once per optimizer step; the gate-scaled weights of one backward pass):
  * jobs_dev[n_jobs] in device memory, each {X (f32 [R][C], row stride ld), P (ofb_pformat_bytes(R, C) bytes), rowscale (optional:
  * row r is multiplied by rowscale[r]), R, C, ld}; max_R / max_C = the largest R / C among them. */

@@ -104,6 +104,27 @@ __global__ void to_pformat_kernel(const float* __restrict__ X, int R, int C, int
   }
   store_p4(P + ((size_t)rg * ncb + (c >> 4)) * GRAN + (c & 15) * 8, v[0], v[1], v[2], v[3]);
 }
+// Patch matrix of a conv-as-GEMM straight from the images (models/layers.py:177: Conv2d(k = s = patch) == patchify + Linear): row
+// (b, py, px) x column (c, i, j) = img[b][c][py * patch + i][px * patch + j], written as planes without the [B*L][C*patch^2] f32 copy in between
+__global__ void patchify_pformat_kernel(const float* __restrict__ img, int B, int Cin, int Hh, int Ww, int patch, char* __restrict__ P,
+                                        int ncb) {
+  const int gw = Ww / patch, L = (Hh / patch) * gw, R = B * L, Cc = Cin * patch * patch;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, rg = blockIdx.y;
+  if (c >= ncb * 16) return;
+  const int ch = c / (patch * patch), rem = c - ch * patch * patch, i = rem / patch, j = rem - i * patch;
+  float v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = 4 * rg + t;
+    float x = 0.f;
+    if (r < R && c < Cc) {
+      const int b = r / L, l = r - b * L, py = l / gw, px = l - py * gw;
+      x = img[(((size_t)b * Cin + ch) * Hh + py * patch + i) * Ww + px * patch + j];
+    }
+    v[t] = x;
+  }
+  store_p4(P + ((size_t)rg * ncb + (c >> 4)) * GRAN + (c & 15) * 8, v[0], v[1], v[2], v[3]);
+}
 // Many matrices in ONE launch (the weights of the model, once per optimizer step): blockIdx.z picks the matrix, the grid covers the
 // largest one and the blocks beyond a matrix's own extent leave at once.
 __global__ void to_pformat_multi_kernel(const ofb_pformat_job* __restrict__ jobs) {
@@ -760,6 +781,17 @@ extern "C" int ofb_to_pformat(const float* X, int32_t R, int32_t C, int32_t ld, 
   const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4;
   hipLaunchKernelGGL(to_pformat_kernel, dim3((ncb * 16 + 255) / 256, rgs), dim3(256), 0, (hipStream_t)stream, X, R, C, ld, (char*)P,
                      ncb, rowscale, rs_div);
+  return ofb_launch_status();
+}
+
+// img [B][Cin][H][W] -> P-format planes of the patch matrix [B * (H/patch) * (W/patch)][Cin * patch * patch]
+extern "C" int ofb_patchify_pformat(const float* img, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* P, void* stream) {
+  if (!img || !P || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || patch <= 0 || H % patch || W % patch) return OFB_EINVAL;
+  const int64_t R = (int64_t)B * (H / patch) * (W / patch), Cc = (int64_t)Cin * patch * patch;
+  if (R > 0x7fffffff / 4 || Cc > 65536) return OFB_ELIMIT;
+  const int ncb = (int)((Cc + 15) / 16), rgs = (int)(((R + 15) / 16) * 4);
+  hipLaunchKernelGGL(patchify_pformat_kernel, dim3((ncb * 16 + 255) / 256, rgs), dim3(256), 0, (hipStream_t)stream, img, B, Cin, H, W, patch,
+                     (char*)P, ncb);
   return ofb_launch_status();
 }
 

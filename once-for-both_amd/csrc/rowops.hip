@@ -368,19 +368,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x
 }
 
 // Many column-sum jobs in ONE launch (the LayerNorm parameter gradients of a whole backward pass: 25 x [1024 partial rows][3 D]):
-// block (column block, job); wave w adds the job's rows w, w + 4, ... in order, the four waves' sums are added in wave order.
-__global__ __launch_bounds__(256) void colsum_multi_kernel(const ofb_colsum_job* __restrict__ jobs) {
-  __shared__ float red[4][64];
+// block (column block, job) of 16 waves; wave w adds the job's rows w, w + 16, ... in a fixed order, then the 16 sums in wave order.
+__global__ __launch_bounds__(1024) void colsum_multi_kernel(const ofb_colsum_job* __restrict__ jobs) {
+  __shared__ float red[16][64];
   const ofb_colsum_job j = jobs[blockIdx.y];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
   if (blockIdx.x * 64 >= j.N) return;
-  float s = 0.f;
-  if (col < j.N)
-    for (int r = w; r < j.M; r += 4) s += j.x[(size_t)r * j.ld + col];
-  red[w][lane] = s;
+  float s0 = 0.f, s1 = 0.f;                                // two loads in flight per thread; rows w, w + 16, ... added in order
+  if (col < j.N) {
+    int r = w;
+    for (; r + 16 < j.M; r += 32) { s0 += j.x[(size_t)r * j.ld + col]; s1 += j.x[(size_t)(r + 16) * j.ld + col]; }
+    if (r < j.M) s0 += j.x[(size_t)r * j.ld + col];
+  }
+  red[w][lane] = s0 + s1;
   __syncthreads();
-  if (w == 0 && col < j.N) j.out[col] = red[0][lane] + red[1][lane] + red[2][lane] + red[3][lane];
+  if (w == 0 && col < j.N) {
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][lane];
+    j.out[col] = s;
+  }
 }
 
 __global__ void scale_rows_kernel(const float* __restrict__ W, const float* __restrict__ g, float* __restrict__ out, int N,
@@ -562,6 +570,6 @@ extern "C" int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float
 // out[N] = column sums of x[M][ld] for every job, one launch; max_N = the widest job
 extern "C" int ofb_colsum_multi(const ofb_colsum_job* jobs_dev, int32_t n_jobs, int32_t max_N, void* stream) {
   if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535 || max_N <= 0) return OFB_EINVAL;
-  hipLaunchKernelGGL(colsum_multi_kernel, dim3(ofb_cdiv(max_N, 64), n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
+  hipLaunchKernelGGL(colsum_multi_kernel, dim3(ofb_cdiv(max_N, 64), n_jobs), dim3(1024), 0, (hipStream_t)stream, jobs_dev);
   return ofb_launch_status();
 }

@@ -58,10 +58,13 @@ class GraphedStep:
     (allocator / workspaces warm); it may use the side stream (it is forked from and joined into the capturing stream).  The AdamW
     instances passed in read their learning rate and bias corrections from device memory inside the graph (optim.AdamW.begin_capture)
     and are refreshed before every replay; random draws (DropPath, patch masking) come from torch's graph-safe generator.
-    Not for world size > 1 (the RCCL exchange is not captured) and not across compress() (shapes change: capture again)."""
+    With a data-parallel reducer (pass it as `reducer`): the bucketed RCCL all-reduces of the step are captured with it (RCCL
+    collectives are stream-ordered kernels; every rank captures and replays the same sequence) - the launch-bound sizes keep the
+    graph's gain when a second rank exists.  Not across compress() (shapes and buckets change: capture again)."""
 
-    def __init__(self, fn, optimizers):
+    def __init__(self, fn, optimizers, reducer=None):
         self.fn, self.opts = fn, [o for o in optimizers if o is not None]
+        self.reducer = reducer
         self.graph, self.out, self.k, self._keep = None, None, 0, None
 
     def capture(self, warm_steps=2):

@@ -21,7 +21,7 @@ ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_gemm_p_colpart_rows', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_gemm_p_colpart_rows', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_patchify_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_fwd_p', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
@@ -179,6 +179,16 @@ def to_pformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1, colsum_out=
 def to_pformat_into(x, R, Cc, ld, pm, rowscale=None, rs_div=1):
     """the same conversion into existing planes `pm` (persistent weight planes)"""
     check(lib().ofb_to_pformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), stream()), 'ofb_to_pformat')
+    return pm
+
+
+def patchify_pformat(imgs, patch):
+    """[B][Cin][H][W] f32 images -> PMat of the patch matrix [B * L][Cin * patch^2] (conv-as-GEMM operand), no f32 copy in between"""
+    if imgs.dtype != torch.float32 or not imgs.is_contiguous() or imgs.dim() != 4:
+        raise OfbError('patchify_pformat needs a contiguous float32 [B][C][H][W] tensor')
+    B, Cin, Hh, Ww = imgs.shape
+    pm = PMat(B * (Hh // patch) * (Ww // patch), Cin * patch * patch, imgs.device)
+    check(lib().ofb_patchify_pformat(ptr(imgs), _i(B), _i(Cin), _i(Hh), _i(Ww), _i(patch), ptr(pm.buf), stream()), 'ofb_patchify_pformat')
     return pm
 
 

@@ -468,13 +468,12 @@ class PatchEmbedTokens(torch.autograd.Function):
         B, Cin, Hh, Ww = imgs.shape
         gh, gw = Hh // patch, Ww // patch
         L, D = gh * gw, wconv.shape[0]
-        # patchify = pure data movement (one strided copy): rows (b, py, px), columns (c, i, j)
-        patches = imgs.reshape(B, Cin, gh, patch, gw, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * L, Cin * patch * patch)
-        patches = _c(patches)
+        # patchify is folded into the operand conversion: the planes of the patch matrix (rows (b, py, px), columns (c, i, j)) are
+        # written straight from the images; the backward needs them only as a weight-gradient operand
         w2d = wconv.reshape(D, -1)
-        patchesP = hip.to_pformat(patches, B * L, w2d.shape[1], w2d.shape[1])
+        patchesP = hip.patchify_pformat(_c(imgs), patch)
         conv, _ = p_linear_fwd(patchesP, B * L, w2d.shape[1], hip.weight_p(wconv, (D, w2d.shape[1])), bconv)
-        patches = patchesP.buf                           # the backward needs the patches only as a weight-gradient operand
+        patches = patchesP.buf
         tok = _new(imgs, B, L + 1, D)
         gv = None if g is None else _c(g.reshape(-1))
         posv, clsv = _c(pos.reshape(L + 1, D)), _c(cls.reshape(-1))

@@ -108,3 +108,40 @@ def test_rccl_all_reduce_moves_bytes(rccl_world_of_one):
         assert dist.get_backend() == 'nccl' and dist.get_world_size() == 1
     finally:
         red.close()
+
+
+def test_graphed_step_with_rccl_exchange(rccl_world_of_one):
+    """hipGraph capture of the whole step INCLUDING the bucketed RCCL exchange (engine.GraphedStep with a reducer): the replays must
+    walk the parameters like eager steps with the same reducer.  One rank: the collective is issued for real (force_collective)."""
+    import ofb_amd
+    from ofb_amd import engine
+    z, cfg, st, inputs, lr = load_case('micro_a')
+    prev = torch.cuda.current_stream()
+    torch.cuda.set_stream(torch.cuda.Stream())
+    try:
+        res = []
+        for graphed in (False, True):
+            m = build_product(cfg, st, inputs)
+            opts = engine.build_optimizers(m, 1e-3)
+            red = ofb_amd.dp.GradAllReducer(list(m.parameters()), bucket_bytes=256 * 1024, force_collective=True)
+            crit = _crit()
+            imgs, labels = inputs['imgs'].cuda(), inputs['labels'].cuda()
+            step = lambda: engine.search_step(m, crit, imgs, labels, 1.0, opts, reducer=red)
+            try:
+                if graphed:
+                    gs = engine.GraphedStep(step, opts, reducer=red)
+                    gs.capture(warm_steps=2)
+                    for _ in range(3):
+                        gs()
+                else:
+                    for _ in range(5):
+                        step()
+                torch.cuda.synchronize()
+                res.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+            finally:
+                red.close()
+        worst = max(float((res[0][k].double() - res[1][k].double()).abs().max() / (res[0][k].double().abs().max() + 1e-12)) for k in res[0])
+        print('graphed + RCCL vs eager + RCCL: worst relative parameter difference', worst)
+        assert worst <= 1e-5
+    finally:
+        torch.cuda.set_stream(prev)

@@ -187,3 +187,17 @@ def test_weight_planes_are_refreshed_together():
     out = torch.empty(50, 70, device='cuda')
     hip.gemm_p(hip.to_pformat(a), hip.weight_p(ws[5]), 1, 1, 50, 70, 36, C_out=out, ldc=70)
     _close(out, a.double().cpu() @ ws[5].detach().double().cpu().t(), 'multi-converted planes as GEMM operand', tol=2e-6)
+
+
+@pytest.mark.parametrize('B,Cin,S,patch', [(3, 3, 224, 16), (2, 3, 64, 16), (5, 1, 48, 8)])
+def test_patchify_planes_equal_the_patch_matrix(B, Cin, S, patch):
+    """ofb_patchify_pformat: the planes of the patch-embedding conv's GEMM operand written straight from the images hold exactly the
+    patch matrix of models/layers.py:177 (Conv2d with kernel = stride = patch): rows (b, py, px), columns (c, i, j)"""
+    from ofb_amd import hip
+    g = torch.Generator().manual_seed(B + S)
+    imgs = torch.randn(B, Cin, S, S, generator=g).cuda()
+    gh = S // patch
+    ref = imgs.reshape(B, Cin, gh, patch, gh, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gh, Cin * patch * patch)
+    pm = hip.patchify_pformat(imgs, patch)
+    assert (pm.R, pm.C) == tuple(ref.shape)
+    assert torch.equal(pm.to_f32(), ref)
