@@ -682,9 +682,13 @@ int p_tile_choice(const ofb_gemm_p_args&) {
 template <class CF>
 Plan plan_p(const ofb_gemm_p_args& g) {
   int W = p_cu_count() * CF::WGS;
-  if (!g.a_kc && !g.b_kc) {                                          // weight-gradient form (lab knob): workgroups per CU
+  if (!g.a_kc && !g.b_kc) {
+    // weight-gradient form: ONE workgroup per CU.  Its 18-24 output tiles are cut along K into W pieces, each leaving a 96-KB
+    // partial tile for the fix-up: half the workgroups = half that traffic (2.4 GB written + re-read per DeiT-S step) at an
+    // equal step time (same-box A/B 24.9 / 25.0 ms both ways; the K loops of the co-running main-stream kernels fill the CUs).
+    // OFB_GEMM_P_DW_WGS=2 restores two per CU (lab).
     static int dw_wgs = -1;
-    if (dw_wgs < 0) { const char* e = getenv("OFB_GEMM_P_DW_WGS"); dw_wgs = e ? atoi(e) : 0; }
+    if (dw_wgs < 0) { const char* e = getenv("OFB_GEMM_P_DW_WGS"); dw_wgs = e ? atoi(e) : 1; }
     if (dw_wgs > 0 && dw_wgs < CF::WGS) W = p_cu_count() * dw_wgs;
   }
 #ifdef OFB_P_STAMPS
