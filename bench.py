@@ -213,6 +213,7 @@ def main():
                     '(engine.GraphedStep); for launch-bound sizes (small batches); the sampled profile steps stay eager')
     ap.add_argument('--force-dp', action='store_true', help='exercise the DP bucket path even with one rank (debug)')
     args = ap.parse_args()
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')          # before the HIP runtime starts: see ofb_amd.hip.ensure_side_stream
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:     # bare `python bench.py --gpus N`: become the launcher
         raise SystemExit(self_launch(args.gpus))
@@ -232,6 +233,8 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the once-for-both_amd hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    import ofb_amd
+    ofb_amd.hip.ensure_side_stream(dev)                      # before RCCL creates its streams (hardware-queue mapping)
     import torch.distributed as dist
     if world > 1 or (args.force_dp and 'MASTER_ADDR' in os.environ):      # --force-dp under torchrun: a one-rank RCCL group
         dist.init_process_group('nccl', init_method='env://', device_id=dev)

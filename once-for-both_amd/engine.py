@@ -89,8 +89,13 @@ class GraphedStep:
         for o in self.opts:
             o.begin_capture()
         graph = torch.cuda.CUDAGraph()
+        # With a process group in the process its watchdog thread polls the events of earlier collectives while this thread
+        # captures: under the default 'global' capture mode a runtime call from ANOTHER thread can invalidate the capture (or abort
+        # the process from that thread); 'thread_local' restricts the checks to the capturing thread.
+        import torch.distributed as dist
+        mode = 'thread_local' if (dist.is_available() and dist.is_initialized()) else 'global'
         try:
-            with torch.cuda.graph(graph, stream=self.stream):
+            with torch.cuda.graph(graph, stream=self.stream, capture_error_mode=mode):
                 self.out = self.fn()
         finally:
             hip.end_capture_arena()

@@ -27,8 +27,11 @@ def rccl_world_of_one():
     port = s.getsockname()[1]
     s.close()
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    from ofb_amd import hip
+    hip.ensure_side_stream(torch.device('cuda', 0))          # before RCCL's streams exist (hardware-queue mapping)
     dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', world_size=1, rank=0, device_id=torch.device('cuda', 0))
     yield
+    torch.cuda.synchronize()
     dist.destroy_process_group()
 
 
