@@ -432,6 +432,13 @@ typedef struct ofb_jpeg_job {
 } ofb_jpeg_job;
 int ofb_jpeg_parse(const uint8_t* data, int64_t nbytes, ofb_jpeg_info* info);
 int ofb_jpeg_decode_coefficients(const uint8_t* data, int64_t nbytes, const ofb_jpeg_info* info, int16_t* coef);
+/* Whole-batch host stage: plan = parse every header and lay the batch out (infos[n], jobs[n] with absolute offsets, totals[6] =
+   {coefficient elements, plane bytes, pixel bytes, max blocks of a component, max width, max height}); decode = the Huffman stage of all
+   files on `threads` host threads into the staging buffer the plan sized (pinned memory; one H2D copy follows). */
+int ofb_jpeg_plan_batch(const uint8_t* const* files, const int64_t* nbytes, int32_t n, ofb_jpeg_info* infos, ofb_jpeg_job* jobs,
+                        int64_t* totals);
+int ofb_jpeg_decode_batch(const uint8_t* const* files, const int64_t* nbytes, int32_t n, const ofb_jpeg_info* infos,
+                          const ofb_jpeg_job* jobs, int16_t* coef, int32_t threads);
 int ofb_jpeg_decode_pixels(const ofb_jpeg_job* jobs_dev, int32_t n_images, int32_t max_blocks, int32_t max_w, int32_t max_h,
                            const int16_t* coef_dev, uint8_t* planes_dev, uint8_t* out_dev, void* stream);
 

@@ -10,6 +10,9 @@
 // with edge replication, jdcolor.c fixed-point YCbCr -> RGB.  Scope: baseline / extended-sequential Huffman JPEG (SOF0 / SOF1),
 // 8-bit, 1 (grayscale -> RGB) or 3 (YCbCr) components, any scan structure, restart intervals.  Progressive (SOF2), arithmetic
 // coding, CMYK and 12-bit files are rejected with OFB_ELIMIT (the loader may hand those few files to another decoder).
+#include <atomic>
+#include <thread>
+#include <vector>
 #include "ofb_common.h"
 #include <string.h>
 
@@ -331,6 +334,59 @@ extern "C" int ofb_jpeg_decode_coefficients(const uint8_t* data, int64_t nbytes,
     pos += len;
   }
   return OFB_OK;
+}
+
+// Whole-batch host stage (what data.JpegDecoder calls): the per-file work above without a Python round trip per file.
+// plan: parses every frame header and lays the batch out - infos[i], the device job records jobs[i] (absolute coefficient / plane /
+// pixel offsets), totals[6] = {coefficient elements, plane bytes, pixel bytes, max blocks of a component, max width, max height}.
+extern "C" int ofb_jpeg_plan_batch(const uint8_t* const* files, const int64_t* nbytes, int32_t n, ofb_jpeg_info* infos, ofb_jpeg_job* jobs,
+                                   int64_t* totals) {
+  if (!files || !nbytes || !infos || !jobs || !totals || n <= 0) return OFB_EINVAL;
+  int64_t coef_total = 0, plane_total = 0, out_total = 0, max_blocks = 1, max_w = 1, max_h = 1;
+  for (int i = 0; i < n; ++i) {
+    if (int rc = ofb_jpeg_parse(files[i], nbytes[i], &infos[i])) return rc;
+    const ofb_jpeg_info& I = infos[i];
+    ofb_jpeg_job& J = jobs[i];
+    memset(&J, 0, sizeof(J));
+    J.width = I.width; J.height = I.height; J.ncomp = I.ncomp; J.hmax = I.hmax; J.vmax = I.vmax;
+    for (int c = 0; c < I.ncomp; ++c) {
+      J.hs[c] = I.hs[c]; J.vs[c] = I.vs[c]; J.blocks_w[c] = I.blocks_w[c]; J.blocks_h[c] = I.blocks_h[c];
+      J.coef_off[c] = coef_total + I.coef_off[c];
+      J.plane_off[c] = plane_total;
+      const int64_t nb = (int64_t)I.blocks_w[c] * I.blocks_h[c];
+      plane_total += (nb * 64 + 15) / 16 * 16;
+      max_blocks = nb > max_blocks ? nb : max_blocks;
+      memcpy(J.quant[c], I.quant[c], sizeof(J.quant[c]));
+    }
+    J.out_off = out_total;
+    out_total += ((int64_t)I.height * I.width * 3 + 15) / 16 * 16;
+    coef_total += (I.coef_count + 7) / 8 * 8;
+    max_w = I.width > max_w ? I.width : max_w;
+    max_h = I.height > max_h ? I.height : max_h;
+  }
+  totals[0] = coef_total; totals[1] = plane_total; totals[2] = out_total; totals[3] = max_blocks; totals[4] = max_w; totals[5] = max_h;
+  return OFB_OK;
+}
+
+// entropy stage of the planned batch on `threads` host threads (a work queue over the files); coef: totals[0] int16 of staging
+extern "C" int ofb_jpeg_decode_batch(const uint8_t* const* files, const int64_t* nbytes, int32_t n, const ofb_jpeg_info* infos,
+                                     const ofb_jpeg_job* jobs, int16_t* coef, int32_t threads) {
+  if (!files || !nbytes || !infos || !jobs || !coef || n <= 0) return OFB_EINVAL;
+  std::atomic<int> next(0), status(OFB_OK);
+  auto work = [&]() {
+    for (;;) {
+      const int i = next.fetch_add(1);
+      if (i >= n) return;
+      const int rc = ofb_jpeg_decode_coefficients(files[i], nbytes[i], &infos[i], coef + (jobs[i].coef_off[0] - infos[i].coef_off[0]));
+      if (rc != OFB_OK) { int ok = OFB_OK; status.compare_exchange_strong(ok, rc); }
+    }
+  };
+  const int nt = threads < 1 ? 1 : (threads > n ? n : threads);
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(work);
+  work();
+  for (auto& th : pool) th.join();
+  return status.load();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------

@@ -9,6 +9,7 @@ import math
 import random
 
 import numpy as np
+import os
 import torch
 
 from . import hip
@@ -535,6 +536,18 @@ class DeviceTransform:
         return (out, out_u8) if want_u8 else out
 
 
+def _cpu_share():
+    """CPUs this process may really use: the cgroup quota (cpu.max) when there is one, else the affinity mask"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 8)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 class JpegDecoder:
     """JPEG files (bytes) -> decoded uint8 HWC RGB pixels in ONE device buffer: what PIL's default_loader hands the reference's
     transforms (datasets.py:90-125), produced without the pixels ever visiting the host.  Per batch: the frame headers are parsed,
@@ -544,56 +557,33 @@ class JpegDecoder:
     default path (JDCT_ISLOW, fancy upsampling), bit-exact with Pillow on the committed fixtures.  Scope: baseline / extended-
     sequential Huffman files with 1 or 3 components; a progressive / CMYK / arithmetic-coded file raises hip.OfbError."""
 
-    def __init__(self, device='cuda', threads=8):
-        from concurrent.futures import ThreadPoolExecutor
+    def __init__(self, device='cuda', threads=None):
         self.device = torch.device(device)
-        self.pool = ThreadPoolExecutor(max_workers=max(1, int(threads)))
+        self.threads = int(threads) if threads else max(1, min(16, _cpu_share()))
         self._pins, self._slot = [None, None], 0
 
     def decode(self, blobs):
         """-> (flat uint8 device tensor, byte offset of each image's [H][W][3] pixels, [(H, W)])"""
         if self.device.type != 'cuda':
             raise hip.OfbError('once-for-both_amd kernels need device tensors (no CPU fallback); JpegDecoder was built for ' + str(self.device))
-        metas = [hip.jpeg_parse(bytes(b)) for b in blobs]
-        n = len(metas)
-        coef_offs, total = [], 0
-        for info, _ in metas:
-            coef_offs.append(total)
-            total += (int(info.coef_count) + 7) // 8 * 8
+        pb = hip.jpeg_plan_batch(blobs)                       # headers of all files, batch layout, device job records (native)
         self._slot ^= 1
         pin = self._pins[self._slot]
-        if pin is None or pin[0].numel() < total:
-            t = torch.empty(int(total * 1.25) + 4096, dtype=torch.int16).pin_memory()
+        if pin is None or pin[0].numel() < pb.coef_total:
+            t = torch.empty(int(pb.coef_total * 1.25) + 4096, dtype=torch.int16).pin_memory()
             pin = self._pins[self._slot] = (t, torch.cuda.Event())
         stage, done = pin
-        done.synchronize()
-        base = stage.data_ptr()
-        list(self.pool.map(lambda a: hip.jpeg_decode_coefficients(a[0][1], len(a[0][1]), a[0][0], base + 2 * a[1]), zip(metas, coef_offs)))
-        coef = stage[:total].to(self.device, non_blocking=True)
+        done.synchronize()                                    # the copy that last read this staging buffer has finished
+        hip.jpeg_decode_batch(pb, stage.data_ptr(), self.threads)
+        coef = stage[:pb.coef_total].to(self.device, non_blocking=True)
         done.record()
-        jobs = (hip.JpegJob * n)()
-        plane_total, out_total, max_blocks, max_w, max_h = 0, 0, 1, 1, 1
-        offs, sizes = [], []
-        for j, ((info, _), co) in zip(jobs, zip(metas, coef_offs)):
-            j.width, j.height, j.ncomp, j.hmax, j.vmax = info.width, info.height, info.ncomp, info.hmax, info.vmax
-            for c in range(info.ncomp):
-                j.hs[c], j.vs[c], j.blocks_w[c], j.blocks_h[c] = info.hs[c], info.vs[c], info.blocks_w[c], info.blocks_h[c]
-                j.coef_off[c] = co + info.coef_off[c]
-                j.plane_off[c] = plane_total
-                plane_total += (info.blocks_w[c] * info.blocks_h[c] * 64 + 15) // 16 * 16
-                max_blocks = max(max_blocks, info.blocks_w[c] * info.blocks_h[c])
-                for k in range(64):
-                    j.quant[c][k] = info.quant[c][k]
-            j.out_off = out_total
-            offs.append(out_total)
-            sizes.append((int(info.height), int(info.width)))
-            out_total += (info.height * info.width * 3 + 15) // 16 * 16
-            max_w, max_h = max(max_w, info.width), max(max_h, info.height)
-        jobs_dev, host = hip.upload_structs(jobs, self.device)
-        planes = torch.empty(plane_total, device=self.device, dtype=torch.uint8)
-        out = torch.empty(out_total, device=self.device, dtype=torch.uint8)
-        hip.jpeg_decode_pixels(jobs_dev, n, max_blocks, max_w, max_h, coef, planes, out)
+        jobs_dev, host = hip.upload_structs(pb.jobs, self.device)
+        planes = torch.empty(pb.plane_total, device=self.device, dtype=torch.uint8)
+        out = torch.empty(pb.out_total, device=self.device, dtype=torch.uint8)
+        hip.jpeg_decode_pixels(jobs_dev, pb.n, pb.max_blocks, pb.max_w, pb.max_h, coef, planes, out)
         self._keep = (jobs_dev, host, coef, planes)
+        offs = [int(j.out_off) for j in pb.jobs]
+        sizes = [(int(j.height), int(j.width)) for j in pb.jobs]
         return out, offs, sizes
 
 

@@ -28,7 +28,7 @@ SYMBOLS = [
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
     'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
     'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm', 'ofb_random_erase',
-    'ofb_randaug_layer', 'ofb_normalize_u8', 'ofb_jpeg_parse', 'ofb_jpeg_decode_coefficients', 'ofb_jpeg_decode_pixels',
+    'ofb_randaug_layer', 'ofb_normalize_u8', 'ofb_jpeg_parse', 'ofb_jpeg_decode_coefficients', 'ofb_jpeg_plan_batch', 'ofb_jpeg_decode_batch', 'ofb_jpeg_decode_pixels',
 ]
 
 
@@ -687,7 +687,11 @@ def upload_structs(array, device):
         dev = torch.empty(n, dtype=torch.uint8, device=device)
         check(lib().ofb_upload(ptr(dev), C.c_void_p(host.data_ptr()), C.c_int64(n), stream()), 'ofb_upload')
         return dev, host
-    host = torch.frombuffer(bytearray(raw), dtype=torch.uint8).pin_memory()
+    # pinned block from torch's caching host allocator, filled by memmove: `frombuffer(...).pin_memory()` copies with ATen's parallel
+    # copy, which above 32 K elements wakes every OpenMP thread of the process (128 spinning threads on a 16-CPU cgroup share got
+    # the whole process throttled for ~90 ms at a time: JPEG job tables, scripts/lab/time_jpeg_stages.py)
+    host = torch.empty(len(raw), dtype=torch.uint8, pin_memory=True)
+    C.memmove(host.data_ptr(), raw, len(raw))
     return host.to(device, non_blocking=True), host
 
 
@@ -944,6 +948,34 @@ def jpeg_parse(data):
 def jpeg_decode_coefficients(buf, nbytes, info, out_ptr):
     """host Huffman stage: writes info.coef_count int16 at out_ptr (the ctypes call releases the GIL: run it on worker threads)"""
     check(lib().ofb_jpeg_decode_coefficients(buf, C.c_int64(nbytes), C.byref(info), C.c_void_p(out_ptr)), 'ofb_jpeg_decode_coefficients')
+
+
+class JpegBatch:
+    """the host-side plan of a batch of JPEG files (ofb_jpeg_plan_batch): per-file info and device job records, the buffer sizes"""
+    __slots__ = ('n', 'files', 'nbytes', 'infos', 'jobs', 'coef_total', 'plane_total', 'out_total', 'max_blocks', 'max_w', 'max_h', '_blobs')
+
+
+def jpeg_plan_batch(blobs):
+    n = len(blobs)
+    if n == 0:
+        raise OfbError('jpeg_plan_batch: empty batch')
+    blobs = [b if isinstance(b, bytes) else bytes(b) for b in blobs]
+    pb = JpegBatch()
+    pb.n, pb._blobs = n, blobs
+    pb.files = (C.c_char_p * n)(*blobs)                       # pointers into the bytes objects (kept alive by _blobs)
+    pb.nbytes = (C.c_int64 * n)(*[len(b) for b in blobs])
+    pb.infos, pb.jobs = (JpegInfo * n)(), (JpegJob * n)()
+    totals = (C.c_int64 * 6)()
+    check(lib().ofb_jpeg_plan_batch(pb.files, pb.nbytes, _i(n), pb.infos, pb.jobs, totals), 'ofb_jpeg_plan_batch')
+    pb.coef_total, pb.plane_total, pb.out_total, pb.max_blocks, pb.max_w, pb.max_h = [int(v) for v in totals]
+    return pb
+
+
+def jpeg_decode_batch(pb, coef_ptr, threads):
+    """host Huffman stage of the whole batch on `threads` native threads (the ctypes call releases the GIL); coef_ptr: pb.coef_total
+    int16 of (pinned) host memory"""
+    check(lib().ofb_jpeg_decode_batch(pb.files, pb.nbytes, _i(pb.n), pb.infos, pb.jobs, C.c_void_p(coef_ptr), _i(max(1, int(threads)))),
+          'ofb_jpeg_decode_batch')
 
 
 def jpeg_decode_pixels(jobs_dev, n, max_blocks, max_w, max_h, coef_dev, planes_dev, out_dev):

@@ -39,3 +39,39 @@ tot = st.total_tt
 print(f'one call under cProfile: {tot * 1e3:.1f} ms; top host costs:')
 for func, (cc, nc, tt, ct, callers) in sorted(st.stats.items(), key=lambda kv: -kv[1][3])[:8]:
     print(f'   {ct * 1e3:7.2f} ms  {func[2]} ({os.path.basename(func[0])}:{func[1]})')
+
+# ---- JPEG bytes in (datasets.py:90-125): host Huffman stage on a thread pool + device IDCT / upsampling / colour ----
+try:
+    import io
+    from PIL import Image
+    # photo-like content (smooth gradients + texture) so that the entropy-coded size is ImageNet-like (~110 KB at 500 x 375, q = 90)
+    def photo(h, w):
+        yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+        base = np.stack([128 + 80 * np.sin(xx / 37 + c) * np.cos(yy / 53 - c) for c in range(3)], -1)
+        return np.clip(base + rng.normal(0, 12, size=(h, w, 3)), 0, 255).astype(np.uint8)
+    blobs = []
+    for im in imgs:
+        buf = io.BytesIO()
+        Image.fromarray(photo(im.shape[0], im.shape[1])).save(buf, format='JPEG', quality=90, subsampling='4:2:0')
+        blobs.append(buf.getvalue())
+    print(f'JPEG batch: {B} files, {sum(len(b) for b in blobs) / B / 1e3:.0f} KB each on average')
+    for threads in (4, 8, 16):
+        dec = ofb_amd.JpegDecoder('cuda', threads=threads)
+        for _ in range(3): dec.decode(blobs)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(10): dec.decode(blobs)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+        print(f'JpegDecoder.decode, {threads:2d} host threads          {B / dt:9.0f} images/s   ({dt * 1e3:.2f} ms per batch)')
+    t0 = time.perf_counter()
+    for _ in range(3):
+        ref = [np.asarray(Image.open(io.BytesIO(b)).convert('RGB')) for b in blobs]
+    dt = (time.perf_counter() - t0) / 3
+    print(f'Pillow decode, one thread (the reference loader, per worker)   {B / dt:9.0f} images/s')
+    tf = ofb_amd.DeviceTransform(224, True, 'bicubic', auto_augment='rand-m9-mstd0.5-inc1', re_prob=0.25)
+    for _ in range(3): tf(blobs)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(10): x = tf(blobs)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 10
+    print(f'JPEG bytes -> decode -> crop / RandAugment / normalize / erase   {B / dt:9.0f} images/s   ({dt * 1e3:.2f} ms per batch)')
+except ImportError as e:
+    print('JPEG leg skipped:', e)

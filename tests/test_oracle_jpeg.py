@@ -71,3 +71,33 @@ def test_out_of_scope_files_are_rejected():
         hip.jpeg_decode_coefficients(buf2, len(bad), info2, coef.ctypes.data)
     except hip.OfbError:
         pass
+
+
+def test_batch_host_stage_equals_the_per_file_calls():
+    """ofb_jpeg_plan_batch / ofb_jpeg_decode_batch (native thread pool, what JpegDecoder uses) against the per-file entry points"""
+    import __graft_entry__ as g
+    g.build()
+    from ofb_amd import hip
+    cases = _cases()
+    blobs = [c[1] for c in cases] * 3                                  # 36 files over 5 threads: the work queue wraps around
+    pb = hip.jpeg_plan_batch(blobs)
+    coef = np.full(pb.coef_total, 77, np.int16)
+    hip.jpeg_decode_batch(pb, coef.ctypes.data, 5)
+    out_off, plane_off = 0, 0
+    for i, data in enumerate(blobs):
+        info, buf = hip.jpeg_parse(data)
+        one = np.zeros(int(info.coef_count), np.int16)
+        hip.jpeg_decode_coefficients(buf, len(data), info, one.ctypes.data)
+        j = pb.jobs[i]
+        assert (j.width, j.height, j.ncomp, j.out_off) == (info.width, info.height, info.ncomp, out_off)
+        base = j.coef_off[0] - info.coef_off[0]
+        assert np.array_equal(coef[base:base + int(info.coef_count)], one), i
+        for c in range(info.ncomp):
+            assert j.coef_off[c] == base + info.coef_off[c] and j.plane_off[c] == plane_off
+            assert list(j.quant[c]) == list(info.quant[c])
+            plane_off += (info.blocks_w[c] * info.blocks_h[c] * 64 + 15) // 16 * 16
+        out_off += (info.height * info.width * 3 + 15) // 16 * 16
+    assert (pb.out_total, pb.plane_total) == (out_off, plane_off)
+    z = np.load(GOLDEN)
+    with pytest.raises(hip.OfbError):
+        hip.jpeg_plan_batch([blobs[0], z['progressive.jpg'].tobytes()])
