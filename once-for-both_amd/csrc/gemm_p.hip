@@ -58,10 +58,15 @@ struct Cfg {
   static constexpr int HR = (NST * STAGE >= BN * 132 * 4) ? 128 : 64;                 // rows of the tile parked in LDS per epilogue pass
   static constexpr int TROW = HR + 4, ITEMS = BN * (HR / 4) / NT;
   static_assert(A_PIECES % NW == 0 && MI % 2 == 0 && BM % HR == 0 && (32 * MI) <= HR && HR % (32 * MI) == 0, "piece / epilogue schedule");
-  static_assert(BN * TROW * 4 <= NST * STAGE && QA == 3 && QB <= 5 && NST >= 2 && NST <= 3, "LDS budget / schedule");
+  static_assert(BN * TROW * 4 <= NST * STAGE && QA >= 3 && QA <= 6 && QB <= 5 && NST >= 2 && NST <= 3, "LDS budget / schedule");
 };
 using C192 = Cfg<4, 2, 2, 3, 3, 1>;
 using C128 = Cfg<2, 2, 2, 3, 2, 2>;
+//   C96:  256 x 96, 4 waves stacked along M (the same 64 x 96 wave tile), two workgroups per CU, 2 stages: for output widths that pad
+//         badly on 192 columns (N mod 192 in (0, 96]: the pruned / finetune widths 264, 480, 672, ...).  A tile with dead wave
+//         columns costs nearly a whole tile's time (the K loop is paced by its stages and barriers), so 264 columns on 192-wide
+//         tiles run at 69 % column efficiency, on 96-wide tiles at 92 %.
+using C96 = Cfg<4, 1, 2, 3, 2, 2>;
 constexpr int GRAN = 384;
 constexpr int CS_SLAB_RG = 64;                      // row groups (256 rows) per column-sum slab
 
@@ -243,7 +248,7 @@ __device__ unsigned long long ofb_p_stamps[1024 * 8 * 4];
 #define OFB_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
 __device__ __forceinline__ void vm_wait(int n) {           // n is wave-uniform
   switch (n) {
-    OFB_VMW(0) OFB_VMW(5) OFB_VMW(6) OFB_VMW(7) OFB_VMW(8) OFB_VMW(10) OFB_VMW(12) OFB_VMW(14) OFB_VMW(16)
+    OFB_VMW(0) OFB_VMW(5) OFB_VMW(6) OFB_VMW(7) OFB_VMW(8) OFB_VMW(9) OFB_VMW(10) OFB_VMW(12) OFB_VMW(14) OFB_VMW(16) OFB_VMW(18)
     default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
   }
 }
@@ -461,8 +466,11 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
       // Item map: a thread keeps its lane's columns (lane + 64 c, c < BN/64) and walks the 4-row groups rg = w, w + NW, ..., so
       // the per-column inputs (bias, gate) are loaded once per tile; the side inputs of ALL items of a pass (residual or saved
       // pre-activation, DropPath row scales) are requested before any item is finished: one exposed memory latency per pass.
-      constexpr int NC = BN / 64, NRG = (HR / 4) / NW, ITEMS = NC * NRG;
-      static_assert(BN % 64 == 0 && (HR / 4) % NW == 0, "epilogue item map");
+      // PART: the tile width is not a multiple of 64 (C96): the last column chunk is half empty, its lanes >= BN sit out
+      constexpr int NC = (BN + 63) / 64, NRG = (HR / 4) / NW, ITEMS = NC * NRG;
+      constexpr bool PART = (BN % 64) != 0;
+      static_assert((HR / 4) % NW == 0, "epilogue item map");
+      const bool lane_in_last = !PART || lane + 64 * (NC - 1) < BN;
       constexpr bool ANY = (EPI & E_ANY) != 0;
       // which parts exist: known at compile time for the specialised forms, asked at run time by the generic form (E_ANY)
       const bool has_c = ANY ? g.C != nullptr : (EPI & E_C) != 0, has_p = ANY ? g.Cp != nullptr : (EPI & E_P) != 0;
@@ -506,6 +514,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
               const int lcol = lane + 64 * c;
+              if (PART && c == NC - 1 && !lane_in_last) continue;
               const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + lcol * TROW + 4 * rgl);
               float* __restrict__ ws = g.workspace + (size_t)cur.slot * (BM * BN) + (size_t)(HR * half + 4 * rgl) * BN + lcol;
 #pragma unroll
@@ -520,8 +529,8 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
             constexpr bool GD = decltype(GUARDED)::value;
             // two batches of row groups per pass: all side inputs of a batch are requested before any item of it is finished
             // (one exposed latency per batch); a whole pass in one batch needs > 100 registers for side inputs and spills
-            constexpr int KB = NRG / 2, BI = KB * NC;
-            static_assert(NRG % 2 == 0, "epilogue batches");
+            constexpr int KB = NRG > 4 ? NRG / 4 : NRG / 2, BI = KB * NC;
+            static_assert(NRG % 2 == 0 && NRG % KB == 0, "epilogue batches");
 #pragma unroll
             for (int k0 = 0; k0 < NRG; k0 += KB) {
               f32x4 side[BI], side2[BI], rsv[KB];
@@ -534,7 +543,8 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
                   rsv[kk][tt] = has_rs ? rowscale[g.rs_div == 1 ? rowc : rowc / g.rs_div] : 1.f;
 #pragma unroll
                   for (int c = 0; c < NC; ++c) {
-                    const int col = cur.n0 + lane + 64 * c, colc = (!GD || col < g.N) ? col : g.N - 1;
+                    // (a lane outside a PART tile's last chunk reads its neighbour tile's columns, clamped into the matrix: unused)
+                    const int col = cur.n0 + lane + 64 * c, colc = ((!GD && !PART) || col < g.N) ? col : g.N - 1;
                     side[kk * NC + c][tt] = (dg || mula) ? auxr[(size_t)rowc * g.ldaux + colc] : 0.f;
                     side2[kk * NC + c][tt] = has_res ? resid[(size_t)rowc * g.ldr + colc] : 0.f;
                   }
@@ -546,6 +556,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_p_kernel(const ofb_gemm_p_args
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
                   const int lcol = lane + 64 * c, col = cur.n0 + lcol;
+                  if (PART && c == NC - 1 && !lane_in_last) continue;
                   const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + lcol * TROW + 4 * rgl);
                   const bool colok = !GD || col < g.N;
                   float pv[4];
@@ -670,12 +681,28 @@ int p_cu_count() {
 
 // Tile configuration: C128 (two workgroups per CU) measured equal or faster than C192 on every product of the step (same-box
 // scripts/gemm_step_shapes_p.py); C192 is compiled only into lab builds (-DOFB_GEMM_P_LAB, OFB_GEMM_P_TILE=192).
-int p_tile_choice(const ofb_gemm_p_args&) {
-#ifdef OFB_GEMM_P_LAB
+int p_tile_choice(const ofb_gemm_p_args& g) {
   static int forced = -1;
   if (forced < 0) { const char* e = getenv("OFB_GEMM_P_TILE"); forced = e ? atoi(e) : 0; }
+#ifdef OFB_GEMM_P_LAB
   if (forced == 192) return 192;
 #endif
+  if (forced == 128) return 128;
+  // 96-wide tiles (C96) where they compute fewer padded columns than 192-wide ones: token-row products only (a_kc: the tall
+  // operand is A; the weight-gradient form has the ragged extent on its 128-row axis) and no per-tile column sums (laid out per
+  // 128-row tile row)
+  if (g.a_kc && !g.colpart && g.M >= 4 * C96::BM) {
+    const int c192 = ofb_cdiv(g.N, 192) * 192, c96 = ofb_cdiv(g.N, 96) * 96;
+    if (forced == 96) return 96;
+    if (c96 < c192) {
+      // measured on the configs[4] shapes (scripts/lab/time_ragged_gemm.py, M = 50432): fewer padded columns win 7-33 % (N = 264 at
+      // K >= 576, N = 480 / 672 at K = 264) EXCEPT when the 96-wide tiling ends in a small streamed tail of short K pieces
+      // (N = 264 at K = 192: 591 tiles = 1.15 rounds, 68 vs 52 us; N = 224 at K = 264): a tail below 0.3 rounds needs K >= 384
+      const double rounds = (double)ofb_cdiv(g.M, C96::BM) * (c96 / 96) / (double)(p_cu_count() * C96::WGS);
+      const double frac = rounds - (double)(long long)rounds;
+      if (!(frac > 0.0 && frac < 0.3 && g.K < 384)) return 96;
+    }
+  }
   return 128;
 }
 
@@ -840,6 +867,7 @@ extern "C" int64_t ofb_gemm_p_workspace_bytes(const ofb_gemm_p_args* args) {
 #ifdef OFB_GEMM_P_LAB
   if (p_tile_choice(*args) == 192) { const Plan p = plan_p<C192>(*args); return p.R ? (int64_t)2 * p.W * C192::BM * C192::BN * (int64_t)sizeof(float) : 0; }
 #endif
+  if (p_tile_choice(*args) == 96) { const Plan p = plan_p<C96>(*args); return p.R ? (int64_t)2 * p.W * C96::BM * C96::BN * (int64_t)sizeof(float) : 0; }
   const Plan p = plan_p<C128>(*args);
   return p.R ? (int64_t)2 * p.W * C128::BM * C128::BN * (int64_t)sizeof(float) : 0;
 }
@@ -870,10 +898,11 @@ extern "C" int ofb_gemm_p(const ofb_gemm_p_args* args, void* stream) {
   if (!ofb_aligned16(g.A) || !ofb_aligned16(g.B) || (g.Cp && !ofb_aligned16(g.Cp))) return OFB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   ofb_prof_pre(0, s, 2.0 * g.M * g.N * (double)g.K);
+  const int tile = p_tile_choice(g);
 #ifdef OFB_GEMM_P_LAB
-  const int rc = p_tile_choice(g) == 192 ? run_p<C192>(g, s) : run_p<C128>(g, s);
+  const int rc = tile == 192 ? run_p<C192>(g, s) : (tile == 96 ? run_p<C96>(g, s) : run_p<C128>(g, s));
 #else
-  const int rc = run_p<C128>(g, s);
+  const int rc = tile == 96 ? run_p<C96>(g, s) : run_p<C128>(g, s);
 #endif
   ofb_prof_post(0, s);
   return rc;

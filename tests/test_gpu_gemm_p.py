@@ -49,7 +49,11 @@ def test_pformat_with_column_sums():
 
 
 SHAPES = [(256, 256, 64), (394, 384, 384), (591, 1152, 384), (130, 70, 36), (128, 1000, 384), (77, 13, 5), (591, 264, 200),
-          (2600, 520, 48), (8192, 1024, 80)]
+          (2600, 520, 48), (8192, 1024, 80),
+          # widths that pad badly on 192 columns and M >= 1024: the 256 x 96 tile (C96) takes the token-row forms (kc,kc / kc,kr);
+          # the pruned / finetune widths of configs[4] (264, 480, 672, 160, 224, 576, 960) and odd ones
+          (1100, 264, 200), (2048, 480, 264), (1500, 96, 64), (1300, 672, 264), (1024, 100, 40), (5000, 224, 160), (1234, 77, 264),
+          (1027, 576, 264), (1500, 960, 264)]
 
 
 @pytest.mark.parametrize('M,N,K', SHAPES)
@@ -78,7 +82,7 @@ def test_gemm_p_modes_and_outputs(M, N, K):
     _close(y, exact.t() @ a.double(), 'P output as KR operand (zero padding)', tol=2e-5)
 
 
-@pytest.mark.parametrize('M,N,K', [(394, 384, 384), (300, 1536, 384), (130, 70, 36)])
+@pytest.mark.parametrize('M,N,K', [(394, 384, 384), (300, 1536, 384), (130, 70, 36), (1200, 264, 72), (1400, 480, 264), (2100, 672, 100)])
 def test_gemm_p_epilogues(M, N, K):
     from ofb_amd import hip
     x, w, b = _mk((M, K), 5), _mk((N, K), 6, 0.1), _mk((N,), 7)
