@@ -213,7 +213,6 @@ def main():
                     '(engine.GraphedStep); for launch-bound sizes (small batches); the sampled profile steps stay eager')
     ap.add_argument('--force-dp', action='store_true', help='exercise the DP bucket path even with one rank (debug)')
     args = ap.parse_args()
-    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')          # before the HIP runtime starts: see ofb_amd.hip.ensure_side_stream
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:     # bare `python bench.py --gpus N`: become the launcher
         raise SystemExit(self_launch(args.gpus))

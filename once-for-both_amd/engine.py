@@ -62,9 +62,9 @@ class GraphedStep:
     collectives are stream-ordered kernels; every rank captures and replays the same sequence) - the launch-bound sizes keep the
     graph's gain when a second rank exists.  Not across compress() (shapes and buckets change: capture again)."""
 
-    def __init__(self, fn, optimizers, reducer=None):
+    def __init__(self, fn, optimizers, reducer=None, side_stream=False):
         self.fn, self.opts = fn, [o for o in optimizers if o is not None]
-        self.reducer = reducer
+        self.reducer, self.side_stream = reducer, side_stream
         self.graph, self.out, self.k, self._keep = None, None, 0, None
 
     def capture(self, warm_steps=2):
@@ -80,6 +80,19 @@ class GraphedStep:
             raise RuntimeError('GraphedStep: build the model and run the step on a non-default stream '
                                '(torch.cuda.set_stream(torch.cuda.Stream()) before creating it)')
         self.stream = cur
+        # The captured step is a SINGLE-stream chain unless side_stream=True was asked for: how the runtime places a graph's parallel
+        # branches on hardware queues depends on which streams exist in the process (queues x priorities x RCCL: scripts/lab/
+        # queue_matrix.sh) - the same bs-128 capture replays in 25.9 or 37.3 ms - and the sizes graphs are for (launch-bound: few
+        # tokens) do not use the side stream anyway (ops._side_ok).  One stream: 25.7 ms at bs 128, always.
+        side_was = hip.SIDE_STREAM
+        hip.SIDE_STREAM = side_was and self.side_stream
+        try:
+            self._capture(warm_steps)
+        finally:
+            hip.SIDE_STREAM = side_was
+
+    def _capture(self, warm_steps):
+        from . import hip
         for _ in range(warm_steps):
             self.out = self.fn()
         hip.join_side()

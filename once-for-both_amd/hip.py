@@ -210,22 +210,25 @@ SIDE_STREAM = os.environ.get('OFB_SIDE_STREAM', '1') != '0'
 _side_streams, _side_keep, _side_dirty = {}, [], [False]
 
 
-def ensure_side_stream(device):
-    """Creates the side stream of `device` (idempotent).  Call it BEFORE torch.distributed / RCCL is initialised in the process: HIP
-    maps streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) in creation order, and with RCCL's own streams created first the
-    side stream can land on the main stream's hardware queue - the two then run one after the other and the weight-gradient overlap
-    is lost (measured at one rank: 26.1 instead of 24.9 ms per step).  Three guards: the stream is created at high priority (below),
-    bench.py and the DP tests create it right after set_device(), and ofb_amd/__init__.py raises GPU_MAX_HW_QUEUES to 8 when the
-    variable is unset and HIP is not initialised yet."""
+def ensure_side_stream(device, priority=None):
+    """Creates the side stream of `device` (idempotent; `priority` given: replaces it, after joining the old one).
+    HIP maps streams onto its hardware queues (GPU_MAX_HW_QUEUES, default 4) in creation order: with RCCL's own streams created first a
+    normal-priority side stream lands on the main stream's hardware queue - the two then run one after the other and the
+    weight-gradient overlap is lost (one rank, DeiT-S bs 128: 27.0 instead of 25.0 ms per step).  A HIGH-priority stream has a queue
+    of its own whatever was created before it (25.4 ms with RCCL, 25.0 without), so that is the default for eager steps.  Inside a
+    captured hipGraph the placement of parallel branches is a lottery (a high-priority branch, GPU_MAX_HW_QUEUES = 8 or merely other
+    streams in the process make the replay of the bs-128 step 37 instead of 26 ms): engine.GraphedStep captures single-stream
+    (scripts/lab/queue_matrix.sh has the table: queues x priority x eager / graph x plain / one-rank RCCL)."""
     device = torch.device(device)
     if device.index is None:
         device = torch.device('cuda', torch.cuda.current_device())
     side = _side_streams.get(device)
-    if side is None:
-        # a HIGH-priority stream: priority classes have hardware queues of their own, so the side stream never shares the main
-        # stream's queue, whatever else (RCCL, a data loader) created streams first: measured with RCCL initialised first and the
-        # default 4 queues: 26.1 ms per step at normal priority (no overlap left), 24.9 at high priority = the run without RCCL
-        side = _side_streams[device] = torch.cuda.Stream(device=device, priority=int(os.environ.get('OFB_SIDE_PRIORITY', '-1')))
+    if side is None or priority is not None:
+        if side is not None:
+            join_side()
+            torch.cuda.current_stream(device).wait_stream(side)
+        pr = int(os.environ.get('OFB_SIDE_PRIORITY', '-1')) if priority is None else int(priority)
+        side = _side_streams[device] = torch.cuda.Stream(device=device, priority=pr)
     return side
 
 
