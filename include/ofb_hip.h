@@ -152,10 +152,11 @@ int ofb_colsum_multi(const ofb_colsum_job* jobs_dev, int32_t n_jobs, int32_t max
  * conv out *= g: :191).  out = g[n] * W[n][:]; and the matching backward: from the UNGATED raw gradients
  * dWraw = dY^T x, dbraw = colsum(dY): dW = g*dWraw, db = g*dbraw, dg[n] = <dWraw[n], W[n]> + dbraw[n]*b[n].
  * dbraw: [dbraw_rows][N]; with dbraw_rows > 1 the rows are partial column sums (per image from the attention backward, per
- * tile from a GEMM epilogue) that this kernel adds up itself. */
+ * tile from a GEMM epilogue) that this kernel adds up itself.  fold > 1: ONE gate vector of N / fold values serves `fold` row
+ * groups (q | k | v, layers.py:507-509): g holds the tiled N values, dg receives the N / fold sums over the groups. */
 int ofb_scale_rows(const float* W, const float* g, float* out, int32_t N, int32_t K, void* stream);
 int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const float* dbraw, int32_t dbraw_rows, const float* b,
-                      float* dW, float* db, float* dg, int32_t N, int32_t K, void* stream);
+                      float* dW, float* db, float* dg, int32_t N, int32_t K, int32_t fold, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Attention core softmax(q k^T * scale) v with probabilities kept on chip

@@ -415,28 +415,35 @@ __global__ __launch_bounds__(256) void gate_fold_bwd_kernel(const float* __restr
                                                             const float* __restrict__ g, const float* __restrict__ dbraw,
                                                             const float* __restrict__ b, float* __restrict__ dW,
                                                             float* __restrict__ db, float* __restrict__ dg, int N, int K,
-                                                            int dbraw_rows) {
-  const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (n >= N) return;
-  const float gn = g[n];
-  // dbraw may arrive as dbraw_rows partial rows [rows][N] (per-image / per-tile column sums straight from the producing kernel):
-  // they are added here (lane r, r + 64, ... in order, then the fixed wave tree) instead of by a reduction launch of their own
-  float dbr = 0.f;
-  if (dbraw) {
-    for (int r = lane; r < dbraw_rows; r += 64) dbr += dbraw[(size_t)r * N + n];
-    dbr = dbraw_rows > 1 ? ofb_wave_sum(dbr) : __shfl(dbr, 0, 64);
+                                                            int dbraw_rows, int fold) {
+  // fold > 1: the gate vector is N / fold values applied to `fold` row groups (q | k | v share one gate, layers.py:507-509): g holds the
+  // tiled N values, dg the N / fold sums over the groups (added in group order) - no separate 3-way sum launch
+  const int lane = threadIdx.x & 63, j = blockIdx.x * 4 + (threadIdx.x >> 6), Nf = N / fold;
+  if (j >= Nf) return;
+  float tot = 0.f;
+  for (int f = 0; f < fold; ++f) {
+    const int n = j + f * Nf;
+    const float gn = g[n];
+    // dbraw may arrive as dbraw_rows partial rows [rows][N] (per-image / per-tile column sums straight from the producing kernel):
+    // they are added here (lane r, r + 64, ... in order, then the fixed wave tree) instead of by a reduction launch of their own
+    float dbr = 0.f;
+    if (dbraw) {
+      for (int r = lane; r < dbraw_rows; r += 64) dbr += dbraw[(size_t)r * N + n];
+      dbr = dbraw_rows > 1 ? ofb_wave_sum(dbr) : __shfl(dbr, 0, 64);
+    }
+    float s = 0.f;
+    for (int k = lane; k < K; k += 64) {
+      const float d = dWraw[(size_t)n * K + k];
+      s += d * W[(size_t)n * K + k];
+      dW[(size_t)n * K + k] = d * gn;
+    }
+    s = ofb_wave_sum(s);
+    if (lane == 0) {
+      tot += s + (b ? dbr * b[n] : 0.f);
+      if (db) db[n] = dbr * gn;
+    }
   }
-  float s = 0.f;
-  for (int k = lane; k < K; k += 64) {
-    const float d = dWraw[(size_t)n * K + k];
-    s += d * W[(size_t)n * K + k];
-    dW[(size_t)n * K + k] = d * gn;
-  }
-  s = ofb_wave_sum(s);
-  if (lane == 0) {
-    dg[n] = s + (b ? dbr * b[n] : 0.f);
-    if (db) db[n] = dbr * gn;
-  }
+  if (lane == 0) dg[j] = tot;
 }
 
 }  // namespace
@@ -559,10 +566,10 @@ extern "C" int ofb_scale_rows(const float* W, const float* g, float* out, int32_
 }
 
 extern "C" int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const float* dbraw, int32_t dbraw_rows,
-                                 const float* b, float* dW, float* db, float* dg, int32_t N, int32_t K, void* stream) {
-  if (!dWraw || !W || !g || !dW || !dg || N <= 0 || K <= 0 || (dbraw && dbraw_rows <= 0)) return OFB_EINVAL;
-  hipLaunchKernelGGL(gate_fold_bwd_kernel, dim3(ofb_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, dWraw, W, g, dbraw, b,
-                     dW, db, dg, N, K, dbraw_rows);
+                                 const float* b, float* dW, float* db, float* dg, int32_t N, int32_t K, int32_t fold, void* stream) {
+  if (!dWraw || !W || !g || !dW || !dg || N <= 0 || K <= 0 || (dbraw && dbraw_rows <= 0) || fold <= 0 || N % fold) return OFB_EINVAL;
+  hipLaunchKernelGGL(gate_fold_bwd_kernel, dim3(ofb_cdiv(N / fold, 4)), dim3(256), 0, (hipStream_t)stream, dWraw, W, g, dbraw, b,
+                     dW, db, dg, N, K, dbraw_rows, fold);
   return ofb_launch_status();
 }
 

@@ -582,12 +582,15 @@ def scale_rows(W, g, out, N, K):
     check(lib().ofb_scale_rows(ptr(W), ptr(g), ptr(out), _i(N), _i(K), stream()), 'ofb_scale_rows')
 
 
-def gate_fold_bwd(dWraw, W, g, dbraw, b, dW, db, dg, N, K, dbraw_rows=1):
-    """dbraw: [dbraw_rows][N]; rows > 1: partial column sums (per image / per tile) that the kernel adds up itself"""
+def gate_fold_bwd(dWraw, W, g, dbraw, b, dW, db, dg, N, K, dbraw_rows=1, fold=1):
+    """dbraw: [dbraw_rows][N]; rows > 1: partial column sums (per image / per tile) that the kernel adds up itself.
+    fold > 1: g is one gate of N / fold values tiled `fold` times (q | k | v); dg gets the N / fold sums over the groups"""
     if dbraw is not None and dbraw.numel() < dbraw_rows * N:
         raise OfbError('gate_fold_bwd: dbraw must hold dbraw_rows * N floats')
+    if N % fold or dg.numel() < N // fold:
+        raise OfbError('gate_fold_bwd: dg must hold N / fold floats')
     check(lib().ofb_gate_fold_bwd(ptr(dWraw), ptr(W), ptr(g), ptr(dbraw), _i(dbraw_rows), ptr(b), ptr(dW), ptr(db), ptr(dg), _i(N),
-                                  _i(K), stream()), 'ofb_gate_fold_bwd')
+                                  _i(K), _i(fold), stream()), 'ofb_gate_fold_bwd')
 
 
 def _check_lse(lse, B, N, H):

@@ -108,7 +108,7 @@ class _nullctx:
     def __exit__(self, *a): return False
 
 
-def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None):
+def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None, fold=1):
     """P-format backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None): dx (+resid fused), dW, db, dg.
     WP: the forward's P-format copy of W; dy_colsum: callable giving colsum(dY) (the raw bias gradient) as a vector [N] or as
     (partials [rows][N], rows) straight from the producing kernel - the gate-fold kernel adds partial rows up itself."""
@@ -130,10 +130,10 @@ def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None):
         if isinstance(dbraw, tuple):
             dbraw, rows = dbraw
     dW = slot if slot is not None else _new(W, N, K)
-    db, dg, dWraw = (_new(W, N) if b is not None else None), _new(W, N), _new(W, N, K)
+    db, dg, dWraw = (_new(W, N) if b is not None else None), _new(W, N // fold), _new(W, N, K)   # fold: see hip.gate_fold_bwd
     with (hip.side_work(W.device, keep=[dyP.buf, xP.buf, dWraw, dbraw, gvec]) if side else _nullctx()):
         p_linear_bwd_weight(dyP, xP, M, N, K, out=dWraw)
-        hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K, dbraw_rows=rows)
+        hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K, dbraw_rows=rows, fold=fold)
     return dx, dW, db, dg
 
 
@@ -306,7 +306,7 @@ class AttnBranch(torch.autograd.Function):
     gate gradient and the join in BiMaskGates.backward (a race)."""
 
     @staticmethod
-    def forward(ctx, x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale):
+    def forward(ctx, x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale, g3_pre=None):
         x = _c(x)
         B, N, D = x.shape
         M = B * N
@@ -320,7 +320,12 @@ class AttnBranch(torch.autograd.Function):
                 if g.dim() != 2 or gshape[0] not in (1, heads) or gshape[1] not in (1, dh):
                     raise hip.OfbError(f'attention gate of shape {gshape} does not broadcast to ({heads}, {dh})')
                 g = g.expand(heads, dh)
-            g3 = g.reshape(-1).repeat(3).contiguous()
+            # the q | k | v tiling of the gate: handed in by the model for all blocks at once (vision_transformer._compute_gates,
+            # two launches per forward instead of one per block) or made here
+            if g3_pre is not None and g3_pre.numel() == 3 * Hd and g3_pre.is_contiguous() and g.numel() == Hd:
+                g3 = g3_pre
+            else:
+                g3 = g.reshape(-1).repeat(3).contiguous()
         r2d = x2d if resid is None else _c(resid).view(M, D)
         xP, wqP, wpP = _P(x, M, D), hip.weight_p(wqkv), hip.weight_p(wproj)
         ctx.wp = (wqP, wpP)
@@ -370,22 +375,23 @@ class AttnBranch(torch.autograd.Function):
             dqkv = torch.empty_like(qkv)
             hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
             dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw)
-        dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None)
+        # fold = 3: the gate-fold kernel adds the q | k | v contributions to the gate gradient itself
+        dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None, fold=3)
         dg = None
         if dg3 is not None:
-            # dg3 may still be in flight on the side stream: the 3-way sum and the reduction to the module's gate shape run there
-            # too; the consumer (BiMaskGates.backward) joins the side stream before it reads any gate gradient
-            with (hip.side_work(d2.device, keep=[dg3]) if hip._side_dirty[0] else _nullctx()):
-                dg = dg3.view(3, heads, dh).sum(0)
-                if gshape != (heads, dh):
+            dg = dg3.view(heads, dh)
+            if gshape != (heads, dh):
+                # head-only / channel-only spaces: dg3 may still be in flight on the side stream, so the reduction to the module's gate
+                # shape runs there too; the consumer (BiMaskGates.backward) joins the side stream before it reads any gate gradient
+                with (hip.side_work(d2.device, keep=[dg3]) if hip._side_dirty[0] else _nullctx()):
                     if gshape[0] == 1:
                         dg = dg.sum(0, keepdim=True)
                     if gshape[1] == 1:
                         dg = dg.sum(1, keepdim=True)
-                if hip._side_dirty[0]:
-                    hip._side_keep.append(dg)
+                    if hip._side_dirty[0]:
+                        hip._side_keep.append(dg)
         dres = None if self_resid else dout
-        return dx.view(B, N, D), dres, dwq, dbq, dwp, dbp, dg, None, None, None
+        return dx.view(B, N, D), dres, dwq, dbq, dwp, dbp, dg, None, None, None, None
 
 
 class MlpBranch(torch.autograd.Function):
@@ -448,7 +454,7 @@ class MlpBranch(torch.autograd.Function):
 
 
 def attn_branch(x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale):
-    out = AttnBranch.apply(x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale)
+    out = AttnBranch.apply(x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale, getattr(g, '_ofb_g3', None))
     out._ofb_up = (rowscale,)                                # for the LayerNorm that reads this output (see LayerNorm)
     return out
 

@@ -308,6 +308,14 @@ class MIMVisionTransformer(MAEBaseModel):
         n = len(live)
         for i, m in enumerate(live):
             m._set_gate_outputs(outs[i], outs[n + i], outs[2 * n + i])
+        # q | k | v share an attention module's gate (layers.py:507-509): the tiled copies the qkv GEMM's column scale needs are made
+        # for ALL blocks here (stack + one expanding copy) instead of one repeat launch per block; each gate carries its row along
+        att = [m for m in live if hasattr(m, 'num_heads') and m._g.dim() == 2 and m._g.shape == (m.num_heads, m.head_dim)]
+        if len(att) > 1 and len({m._g.numel() for m in att}) == 1:
+            hd = att[0]._g.numel()
+            g3_all = torch.stack([m._g.detach().reshape(-1) for m in att]).unsqueeze(1).expand(-1, 3, -1).reshape(len(att), 3 * hd)
+            for i, m in enumerate(att):
+                m._g._ofb_g3 = g3_all[i]
         wsum = outs[3 * n]
         scales = [m.wsum_scale() if hasattr(m, 'wsum_scale') else 1.0 for m in live]
         if any(sc != 1.0 for sc in scales):                   # head-only / channel-only attention: the FLOPs model sums the broadcast staircase

@@ -117,4 +117,12 @@ def test_gate_fold(N, K):
     hip.gate_fold_bwd(dWraw.cuda(), W.cuda(), g.cuda(), dbraw.cuda(), b.cuda(), dW, db, dg, N, K)
     _close(dW, dWraw.double() * g.double().unsqueeze(1), 1e-6, 'fold dW')
     _close(db, dbraw.double() * g.double(), 1e-6, 'fold db')
-    _close(dg, (dWraw.double() * W.double()).sum(1) + dbraw.double() * b.double(), 1e-5, 'fold dg')
+    full = (dWraw.double() * W.double()).sum(1) + dbraw.double() * b.double()
+    _close(dg, full, 1e-5, 'fold dg')
+    if N % 3 == 0:                                         # q | k | v share one gate: g tiled three times, dg summed over the three groups
+        g3 = g[:N // 3].repeat(3)
+        dW3, db3, dg3 = torch.empty(N, K, device='cuda'), torch.empty(N, device='cuda'), torch.empty(N // 3, device='cuda')
+        hip.gate_fold_bwd(dWraw.cuda(), W.cuda(), g3.cuda(), dbraw.cuda(), b.cuda(), dW3, db3, dg3, N, K, fold=3)
+        _close(dW3, dWraw.double() * g3.double().unsqueeze(1), 1e-6, 'fold dW (tiled gate)')
+        _close(db3, dbraw.double() * g3.double(), 1e-6, 'fold db (tiled gate)')
+        _close(dg3, full.view(3, N // 3).sum(0), 1e-5, 'fold dg summed over q | k | v')
