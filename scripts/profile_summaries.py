@@ -61,6 +61,29 @@ f = newest('stats_sideoff/**/*kernel_stats.csv')
 shutil.copy(f, os.path.join(S, f'{tag}_kernel_stats_sidestream_off.csv'))
 print('\n'.join(kernel_summary(f, 12, f'{tag}_kernel_summary_sidestream_off.txt', ', OFB_SIDE_STREAM=0 (kernels serialised: per-kernel times add up)')[:12]))
 
+# ---- steady state: difference of the 20-step and the 12-step side-off runs, per kernel family -------------------------------
+_long = glob.glob(os.path.join(O, 'stats_sideoff_long/**/*kernel_stats.csv'), recursive=True)
+f2 = max(_long, key=os.path.getmtime) if _long else None
+if f2:
+    def fams(path):
+        out = {}
+        for r in csv.DictReader(open(path)):
+            a = out.setdefault(family(r['Name']), [0, 0.0])
+            a[0] += int(r['Calls']); a[1] += float(r['TotalDurationNs'])
+        return out
+    fa, fb, ds = fams(f), fams(f2), 8
+    diff = {k: (fb[k][0] - fa.get(k, [0, 0.0])[0], fb[k][1] - fa.get(k, [0, 0.0])[1]) for k in fb}
+    lines = [f'# {tag}: STEADY-STATE step = (20-step run - 12-step run) / 8 of rocprofv3 --kernel-trace --stats, OFB_SIDE_STREAM=0: model construction, '
+             'optimizer-state allocation (2 fills per parameter) and first-step work cancel out',
+             f'kernel time {sum(t for _, t in diff.values()) / 1e6 / ds:.2f} ms/step, {sum(c for c, _ in diff.values()) / ds:.0f} launches/step']
+    g = [v for k, v in diff.items() if k.startswith('gemm_p')]
+    lines.append(f'{"gemm_p (all)":60s} {sum(v[0] for v in g) / ds:7.1f}/step {sum(v[1] for v in g) / 1e6 / ds:8.3f} ms/step')
+    for k, (c, t) in sorted(diff.items(), key=lambda kv: -kv[1][1])[:32]:
+        if c > 0:
+            lines.append(f'{k[:60]:60s} {c / ds:7.1f}/step {t / 1e6 / ds:8.3f} ms/step  avg {t / c / 1e3:8.1f} us')
+    open(os.path.join(S, f'{tag}_kernel_summary_steady_state.txt'), 'w').write('\n'.join(lines) + '\n')
+    print('\n'.join(lines[:12]))
+
 # ---- HBM-side traffic: FETCH_SIZE x2 (gfx950 reports half of a wide coalesced stream, MI355X_MICROARCH.md) + WRITE_SIZE ----
 steps_pmc = 9
 out = {}

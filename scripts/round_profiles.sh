@@ -18,6 +18,10 @@ echo "stats (default command) done"
 export OFB_SIDE_STREAM=0      # one stream: per-kernel durations / counters are attributable
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sideoff -- python3 $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-prof > $O/stats_sideoff.log 2>&1 || exit 1
 echo "stats (side stream off) done"
+# the same with 8 more timed steps: the difference of the two runs is the STEADY-STATE step (model construction, optimizer-state
+# allocation and the first-step work cancel out)
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_sideoff_long -- python3 $R/bench.py --steps 12 --warmup 2 --no-cpu-baseline --no-prof > $O/stats_sideoff_long.log 2>&1 || exit 1
+echo "stats (side stream off, 8 more steps) done"
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_$c -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-prof > $O/pmc_$c.log 2>&1 || exit 1
   echo "pmc $c done"
