@@ -51,15 +51,35 @@ __global__ __launch_bounds__(256) void gates_fwd_kernel(const ofb_gate_desc* __r
   __syncthreads();
 
   const int e = blockIdx.x * 256 + t;
+  // the score rows this block's 256 elements belong to, staged in LDS when they fit (MLP: one row of 1536; attention: four rows of
+  // 64): the rank of an element is a count over its whole row, and 1536 dependent global loads per thread made this launch 94 us
+  __shared__ float srow[2048];
+  const int e0 = blockIdx.x * 256, e1 = min(e0 + 256, HC) - 1;
+  const int h0 = e0 / d.C, nrows = e1 / d.C - h0 + 1;
+  const bool staged = nrows * d.C <= 2048;
+  if (staged)
+    for (int i = t; i < nrows * d.C; i += 256) srow[i] = d.score[h0 * d.C + i];
+  __syncthreads();
   float sg = 0.f;
   if (e < HC) {
     const int h = e / d.C, c = e % d.C;
     const float sc = d.score[e];
-    const float* row = d.score + h * d.C;
     int rc = 0;
-    for (int k = 0; k < d.C; ++k) {
-      const float o = row[k];
-      rc += (o > sc) || (o == sc && k < c);
+    if (staged) {
+      const float* row = srow + (h - h0) * d.C;
+      int k = 0;
+      for (; k + 4 <= d.C; k += 4) {
+        const float o0 = row[k], o1 = row[k + 1], o2 = row[k + 2], o3 = row[k + 3];
+        rc += ((o0 > sc) || (o0 == sc && k < c)) + ((o1 > sc) || (o1 == sc && k + 1 < c)) + ((o2 > sc) || (o2 == sc && k + 2 < c)) +
+              ((o3 > sc) || (o3 == sc && k + 3 < c));
+      }
+      for (; k < d.C; ++k) rc += (row[k] > sc) || (row[k] == sc && k < c);
+    } else {
+      const float* row = d.score + h * d.C;
+      for (int k = 0; k < d.C; ++k) {
+        const float o = row[k];
+        rc += (o > sc) || (o == sc && k < c);
+      }
     }
     const int rh = rank_h[h];
     float wm = 0.f, wr = 0.f;
@@ -160,9 +180,11 @@ __global__ __launch_bounds__(256) void gates_bwd_kernel(const ofb_gate_desc* __r
 // Sums per-module sparsity losses by kind (0 attn, 1 mlp, 2 embed): out[kind] (base_model.py:80-85).
 __global__ void spars_finalize_kernel(const ofb_gate_desc* __restrict__ descs, int n, int norm, float* __restrict__ out,
                                       float* __restrict__ per_module) {
-  if (threadIdx.x != 0) return;
-  float acc[3] = {0.f, 0.f, 0.f};
-  for (int m = 0; m < n; ++m) {
+  // one thread per module (their loads run side by side: a single thread walking 25 modules took 35 us of dependent round trips),
+  // then thread 0 adds the per-module values by kind in module order (the same order as before: deterministic, same rounding)
+  __shared__ float lm[256];
+  __shared__ int km[256];
+  for (int m = threadIdx.x; m < n; m += blockDim.x) {
     const ofb_gate_desc& d = descs[m];
     int on = 0;
     for (int k = 0; k < d.A0 * d.A1; ++k) on += d.on[k];
@@ -177,7 +199,15 @@ __global__ void spars_finalize_kernel(const ofb_gate_desc* __restrict__ descs, i
       }
     }
     per_module[m] = l;
-    acc[d.kind] += l;
+    if (m < 256) { lm[m] = l; km[m] = d.kind; }
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int m = 0; m < n; ++m) {
+    const float l = m < 256 ? lm[m] : per_module[m];
+    const int kind = m < 256 ? km[m] : descs[m].kind;
+    acc[kind] += l;
   }
   out[0] = acc[0]; out[1] = acc[1]; out[2] = acc[2];
 }
