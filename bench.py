@@ -230,6 +230,10 @@ def main():
         raise SystemExit(rehearsal(args, rank, world, real_stdout))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the once-for-both_amd hot path has no CPU fallback')
+    # the step's host side is one Python thread; ATen's intra-op pool defaults to every core of the node (x N ranks), and a parallel
+    # CPU op above its grain size wakes all of them to spin (on a CPU-quota cgroup that throttled the whole process: DESIGN section 0,
+    # JPEG row).  The CPU baseline sets its own thread count.
+    torch.set_num_threads(max(1, min(torch.get_num_threads(), 16)))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     import ofb_amd
