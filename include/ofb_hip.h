@@ -100,6 +100,52 @@ int ofb_colsum_p(const void* P, int32_t R, int32_t C, float* partial, void* stre
 int64_t ofb_gemm_p_workspace_bytes(const ofb_gemm_p_args* args);
 int ofb_gemm_p(const ofb_gemm_p_args* args, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Round 4 engine: the same contraction on operands split into TWO f16 planes of a power-of-two scaled copy ("H-format",
+ * csrc/hformat.h, csrc/gemm_h.hip): X 2^e = h1 + h2, three v_mfma_f32_32x32x16_f16 terms per product (h2 h1, h1 h2, h1 h1), f32
+ * accumulation.  Per-product error <= 3 2^-24; half the matrix-pipe work and two thirds of the operand bytes of the six-term bf16
+ * form.  A buffer = [256-B header {int32 e; f32 amax, rn2sq, cn2sq}][granules of 4 rows x 16 columns, 256 B: [h1 | h2][c % 16][r % 4]
+ * f16]; the header is written and read on the DEVICE only (the exponent of a tensor follows from data the host never sees).
+ * Same modes, epilogues, outputs and stream-K scheduling as ofb_gemm_p.  An H-format OUTPUT needs its exponent before the first
+ * tile is finished: a one-block pre-kernel bounds |output| by Cauchy-Schwarz from the operand headers and the epilogue inputs
+ * (bias, colscale, rowscale are scanned; aux_bound bounds |aux| of the multiplying activations, default 1.13 = max gelu');
+ * out_bound (device scalar) overrides that bound; with resid it is required.  cbound_out (optional, device scalar) receives the
+ * bound of an f32 output for the consumer that will split it (attention).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct ofb_gemm_h_args {
+  const void* A; const void* B;
+  int32_t a_kc, b_kc;
+  int32_t a_ncb, b_ncb;
+  int32_t M, N, K;
+  float* C; int32_t ldc;
+  void* Cp; int32_t c_ncb;
+  float alpha;
+  const float* bias;
+  const float* colscale;
+  const float* rowscale; int32_t rs_div;
+  const float* resid; int32_t ldr;
+  float* aux; int32_t ldaux;
+  int32_t act;
+  float* workspace; int64_t workspace_bytes;
+  float* colpart;
+  float aux_bound;
+  const float* out_bound;
+  float* cbound_out;
+} ofb_gemm_h_args;
+int32_t ofb_gemm_h_colpart_rows(const ofb_gemm_h_args* args);
+int64_t ofb_hformat_bytes(int32_t R, int32_t C);
+int ofb_to_hformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div, void* stream);
+int ofb_patchify_hformat(const float* img, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* P, void* stream);
+/* scratch: n_jobs * 64 floats (two-stage maxima of every job) */
+int ofb_to_hformat_multi(const ofb_pformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, float* scratch, void* stream);
+int ofb_to_hformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
+                          float* partial, void* stream);
+int ofb_from_hformat(const void* P, int32_t R, int32_t C, float* X, int32_t ld, void* stream);   /* (h1 + h2) 2^-e */
+int32_t ofb_colsum_h_slabs(int32_t R);
+int ofb_colsum_h(const void* P, int32_t R, int32_t C, float* partial, void* stream);
+int64_t ofb_gemm_h_workspace_bytes(const ofb_gemm_h_args* args);
+int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream);
+
 /* out[i] = sum_s workspace[s*count + i] (+ out[i] if accumulate): sums per-chunk partial buffers (embed assembly) */
 int ofb_splitk_reduce(const float* workspace, int32_t splits, int64_t count, float* out, int32_t accumulate,
                       void* stream);

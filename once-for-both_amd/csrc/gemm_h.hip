@@ -1,0 +1,1008 @@
+// f32-class GEMM on operands that are ALREADY split into two f16 planes ("H-format", hformat.h), staged by LDS-DMA.
+//
+// Why two f16 planes: the step runs at the package power cap, so its time is its energy.  Round 1-3 computed every f32
+// product as SIX v_mfma_f32_32x32x16_bf16 terms of an exact three-way bf16 split; a two-way f16 split of a power-of-two scaled copy
+// carries 22-24 significand bits in TWO planes and needs THREE terms (h2 h1, h1 h2, h1 h1; the dropped h2 h2 is <= 2^-24 of the
+// product): half the matrix-pipe work and two thirds of the operand bytes per product, at a per-product error of <= 3 2^-24 with the
+// accumulation still in f32 (measured against fp64: at or below a k-ordered f32 fma chain, tests/test_gpu_accuracy_class.py).
+// f16 has 5 exponent bits, so every tensor carries ONE power-of-two exponent e in its header (hformat.h); the kernel folds
+// 2^-(ea + eb) into alpha.
+//
+// Kernel (product configuration C128): 128 x 192 tile, 4 waves (2 x 2), wave tile 64 x 96 = 2 x 3 blocks of
+// v_mfma_f32_32x32x16_f16, LDS stages of K = 32 (two K16 sub-steps: 36 MFMAs per wave and stage), TWO workgroups per CU, two 40-KB
+// stages (all 160 KB of the CU's LDS) filled by global_load_lds_dwordx4 (inline asm, counted by hand), ONE barrier per stage placed
+// between the two halves of its second sub-step, the fragment reads of the next half-step issued in the MFMA gaps of the current
+// one; epilogue through LDS with compile-time forms.  Scheduling is the hybrid stream-K of gemm_plan.h.
+#include "hformat.h"
+#include "gemm_plan.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace {
+
+using ofb_plan::Plan; using ofb_plan::make_plan; using ofb_plan::tile_coord; using ofb_plan::Seg; using ofb_plan::get_seg;
+
+typedef short hs16x4 __attribute__((ext_vector_type(4)));
+typedef short hs16x8 __attribute__((ext_vector_type(8)));
+#define OFB_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
+
+#ifndef OFB_H_NTERM
+#define OFB_H_NTERM 3               /* 4: also h2 h2 (lab: accuracy comparison) */
+#endif
+
+// Tile configuration: WM x WN waves, wave tile (32 MI) x (32 NI), NST LDS stages of KH K16 sub-steps, WGS workgroups per CU.
+template <int WM_, int WN_, int MI_, int NI_, int NST_, int KH_, int WGS_>
+struct Cfg {
+  static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, NST = NST_, KH = KH_, WGS = WGS_, NW = WM * WN;
+  static constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NT = 64 * NW;
+  static constexpr int A_BYTES = BM * 64 * KH, B_BYTES = BN * 64 * KH, STAGE = A_BYTES + B_BYTES;
+  static constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;          // 1-KB LDS-DMA pieces per stage
+  static constexpr int QA = A_PIECES / NW, QB = (B_PIECES + NW - 1) / NW;             // pieces per wave (the last B piece only for some waves)
+  static constexpr int HA = MI / 2;                                                   // row blocks per half step
+  static constexpr int HR = (NST * STAGE >= BN * 132 * 4) ? 128 : 64;                 // rows of the tile parked in LDS per epilogue pass
+  static constexpr int TROW = HR + 4;
+  static_assert(A_PIECES % NW == 0 && MI % 2 == 0 && BM % HR == 0 && (32 * MI) <= HR && HR % (32 * MI) == 0, "piece / epilogue schedule");
+  static_assert(BN * TROW * 4 <= NST * STAGE && QA >= 1 && QA <= 8 && QB <= 8 && NST >= 2 && NST <= 3 && KH >= 1 && KH <= 2, "LDS budget / schedule");
+  static_assert(NST * STAGE * WGS <= 163840, "LDS per CU");
+};
+using C128 = Cfg<2, 2, 2, 3, 2, 2, 2>;
+//   C96: 256 x 96, 4 waves stacked along M (the same 64 x 96 wave tile): output widths that pad badly on 192 columns (N mod 192 in
+//        (0, 96]: the pruned / finetune widths 264, 480, 672, ...)
+using C96 = Cfg<4, 1, 2, 3, 3, 1, 2>;     // K16 stages: two K32 stages of a 256 x 96 tile x two workgroups do not fit the LDS
+#ifdef OFB_GEMM_H_LAB
+using C128K1 = Cfg<2, 2, 2, 3, 3, 1, 2>;          // lab: K16 stages, three of them
+#endif
+constexpr int GRAN = OFB_HGRAN;
+constexpr int CS_SLAB_RG = 64;                      // row groups (256 rows) per column-sum slab
+
+__device__ __forceinline__ void store_h4(char* slot, float v0, float v1, float v2, float v3) {
+  unsigned a0, b0, a1, b1;
+  ofb_hsplit_pair(v0, v1, a0, b0);
+  ofb_hsplit_pair(v2, v3, a1, b1);
+  *reinterpret_cast<uint2*>(slot) = make_uint2(a0, a1);
+  *reinterpret_cast<uint2*>(slot + 128) = make_uint2(b0, b1);
+}
+
+// ---- statistics + conversion f32 <-> H-format ---------------------------------------------------------------------
+// value = X * rowscale[r / rs_div] (optional).  Stage 1: hdr.amax = max|value|, hdr.rn2sq = max_r sum_c value^2 by atomic max
+// (header zeroed by a memset node ahead of the launch); one wave per row, grid-stride.
+__global__ __launch_bounds__(256) void hstat_kernel(const float* __restrict__ X, int R, int C, int ld, ofb_hhdr* __restrict__ hdr,
+                                                    const float* __restrict__ rowscale, int rs_div) {
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float am = 0.f, rn = 0.f;
+  for (int r = blockIdx.x * 4 + w; r < R; r += gridDim.x * 4) {
+    const float sc = rowscale ? rowscale[rs_div == 1 ? r : r / rs_div] : 1.f;
+    const float* row = X + (size_t)r * ld;
+    float ss = 0.f;
+    for (int c = lane; c < C; c += 64) {
+      const float v = row[c] * sc;
+      am = fmaxf(am, fabsf(v));
+      ss += v * v;
+    }
+    rn = fmaxf(rn, ofb_wave_sum(ss));
+  }
+  am = ofb_wave_max_pos(am);
+  if (lane == 0) { red[0][w] = am; red[1][w] = rn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ofb_atomic_max_pos(&hdr->amax, fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
+    ofb_atomic_max_pos(&hdr->rn2sq, fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+  }
+}
+// images for the patch matrix: amax only (rn2sq stays 0 = unknown)
+__global__ __launch_bounds__(256) void hstat_flat_kernel(const float* __restrict__ X, size_t n, ofb_hhdr* __restrict__ hdr) {
+  __shared__ float red[4];
+  float am = 0.f;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) am = fmaxf(am, fabsf(X[i]));
+  am = ofb_wave_max_pos(am);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+  __syncthreads();
+  if (threadIdx.x == 0) ofb_atomic_max_pos(&hdr->amax, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
+}
+
+// Stage 2: X[R][C] row-major (ld) -> planes; e from hdr.amax (every thread reads the same word; block (0,0) records e)
+__global__ void to_hformat_kernel(const float* __restrict__ X, int R, int C, int ld, char* __restrict__ P, int ncb,
+                                  const float* __restrict__ rowscale, int rs_div) {
+  ofb_hhdr* hdr = reinterpret_cast<ofb_hhdr*>(P);
+  const int e = ofb_h_exp(hdr->amax);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hdr->e = e;
+  const float s = ofb_h_pow2(e);
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, rg = blockIdx.y;
+  if (c >= ncb * 16) return;
+  float v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = 4 * rg + t;
+    float x = (r < R && c < C) ? X[(size_t)r * ld + c] : 0.f;
+    if (rowscale && r < R) x *= rowscale[rs_div == 1 ? r : r / rs_div];
+    v[t] = x * s;
+  }
+  ofb_store_h4(P + OFB_HHDR, ncb, rg, c, v[0], v[1], v[2], v[3]);
+}
+// Patch matrix of a conv-as-GEMM straight from the images (models/layers.py:177: Conv2d(k = s = patch) == patchify + Linear): row
+// (b, py, px) x column (c, i, j) = img[b][c][py * patch + i][px * patch + j], written as planes without the [B*L][C*patch^2] f32 copy
+__global__ void patchify_hformat_kernel(const float* __restrict__ img, int B, int Cin, int Hh, int Ww, int patch, char* __restrict__ P,
+                                        int ncb) {
+  ofb_hhdr* hdr = reinterpret_cast<ofb_hhdr*>(P);
+  const int e = ofb_h_exp(hdr->amax);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hdr->e = e;
+  const float s = ofb_h_pow2(e);
+  const int gw = Ww / patch, L = (Hh / patch) * gw, R = B * L, Cc = Cin * patch * patch;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, rg = blockIdx.y;
+  if (c >= ncb * 16) return;
+  const int ch = c / (patch * patch), rem = c - ch * patch * patch, i = rem / patch, j = rem - i * patch;
+  float v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = 4 * rg + t;
+    float x = 0.f;
+    if (r < R && c < Cc) {
+      const int b = r / L, l = r - b * L, py = l / gw, px = l - py * gw;
+      x = img[(((size_t)b * Cin + ch) * Hh + py * patch + i) * Ww + px * patch + j];
+    }
+    v[t] = x * s;
+  }
+  ofb_store_h4(P + OFB_HHDR, ncb, rg, c, v[0], v[1], v[2], v[3]);
+}
+// Many matrices in ONE launch pair (the weights of the model, once per optimizer step).  Stage 1: HM_NB blocks per job leave their
+// partial maxima in scratch[job][HM_NB][2] (no atomics, no memset); stage 2: every block of a job reduces those 2 x HM_NB words.
+constexpr int HM_NB = 32;
+__global__ __launch_bounds__(256) void hstat_multi_kernel(const ofb_pformat_job* __restrict__ jobs, float* __restrict__ scratch) {
+  __shared__ float red[2][4];
+  const ofb_pformat_job j = jobs[blockIdx.y];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float am = 0.f, rn = 0.f;
+  for (int r = blockIdx.x * 4 + w; r < j.R; r += HM_NB * 4) {
+    const float sc = j.rowscale ? j.rowscale[r] : 1.f;
+    const float* row = j.X + (size_t)r * j.ld;
+    float ss = 0.f;
+    for (int c = lane; c < j.C; c += 64) {
+      const float v = row[c] * sc;
+      am = fmaxf(am, fabsf(v));
+      ss += v * v;
+    }
+    rn = fmaxf(rn, ofb_wave_sum(ss));
+  }
+  am = ofb_wave_max_pos(am);
+  if (lane == 0) { red[0][w] = am; red[1][w] = rn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float* o = scratch + ((size_t)blockIdx.y * HM_NB + blockIdx.x) * 2;
+    o[0] = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    o[1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  }
+}
+__global__ void to_hformat_multi_kernel(const ofb_pformat_job* __restrict__ jobs, const float* __restrict__ scratch) {
+  const ofb_pformat_job j = jobs[blockIdx.z];
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, rg = blockIdx.y, ncb = (j.C + 15) >> 4;
+  if (blockIdx.x * blockDim.x >= ncb * 16 || rg >= ((j.R + 15) >> 4) * 4) return;
+  float am = 0.f, rn = 0.f;
+  const float* sc = scratch + (size_t)blockIdx.z * HM_NB * 2;
+#pragma unroll 8
+  for (int i = 0; i < HM_NB; ++i) { am = fmaxf(am, sc[2 * i]); rn = fmaxf(rn, sc[2 * i + 1]); }
+  const int e = ofb_h_exp(am);
+  if (blockIdx.x == 0 && rg == 0 && threadIdx.x == 0) {
+    ofb_hhdr* hdr = reinterpret_cast<ofb_hhdr*>(j.P);
+    hdr->e = e; hdr->amax = am; hdr->rn2sq = rn; hdr->cn2sq = 0.f;
+  }
+  if (c >= ncb * 16) return;
+  const float s = ofb_h_pow2(e);
+  float v[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = 4 * rg + t;
+    float x = (r < j.R && c < j.C) ? j.X[(size_t)r * j.ld + c] : 0.f;
+    if (j.rowscale && r < j.R) x *= j.rowscale[r];
+    v[t] = x * s;
+  }
+  ofb_store_h4((char*)j.P + OFB_HHDR, ncb, rg, c, v[0], v[1], v[2], v[3]);
+}
+// The same conversion for a gradient whose column sums are wanted as well (bias gradients: db = colsum(dY)): one pass over dY
+// writes the planes AND partial[slab][c] = sum of the slab's (scaled, NOT 2^e-scaled) rows, added in row order.
+__global__ __launch_bounds__(256) void to_hformat_colsum_kernel(const float* __restrict__ X, int R, int C, int ld, char* __restrict__ P,
+                                                                int ncb, int rgs, const float* __restrict__ rowscale, int rs_div,
+                                                                float* __restrict__ partial) {
+  __shared__ float red[4][64];
+  ofb_hhdr* hdr = reinterpret_cast<ofb_hhdr*>(P);
+  const int e = ofb_h_exp(hdr->amax);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hdr->e = e;
+  const float s = ofb_h_pow2(e);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + lane, slab = blockIdx.y;
+  float sum = 0.f;
+  if (c < ncb * 16) {
+    const int rg1 = min(rgs, (slab + 1) * CS_SLAB_RG);
+    for (int rg = slab * CS_SLAB_RG + w; rg < rg1; rg += 4) {
+      float v[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = 4 * rg + t;
+        float x = (r < R && c < C) ? X[(size_t)r * ld + c] : 0.f;
+        if (rowscale && r < R) x *= rowscale[rs_div == 1 ? r : r / rs_div];
+        v[t] = x;
+      }
+      sum += (v[0] + v[1]) + (v[2] + v[3]);
+      ofb_store_h4(P + OFB_HHDR, ncb, rg, c, v[0] * s, v[1] * s, v[2] * s, v[3] * s);
+    }
+  }
+  red[w][lane] = sum;
+  __syncthreads();
+  if (w == 0 && c < ncb * 16) partial[(size_t)slab * (ncb * 16) + c] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// planes -> X[R][C]: (h1 + h2) 2^-e
+__global__ void from_hformat_kernel(const char* __restrict__ P, int ncb, float* __restrict__ X, int R, int C, int ld) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, rg = blockIdx.y;
+  if (c >= C) return;
+  const float inv = ofb_h_pow2(-reinterpret_cast<const ofb_hhdr*>(P)->e);
+  const char* slot = P + OFB_HHDR + ((size_t)rg * ncb + (c >> 4)) * GRAN + (c & 15) * 8;
+  const uint2 a = *reinterpret_cast<const uint2*>(slot), b = *reinterpret_cast<const uint2*>(slot + 128);
+  const float v[4] = {ofb_f16_lo(a.x) + ofb_f16_lo(b.x), ofb_f16_hi(a.x) + ofb_f16_hi(b.x), ofb_f16_lo(a.y) + ofb_f16_lo(b.y),
+                      ofb_f16_hi(a.y) + ofb_f16_hi(b.y)};
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (4 * rg + t < R) X[(size_t)(4 * rg + t) * ld + c] = v[t] * inv;
+}
+
+// partial[slab][c] = sum over the slab's rows of X[r][c]: column sums of an H-format matrix (bias gradients of tensors that exist
+// only as planes).  grid (ncb / 4, slabs), 256 threads = 4 waves x 64 columns; fixed order.
+__global__ __launch_bounds__(256) void colsum_h_kernel(const char* __restrict__ P, int ncb, int rgs, float* __restrict__ partial, int ld) {
+  __shared__ float red[4][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, cb = blockIdx.x * 4 + (lane >> 4), slab = blockIdx.y;
+  const float inv = ofb_h_pow2(-reinterpret_cast<const ofb_hhdr*>(P)->e);
+  float s = 0.f;
+  if (cb < ncb) {
+    const int rg1 = min(rgs, (slab + 1) * CS_SLAB_RG);
+    for (int rg = slab * CS_SLAB_RG + w; rg < rg1; rg += 4) {
+      const char* slot = P + OFB_HHDR + ((size_t)rg * ncb + cb) * GRAN + (lane & 15) * 8;
+      const uint2 a = *reinterpret_cast<const uint2*>(slot), b = *reinterpret_cast<const uint2*>(slot + 128);
+      s += ofb_f16_lo(a.x) + ofb_f16_lo(b.x);
+      s += ofb_f16_hi(a.x) + ofb_f16_hi(b.x);
+      s += ofb_f16_lo(a.y) + ofb_f16_lo(b.y);
+      s += ofb_f16_hi(a.y) + ofb_f16_hi(b.y);
+    }
+  }
+  red[w][lane] = s * inv;
+  __syncthreads();
+  if (w == 0 && cb < ncb) partial[(size_t)slab * ld + blockIdx.x * 64 + lane] = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+}
+
+// ---- the GEMM -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int swz(int tg) { return ((tg >> 1) & 3) << 1; }
+
+// v = alpha*acc (+bias)(*colscale); act; (*rowscale); (+resid)   -- the fix-up kernel's form of the fused epilogue
+__device__ __forceinline__ float epi_value(const ofb_gemm_h_args& g, float alpha, float accv, int row, int col, float bias, float cs, bool ok) {
+  float v = (accv * alpha + bias) * cs;
+  if (g.act == OFB_ACT_GELU) {
+    if (g.aux && ok) g.aux[(size_t)row * g.ldaux + col] = v;
+    v = ofb_gelu(v);
+  } else if (g.act == OFB_ACT_GELU_GRAD) {
+    float Phi, phi;
+    ofb_gelu_parts(v, Phi, phi);
+    if (ok) g.aux[(size_t)row * g.ldaux + col] = Phi + v * phi;
+    v *= Phi;
+  } else if (g.act == OFB_ACT_DGELU) {
+    v *= ofb_dgelu(ok ? g.aux[(size_t)row * g.ldaux + col] : 0.f);
+  } else if (g.act == OFB_ACT_MULAUX) {
+    v *= ok ? g.aux[(size_t)row * g.ldaux + col] : 0.f;
+  }
+  if (g.rowscale) v *= ok ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
+  if (g.resid) v += ok ? g.resid[(size_t)row * g.ldr + col] : 0.f;
+  return v;
+}
+
+// Upper bound of |output| -> the H-format output's header (e) and / or cbound_out, BEFORE the product runs.  Cauchy-Schwarz over
+// the reduction: |sum_k a_k b_k| <= |a|_2 |b|_2, the operand norms from their headers (exact where the producer measured them,
+// else K amax^2); then the epilogue: + max|bias|, x max|colscale|, x aux_bound for the multiplying activations (|gelu(v)| <= |v|),
+// x max|rowscale|.  One block.  out_bound (device scalar) given: it IS the bound.
+__global__ __launch_bounds__(256) void gemm_h_bound_kernel(const ofb_gemm_h_args g) {
+  __shared__ float red[3][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float mb = 0.f, mc = g.colscale ? 0.f : 1.f, mr = g.rowscale ? 0.f : 1.f;
+  if (!g.out_bound) {
+    if (g.bias) for (int i = threadIdx.x; i < g.N; i += 256) mb = fmaxf(mb, fabsf(g.bias[i]));
+    if (g.colscale) for (int i = threadIdx.x; i < g.N; i += 256) mc = fmaxf(mc, fabsf(g.colscale[i]));
+    if (g.rowscale) for (int i = threadIdx.x; i < (g.M + g.rs_div - 1) / g.rs_div; i += 256) mr = fmaxf(mr, fabsf(g.rowscale[i]));
+  }
+  mb = ofb_wave_max_pos(mb); mc = ofb_wave_max_pos(mc); mr = ofb_wave_max_pos(mr);
+  if (lane == 0) { red[0][w] = mb; red[1][w] = mc; red[2][w] = mr; }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  float bound;
+  if (g.out_bound) bound = g.out_bound[0];
+  else {
+    const ofb_hhdr ha = *ofb_h_hdr(g.A), hb = *ofb_h_hdr(g.B);
+    const float ka = (float)g.K * ha.amax * ha.amax, kb = (float)g.K * hb.amax * hb.amax;
+    const float sa = g.a_kc ? ha.rn2sq : ha.cn2sq, sb = g.b_kc ? hb.rn2sq : hb.cn2sq;
+    const float na = (sa > 0.f && sa < ka) ? sa : ka, nb = (sb > 0.f && sb < kb) ? sb : kb;
+    mb = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    mc = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+    mr = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+    bound = (sqrtf(na) * sqrtf(nb) * fabsf(g.alpha) * 1.0001f + mb) * mc;
+    if (g.act == OFB_ACT_DGELU || g.act == OFB_ACT_MULAUX) bound *= g.aux_bound > 0.f ? g.aux_bound : 1.13f;
+    bound *= mr;
+  }
+  if (g.Cp) {
+    ofb_hhdr* h = reinterpret_cast<ofb_hhdr*>(g.Cp);
+    h->e = ofb_h_exp(bound); h->amax = bound; h->rn2sq = 0.f; h->cn2sq = 0.f;
+  }
+  if (g.cbound_out) g.cbound_out[0] = bound;
+}
+
+#define OFB_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
+__device__ __forceinline__ void vm_wait(int n) {           // n is wave-uniform
+  switch (n) {
+    OFB_VMW(0) OFB_VMW(1) OFB_VMW(2) OFB_VMW(3) OFB_VMW(4) OFB_VMW(5) OFB_VMW(6) OFB_VMW(7) OFB_VMW(8) OFB_VMW(9) OFB_VMW(10) OFB_VMW(11)
+    OFB_VMW(12) OFB_VMW(13) OFB_VMW(14) OFB_VMW(15) OFB_VMW(16) OFB_VMW(17) OFB_VMW(18) OFB_VMW(19) OFB_VMW(20) OFB_VMW(21) OFB_VMW(22)
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
+
+// Epilogue forms are compile-time (EPI = set of E_* bits): with run-time flags hipcc has to assume that a side-input load may
+// follow an aliasing store and puts s_waitcnt vmcnt(0) between the stores of every element.
+enum : int { E_C = 1, E_P = 2, E_GELU = 4, E_DGELU = 8, E_RS = 16, E_RES = 32, E_ANY = 64, E_GELUG = 128, E_MULAUX = 256 };
+
+template <class CF, bool A_KC, bool B_KC, bool TAIL, int EPI>
+__global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args g, const Plan p) {
+  constexpr int BM = CF::BM, BN = CF::BN, WN = CF::WN, MI = CF::MI, NI = CF::NI, HA = CF::HA, NST = CF::NST, NW = CF::NW, KH = CF::KH;
+  constexpr int STAGE = CF::STAGE, A_BYTES = CF::A_BYTES, QA = CF::QA, QB = CF::QB, HR = CF::HR, TROW = CF::TROW;
+  constexpr int NBA = BM / 32, NBB = BN / 32;                 // 32-row blocks of each operand's tile
+  __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
+  const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, h = lane >> 5;
+  const int wm0 = (w / WN) * (32 * MI), wn0 = (w % WN) * (32 * NI);
+  const int a_ncb = g.a_ncb, b_ncb = g.b_ncb;
+  const bool blast = w + NW * (QB - 1) < CF::B_PIECES;   // this wave moves a QB-th B piece per stage (wave-uniform)
+  const int n_w = QA + QB - (blast ? 0 : 1);             // LDS-DMA instructions of this wave per stage
+
+  // LDS-DMA source offsets (bytes, relative to the tile / stage base) of this wave's 1-KB pieces (ids w, w + NW, ...)
+  //   KC: piece = (K16 sub-step kh, block j of 32 rows, plane): lane -> granule tg = l>>3 of the block, 16-B chunk cp = (l&7) ^ swz(tg)
+  //       of that plane's 128-B slab; the XOR on the SOURCE chunk (LDS stays lane-linear) makes the transposed reads conflict free
+  //   KR: the stage image is a linear copy of [4 KH row groups][B? / 16 granules] cut into 1-KB pieces = 4 granules; in the ODD
+  //       granules the two plane slabs change places (source chunk ^ 8), so that the two 16-lane groups of a fragment read (granules
+  //       g, g + 1 of one plane) hit opposite 128-B halves of the 256-B bank row
+  unsigned a_off[QA], b_off[QB];
+  {
+    const int tg = lane >> 3, cp = (lane & 7) ^ swz(tg);
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      const int piece = w + NW * q, kh = piece / (2 * NBA), rem = piece % (2 * NBA), j = rem >> 1, pl = rem & 1;
+      const int bl = piece * 1024 + lane * 16, rgl = bl / (BM * 16), wi = bl % (BM * 16), gr = wi >> 8, ch = ((wi >> 4) & 15) ^ ((gr & 1) << 3);
+      a_off[q] = A_KC ? (unsigned)(((8 * j + tg) * a_ncb + kh) * GRAN + pl * 128 + cp * 16)
+                      : (unsigned)((rgl * a_ncb + gr) * GRAN + ch * 16);
+    }
+#pragma unroll
+    for (int q = 0; q < QB; ++q) {
+      const int piece = w + NW * q, kh = piece / (2 * NBB), rem = piece % (2 * NBB), j = rem >> 1, pl = rem & 1;
+      const int bl = piece * 1024 + lane * 16, rgl = bl / (BN * 16), wi = bl % (BN * 16), gr = wi >> 8, ch = ((wi >> 4) & 15) ^ ((gr & 1) << 3);
+      b_off[q] = B_KC ? (unsigned)(((8 * j + tg) * b_ncb + kh) * GRAN + pl * 128 + cp * 16)
+                      : (unsigned)((rgl * b_ncb + gr) * GRAN + ch * 16);
+    }
+  }
+  // fragment read offsets (bytes inside an operand's stage image), two 8-byte reads per fragment
+  //   KC: piece (kh, blk, plane) at ((kh NB + blk) 2 + plane) KB; inside it the transposed-read addresses r0 / r1
+  //   KR: row groups 4 kh + 2 h, + 1; granule 2 blk + (l31 >> 4), whose plane slabs are swapped when it is odd
+  int a_r0, a_r1, b_r0, b_r1;
+  {
+    const int gq = lane >> 4, i = lane & 15, q = i >> 2, pp = i & 3, hh = gq >> 1, tg = 4 * (gq & 1) + pp;
+    const int c0 = 8 * hh + q, c1 = c0 + 4;
+    const int kc0 = (8 * tg + ((c0 >> 1) ^ swz(tg))) * 16 + (c0 & 1) * 8, kc1 = (8 * tg + ((c1 >> 1) ^ swz(tg))) * 16 + (c1 & 1) * 8;
+    const int odd = (l31 >> 4) & 1;
+    const int kr_a0 = ((2 * h) * (BM / 16) + (l31 >> 4)) * GRAN + odd * 128 + (l31 & 15) * 8, kr_a1 = kr_a0 + (BM / 16) * GRAN;
+    const int kr_b0 = ((2 * h) * (BN / 16) + (l31 >> 4)) * GRAN + odd * 128 + (l31 & 15) * 8, kr_b1 = kr_b0 + (BN / 16) * GRAN;
+    a_r0 = A_KC ? kc0 : kr_a0; a_r1 = A_KC ? kc1 : kr_a1;
+    b_r0 = B_KC ? kc0 : kr_b0; b_r1 = B_KC ? kc1 : kr_b1;
+  }
+  const int kr_flip = 128 - 256 * ((l31 >> 4) & 1);     // KR: plane 1 sits at +128 in even granules, at -128 in odd ones
+
+  f32x16 acc[MI][NI];                                // zeroed at the start of every unit: nothing of it lives across an epilogue
+
+  // LDS-DMA in inline asm (through the builtin hipcc drains every LDS-DMA with vmcnt(0) before the next ds_read): invisible to
+  // its wait-count bookkeeping, counted by hand (n_w per wave and stage).  The pieces of one wave sit NW KB apart in the stage
+  // image, A's first, then B's (A_BYTES = QA * NW KB).  M0 is written in the statement that uses it and restored afterwards.
+  const unsigned lds0 = (unsigned)(size_t)OFB_LDSP(lds) + (unsigned)w * 1024u;
+  auto dma = [&](unsigned ldsaddr, unsigned voff, const char* base) __attribute__((always_inline)) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsaddr), "v"(voff), "s"(base) : "memory");
+  };
+  auto issue = [&](int buf, const char* a_src, const char* b_src) __attribute__((always_inline)) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0" : "=s"(keep) :: "memory");
+    const unsigned l0 = lds0 + (unsigned)buf * (unsigned)STAGE;
+#pragma unroll
+    for (int q = 0; q < QA; ++q) dma(l0 + q * (NW * 1024), a_off[q], a_src);
+#pragma unroll
+    for (int q = 0; q < QB - 1; ++q) dma(l0 + (QA + q) * (NW * 1024), b_off[q], b_src);
+    if (blast) dma(l0 + (QA + QB - 1) * (NW * 1024), b_off[QB - 1], b_src);
+    asm volatile("s_mov_b32 m0, %0" :: "s"(keep) : "memory");
+  };
+  auto frag = [&](const char* base, int r0, int r1, bool kc, int nb, int kh, int blk, int plane) __attribute__((always_inline)) -> ofb_f16x8 {
+    hs16x4 lo4, hi4;
+    if (kc) {
+      const char* q = base + ((kh * nb + blk) * 2 + plane) * 1024;
+      lo4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hs16x4*)(q + r0));
+      hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) hs16x4*)(q + r1));
+    } else {
+      const char* q = base + (4 * kh * (nb * 2) + 2 * blk) * GRAN + (plane ? kr_flip : 0);
+      lo4 = *reinterpret_cast<const hs16x4*>(q + r0);
+      hi4 = *reinterpret_cast<const hs16x4*>(q + r1);
+    }
+    hs16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
+    return __builtin_bit_cast(ofb_f16x8, v);
+  };
+  ofb_f16x8 alo[HA][2], ahi[HA][2], bb[2][NI][2];       // A fragments of the two half steps, B fragments of this / the next K16 sub-step
+  auto rdA = [&](ofb_f16x8 (&dst)[HA][2], int buf, int kh, int blk0) __attribute__((always_inline)) {
+    const char* la = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < HA; ++i)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) dst[i][pl] = frag(la, a_r0, a_r1, A_KC, NBA, kh, (wm0 >> 5) + blk0 + i, pl);
+  };
+  auto rdB = [&](ofb_f16x8 (&dst)[NI][2], int buf, int kh) __attribute__((always_inline)) {
+    const char* lb = lds + buf * STAGE + A_BYTES;
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) dst[j][pl] = frag(lb, b_r0, b_r1, B_KC, NBB, kh, (wn0 >> 5) + j, pl);
+  };
+  // product terms, smallest first: [(h2,h2)] (h2,h1) (h1,h2) (h1,h1)
+  constexpr int NTERM = OFB_H_NTERM;
+  constexpr int TA[4] = {1, 1, 0, 0}, TB[4] = {1, 0, 1, 0};
+  constexpr int T0 = 4 - NTERM;
+  constexpr int NMF = NTERM * HA * NI, RD1 = 4 * HA, RD2 = 4 * HA + 4 * NI;   // MFMAs per half step; fragment reads riding in the first / second half
+#define OFB_MMA_HALF(AF, BF, BLK0)                                                                                                   \
+  _Pragma("unroll") for (int q = T0; q < 4; ++q) _Pragma("unroll") for (int i = 0; i < HA; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
+      acc[BLK0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i][TA[q]], BF[j][TB[q]], acc[BLK0 + i][j], 0, 0, 0);
+#define OFB_INTERLEAVE(NM, ND)                                                               \
+  _Pragma("unroll") for (int z_ = 0; z_ < (NM); ++z_) {                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
+    __builtin_amdgcn_sched_group_barrier(0x100, ND, 0);                                      \
+  }
+  // ND reads in total spread over NM MFMA gaps (ND <= 2 NM): the first (ND - NM) gaps carry two
+#define OFB_SPREAD(NM, ND)                                                                   \
+  OFB_INTERLEAVE((ND) > (NM) ? (ND) - (NM) : 0, 2)                                           \
+  OFB_INTERLEAVE((ND) > (NM) ? 2 * (NM) - (ND) : (NM), 1)
+
+  const int v = ofb_xcd_remap(blockIdx.x, p.W);     // consecutive v share an XCD (and thus operand panels in its L2)
+  int sidx = 0;
+  Seg cur = get_seg<TAIL>(p, v, 0);
+  if (!cur.ok) return;
+  // 2^-(ea + eb): the planes hold A 2^ea and B 2^eb
+  const float alpha = TAIL ? 1.f : g.alpha * ofb_h_pow2(-(ofb_h_hdr(g.A)->e + ofb_h_hdr(g.B)->e));
+  const char* Apl = ofb_h_planes(g.A);
+  const char* Bpl = ofb_h_planes(g.B);
+  while (true) {
+    const int nk16 = cur.it1 - cur.it0, nst = (nk16 + KH - 1) / KH;
+    const bool last_full = nk16 == nst * KH;              // KH == 2: an odd number of K16 steps ends in a half stage
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const size_t a_k16 = A_KC ? GRAN : (size_t)4 * a_ncb * GRAN, b_k16 = B_KC ? GRAN : (size_t)4 * b_ncb * GRAN;
+    const size_t a_step = a_k16 * KH, b_step = b_k16 * KH;
+    const char* a_base = Apl + (A_KC ? (size_t)(cur.m0 / 4) * a_ncb * GRAN : (size_t)(cur.m0 / 16) * GRAN) + cur.it0 * a_k16;
+    const char* b_base = Bpl + (B_KC ? (size_t)(cur.n0 / 4) * b_ncb * GRAN : (size_t)(cur.n0 / 16) * GRAN) + cur.it0 * b_k16;
+    __builtin_amdgcn_s_barrier();                        // every wave is past the previous unit's LDS traffic
+    issue(0, a_base, b_base);
+    if (nst > 1) issue(1, a_base + a_step, b_base + b_step);
+    if (NST > 2 && nst > 2) issue(2, a_base + 2 * a_step, b_base + 2 * b_step);
+    vm_wait(((nst < NST ? nst : NST) - 1) * n_w);        // stage 0 landed; the other prologue stages may be in flight
+    __builtin_amdgcn_s_barrier();
+    rdA(alo, 0, 0, 0);
+    rdB(bb[0], 0, 0);
+    // the hand-over inside the LAST sub-step of stage i: this wave is done reading buf(i), its pieces of stage i+1 have landed
+    // (later stages may fly), everybody agrees (barrier), stage i + NST goes into buf(i)
+    auto handover = [&](int i, int buf) __attribute__((always_inline)) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      int young = nst - i - 2;
+      young = young < 0 ? 0 : (young > NST - 2 ? NST - 2 : young);
+      vm_wait(young * n_w);
+      __builtin_amdgcn_s_barrier();
+      if (i + NST < nst) issue(buf, a_base + (size_t)(i + NST) * a_step, b_base + (size_t)(i + NST) * b_step);
+    };
+    auto stage = [&](int i, int buf, bool full) __attribute__((always_inline)) {
+      const int nbuf = buf + 1 == NST ? 0 : buf + 1;
+      if constexpr (KH == 1) {
+        __builtin_amdgcn_sched_barrier(0);
+        rdA(ahi, buf, 0, HA);
+        OFB_MMA_HALF(alo, bb[0], 0)
+        OFB_SPREAD(NMF, RD1)
+        __builtin_amdgcn_sched_barrier(0);
+        handover(i, buf);
+        __builtin_amdgcn_sched_barrier(0);
+        rdA(alo, nbuf, 0, 0);
+        rdB(bb[1], nbuf, 0);
+        OFB_MMA_HALF(ahi, bb[0], HA)
+        OFB_SPREAD(NMF, RD2)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) { bb[0][j][0] = bb[1][j][0]; bb[0][j][1] = bb[1][j][1]; }
+      } else {
+        // sub-step 0, first half: lower row blocks x B(kh 0); the reads of the upper row blocks ride in the MFMA gaps
+        __builtin_amdgcn_sched_barrier(0);
+        rdA(ahi, buf, 0, HA);
+        OFB_MMA_HALF(alo, bb[0], 0)
+        OFB_SPREAD(NMF, RD1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (full) {
+          // sub-step 0, second half: upper row blocks; the reads of sub-step 1 ride in the gaps
+          rdA(alo, buf, 1, 0);
+          rdB(bb[1], buf, 1);
+          OFB_MMA_HALF(ahi, bb[0], HA)
+          OFB_SPREAD(NMF, RD2)
+          __builtin_amdgcn_sched_barrier(0);
+          // sub-step 1, first half
+          rdA(ahi, buf, 1, HA);
+          OFB_MMA_HALF(alo, bb[1], 0)
+          OFB_SPREAD(NMF, RD1)
+          __builtin_amdgcn_sched_barrier(0);
+          handover(i, buf);
+          // sub-step 1, second half: the reads of stage i+1, sub-step 0 ride in the gaps (after the last stage they fetch a stale
+          // buffer that nothing consumes)
+          __builtin_amdgcn_sched_barrier(0);
+          rdA(alo, nbuf, 0, 0);
+          rdB(bb[0], nbuf, 0);
+          OFB_MMA_HALF(ahi, bb[1], HA)
+          OFB_SPREAD(NMF, RD2)
+          __builtin_amdgcn_sched_barrier(0);
+        } else {
+          // the unit's last, half stage (odd number of K16 steps): nothing follows
+          OFB_MMA_HALF(ahi, bb[0], HA)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    };
+    // A wave whose whole 64 x 96 part of the tile lies outside the matrix (ragged shapes: N = 264 in 192-column tiles, ...) takes
+    // part in the staging and the barriers only: no fragment reads, no MFMAs (its accumulators stay zero and are never stored)
+    if (cur.m0 + wm0 < g.M && cur.n0 + wn0 < g.N) {
+      int buf = 0;
+      for (int i = 0; i + 1 < nst; ++i) {
+        stage(i, buf, true);
+        buf = buf + 1 == NST ? 0 : buf + 1;
+      }
+      if (last_full) stage(nst - 1, buf, true);
+      else stage(nst - 1, buf, false);
+    } else {
+      int buf = 0;
+      for (int i = 0; i < nst; ++i) {
+        if (i + 1 < nst || last_full || KH == 1) {
+          int young = nst - i - 2;
+          young = young < 0 ? 0 : (young > NST - 2 ? NST - 2 : young);
+          vm_wait(young * n_w);
+          __builtin_amdgcn_s_barrier();
+          if (i + NST < nst) issue(buf, a_base + (size_t)(i + NST) * a_step, b_base + (size_t)(i + NST) * b_step);
+        }
+        buf = buf + 1 == NST ? 0 : buf + 1;
+      }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the trailing (unused) fragment reads
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (a half last stage leaves its own DMA unwaited)
+
+    {
+      // Epilogue through LDS (the stage buffers are free now): the accumulators of HR rows of the tile are parked as
+      // T[col][HR rows (+4 pad)] f32 - a lane's four consecutive rows of a column are one ds_write_b128 - and all waves finish
+      // those rows together, one (4-row group, column) item per thread and trip: f32 loads / stores are coalesced along the
+      // columns, the H-format store is the item's two 8-byte plane slots.
+      constexpr int NC = (BN + 63) / 64, NRG = (HR / 4) / NW;
+      constexpr bool PART = (BN % 64) != 0;
+      static_assert((HR / 4) % NW == 0, "epilogue item map");
+      const bool lane_in_last = !PART || lane + 64 * (NC - 1) < BN;
+      constexpr bool ANY = (EPI & E_ANY) != 0;
+      const bool has_c = ANY ? g.C != nullptr : (EPI & E_C) != 0, has_p = ANY ? g.Cp != nullptr : (EPI & E_P) != 0;
+      const bool gelu = ANY ? g.act == OFB_ACT_GELU : (EPI & E_GELU) != 0, dg = ANY ? g.act == OFB_ACT_DGELU : (EPI & E_DGELU) != 0;
+      const bool gelug = ANY ? g.act == OFB_ACT_GELU_GRAD : (EPI & E_GELUG) != 0, mula = ANY ? g.act == OFB_ACT_MULAUX : (EPI & E_MULAUX) != 0;
+      const bool has_rs = ANY ? g.rowscale != nullptr : (EPI & E_RS) != 0, has_res = ANY ? g.resid != nullptr : (EPI & E_RES) != 0;
+      float* T = reinterpret_cast<float*>(lds);
+      float* __restrict__ Cout = g.C;
+      float* __restrict__ auxw = g.aux;
+      const float* __restrict__ auxr = g.aux;
+      const float* __restrict__ resid = g.resid;
+      const float* __restrict__ rowscale = g.rowscale;
+      char* __restrict__ Cpl = g.Cp ? (char*)g.Cp + OFB_HHDR : nullptr;
+      const float so = (!TAIL && has_p) ? ofb_h_pow2(reinterpret_cast<const ofb_hhdr*>(g.Cp)->e) : 1.f;   // written by the bound kernel
+      const int rp_out = (g.M + 15) & ~15;
+      float biasv[NC], csv[NC], cacc[NC];
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        cacc[c] = 0.f;
+        const int col = cur.n0 + lane + 64 * c, colc = col < g.N ? col : g.N - 1;
+        biasv[c] = (!TAIL && g.bias) ? g.bias[colc] : 0.f;
+        csv[c] = (!TAIL && g.colscale) ? g.colscale[colc] : 1.f;
+      }
+      __builtin_amdgcn_s_barrier();                                 // every wave has finished its fragment reads / its LDS-DMA
+#pragma unroll
+      for (int half = 0; half < BM / HR; ++half) {
+        if (wm0 / HR == half) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+              for (int gq = 0; gq < 4; ++gq) {
+                f32x4 q4 = {acc[mi][ni][4 * gq], acc[mi][ni][4 * gq + 1], acc[mi][ni][4 * gq + 2], acc[mi][ni][4 * gq + 3]};
+                *reinterpret_cast<f32x4*>(T + (wn0 + 32 * ni + l31) * TROW + (wm0 % HR) + 32 * mi + 8 * gq + 4 * h) = q4;
+              }
+        }
+        __syncthreads();
+        if (TAIL) {                                                   // raw partial tile -> workspace[slot][BM][BN]
+#pragma unroll
+          for (int k = 0; k < NRG; ++k) {
+            const int rgl = w + NW * k;
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+              const int lcol = lane + 64 * c;
+              if (PART && c == NC - 1 && !lane_in_last) continue;
+              const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + lcol * TROW + 4 * rgl);
+              float* __restrict__ ws = g.workspace + (size_t)cur.slot * (BM * BN) + (size_t)(HR * half + 4 * rgl) * BN + lcol;
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt) ws[tt * BN] = q4[tt];
+            }
+          }
+        } else {
+          auto pass = [&](auto GUARDED) __attribute__((always_inline)) {
+            constexpr bool GD = decltype(GUARDED)::value;
+            constexpr int KB = NRG > 4 ? NRG / 4 : NRG / 2, BI = KB * NC;
+            static_assert(NRG % 2 == 0 && NRG % KB == 0, "epilogue batches");
+#pragma unroll
+            for (int k0 = 0; k0 < NRG; k0 += KB) {
+              f32x4 side[BI], side2[BI], rsv[KB];
+#pragma unroll
+              for (int kk = 0; kk < KB; ++kk) {
+                const int row0 = cur.m0 + HR * half + 4 * (w + NW * (k0 + kk));
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) {
+                  const int row = row0 + tt, rowc = (!GD || row < g.M) ? row : g.M - 1;
+                  rsv[kk][tt] = has_rs ? rowscale[g.rs_div == 1 ? rowc : rowc / g.rs_div] : 1.f;
+#pragma unroll
+                  for (int c = 0; c < NC; ++c) {
+                    const int col = cur.n0 + lane + 64 * c, colc = ((!GD && !PART) || col < g.N) ? col : g.N - 1;
+                    side[kk * NC + c][tt] = (dg || mula) ? auxr[(size_t)rowc * g.ldaux + colc] : 0.f;
+                    side2[kk * NC + c][tt] = has_res ? resid[(size_t)rowc * g.ldr + colc] : 0.f;
+                  }
+                }
+              }
+#pragma unroll
+              for (int kk = 0; kk < KB; ++kk) {
+                const int rgl = w + NW * (k0 + kk), row0 = cur.m0 + HR * half + 4 * rgl;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                  const int lcol = lane + 64 * c, col = cur.n0 + lcol;
+                  if (PART && c == NC - 1 && !lane_in_last) continue;
+                  const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + lcol * TROW + 4 * rgl);
+                  const bool colok = !GD || col < g.N;
+                  float pv[4];
+#pragma unroll
+                  for (int tt = 0; tt < 4; ++tt) {
+                    const int row = row0 + tt;
+                    const bool ok = !GD || (colok && row < g.M);
+                    float val = (q4[tt] * alpha + biasv[c]) * csv[c];
+                    if (gelu) {
+                      if (auxw && ok) auxw[(size_t)row * g.ldaux + col] = val;
+                      val = ofb_gelu(val);
+                    } else if (gelug) {
+                      float Phi, phi;
+                      ofb_gelu_parts(val, Phi, phi);
+                      if (ok) auxw[(size_t)row * g.ldaux + col] = Phi + val * phi;
+                      val *= Phi;
+                    } else if (dg) {
+                      val *= ofb_dgelu(side[kk * NC + c][tt]);
+                    } else if (mula) {
+                      val *= side[kk * NC + c][tt];
+                    }
+                    val = val * rsv[kk][tt] + side2[kk * NC + c][tt];
+                    if (has_c && ok) Cout[(size_t)row * g.ldc + col] = val;
+                    pv[tt] = ok ? val : 0.f;
+                  }
+                  cacc[c] += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+                  if (has_p && (!GD || (row0 < rp_out && col < g.c_ncb * 16)))
+                    store_h4(Cpl + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8, pv[0] * so, pv[1] * so, pv[2] * so,
+                             pv[3] * so);
+                }
+              }
+            }
+          };
+          if (cur.m0 + BM <= g.M && cur.n0 + BN <= g.N) pass(std::false_type{});
+          else pass(std::true_type{});
+        }
+        if (half + 1 < BM / HR) __syncthreads();                    // T is rewritten by the next pass (the next unit starts with a barrier)
+      }
+      if (!TAIL && g.colpart) {
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < NC; ++c) T[w * BN + lane + 64 * c] = cacc[c];
+        __syncthreads();
+        if (t < BN && cur.n0 + t < g.N) {
+          float sum = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < NW; ++ww) sum += T[ww * BN + t];
+          g.colpart[(size_t)(cur.m0 / BM) * g.N + cur.n0 + t] = sum;
+        }
+      }
+    }
+    const Seg nxt = get_seg<TAIL>(p, v, ++sidx);
+    if (!nxt.ok) break;
+    cur = nxt;
+  }
+}
+
+// Sums the partial tiles of each streamed tail tile in a fixed contributor order and applies the epilogue.
+// grid (R, BM / 4), BN threads: block (r, rg) handles rows [4*rg, 4*rg+4) of tail tile r, one column per thread.
+template <class CF>
+__global__ __launch_bounds__(CF::BN) void gemm_h_fixup_kernel(const ofb_gemm_h_args g, const Plan p) {
+  constexpr int BM = CF::BM, BN = CF::BN;
+  const int r = blockIdx.x, rgl = blockIdx.y, t = threadIdx.x;
+  const int tile = p.full_rounds * p.W + r;
+  int m0, n0;
+  tile_coord(p, tile, m0, n0);
+  const int lo = r * p.I, hi = lo + p.I;
+  const int v0 = p.S ? 0 : lo / p.q, v1 = p.S ? (p.I + p.qs - 1) / p.qs - 1 : (hi - 1) / p.q;
+  auto slot_of = [&](int v) { return p.S ? v * p.R + r : ((v * p.q < lo) ? 2 * v + 1 : 2 * v); };
+  float sum[4] = {0.f, 0.f, 0.f, 0.f};
+  int v = v0;
+  for (; v + 3 <= v1; v += 4) {                       // four contributors per trip in flight, added in contributor order
+    float x[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float* ws = g.workspace + (size_t)slot_of(v + u) * (BM * BN) + (size_t)(4 * rgl) * BN + t;
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) x[u][tt] = ws[tt * BN];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) sum[tt] += x[u][tt];
+  }
+  for (; v <= v1; ++v) {
+    const float* ws = g.workspace + (size_t)slot_of(v) * (BM * BN) + (size_t)(4 * rgl) * BN + t;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) sum[tt] += ws[tt * BN];
+  }
+  const float alpha = g.alpha * ofb_h_pow2(-(ofb_h_hdr(g.A)->e + ofb_h_hdr(g.B)->e));
+  const float so = g.Cp ? ofb_h_pow2(reinterpret_cast<const ofb_hhdr*>(g.Cp)->e) : 1.f;
+  const int row0 = m0 + 4 * rgl, col = n0 + t;
+  const bool colok = col < g.N;
+  const float bias = (g.bias && colok) ? g.bias[col] : 0.f, cs = (g.colscale && colok) ? g.colscale[col] : 1.f;
+  float pv[4];
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const int row = row0 + tt;
+    const bool ok = colok && row < g.M;
+    const float val = epi_value(g, alpha, sum[tt], row, col, bias, cs, ok);
+    if (g.C && ok) g.C[(size_t)row * g.ldc + col] = val;
+    pv[tt] = ok ? val : 0.f;
+  }
+  if (g.Cp && row0 < ((g.M + 15) & ~15) && col < g.c_ncb * 16)
+    store_h4((char*)g.Cp + OFB_HHDR + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8, pv[0] * so, pv[1] * so, pv[2] * so,
+             pv[3] * so);
+  if (g.colpart && colok)
+    g.colpart[((size_t)(p.mt - p.R / p.nt) + (size_t)(r / p.nt) * (BM / 4) + rgl) * g.N + col] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
+}
+
+int h_cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    hipDeviceProp_t prop;
+    int devid = 0;
+    n = 256;
+    if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.multiProcessorCount > 0)
+      n = prop.multiProcessorCount;
+  }
+  return n;
+}
+
+int h_tile_choice(const ofb_gemm_h_args& g) {
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("OFB_GEMM_H_TILE"); forced = e ? atoi(e) : 0; }
+  if (forced == 128) return 128;
+#ifdef OFB_GEMM_H_LAB
+  if (forced == 1281) return 1281;
+#endif
+  if (g.a_kc && !g.colpart && g.M >= 4 * C96::BM) {
+    const int c192 = ofb_cdiv(g.N, 192) * 192, c96 = ofb_cdiv(g.N, 96) * 96;
+    if (forced == 96) return 96;
+    if (c96 < c192) {
+      const double rounds = (double)ofb_cdiv(g.M, C96::BM) * (c96 / 96) / (double)(h_cu_count() * C96::WGS);
+      const double frac = rounds - (double)(long long)rounds;
+      if (!(frac > 0.0 && frac < 0.3 && g.K < 384)) return 96;
+    }
+  }
+  return 128;
+}
+
+template <class CF>
+Plan plan_h(const ofb_gemm_h_args& g) {
+  int W = h_cu_count() * CF::WGS;
+  if (!g.a_kc && !g.b_kc) {
+    // weight-gradient form: ONE workgroup per CU (half the partial-tile traffic of two at an equal step time)
+    static int dw_wgs = -1;
+    if (dw_wgs < 0) { const char* e = getenv("OFB_GEMM_H_DW_WGS"); dw_wgs = e ? atoi(e) : 1; }
+    if (dw_wgs > 0 && dw_wgs < CF::WGS) W = h_cu_count() * dw_wgs;
+  }
+  const int tiles = ofb_cdiv(g.M, CF::BM) * ofb_cdiv(g.N, CF::BN);
+  const long long iters = (long long)tiles * ofb_cdiv(g.K, 16);
+  if (iters < W) W = (int)iters;
+  Plan p = make_plan(g.M, g.N, g.K, W, CF::BM, CF::BN, 16);
+  if (p.R > 0 && g.colpart && p.R % p.nt != 0) {                     // column sums of tail tiles come from the fix-up kernel, which
+    p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;         // addresses them per whole tile row
+  }
+  if (p.R > 0) {
+    // costs in K16 steps of one workgroup: a streamed tail = its K steps + the partial tiles' round trip through HBM + the extra
+    // launches, against one more (partly idle) data-parallel round of I steps
+    const double PC = 0.03, FIX = 5.0;
+    double best = 0.9 * p.I;
+    int bestS = -1;
+    const int smax = W / p.R;
+    for (int S = 2; S <= smax; ++S) {
+      const double c = (double)((p.I + S - 1) / S) + (double)p.R * S * PC + FIX;
+      if (c < best) { best = c; bestS = S; }
+    }
+    if (smax < 2) {
+      const double c = (double)(((long long)p.R * p.I + W - 1) / W) + (double)(2 * p.R < 2 * W ? 2 * p.R : 2 * W) * PC + FIX;
+      if (c < best) { best = c; bestS = 0; }
+    }
+    if (bestS < 0) { p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0; }
+    else if (bestS > 0) { p.S = bestS; p.qs = (p.I + bestS - 1) / bestS; }
+    else { p.S = 0; p.qs = 0; }
+  }
+  p.stagger = 0;
+  return p;
+}
+
+template <class CF, bool A_KC, bool B_KC, int EPI>
+void launch_full(const ofb_gemm_h_args& g, const Plan& p, hipStream_t s) {
+  hipLaunchKernelGGL((gemm_h_kernel<CF, A_KC, B_KC, false, EPI>), dim3(p.W), dim3(CF::NT), 0, s, g, p);
+}
+
+template <class CF, bool A_KC, bool B_KC>
+int launch_h(const ofb_gemm_h_args& g, const Plan& p, hipStream_t s) {
+  if (g.Cp || g.cbound_out) hipLaunchKernelGGL(gemm_h_bound_kernel, dim3(1), dim3(256), 0, s, g);
+  if (p.full_rounds > 0) {
+    const int f = (g.C ? E_C : 0) | (g.Cp ? E_P : 0) | (g.act == OFB_ACT_GELU ? E_GELU : 0) | (g.act == OFB_ACT_DGELU ? E_DGELU : 0) |
+                  (g.act == OFB_ACT_GELU_GRAD ? E_GELUG : 0) | (g.act == OFB_ACT_MULAUX ? E_MULAUX : 0) |
+                  (g.rowscale ? E_RS : 0) | (g.resid ? E_RES : 0);
+    switch (f) {     // the forms the model issues; anything else takes the generic (run-time flags) instantiation
+      case E_C: launch_full<CF, A_KC, B_KC, E_C>(g, p, s); break;
+      case E_C | E_RES: launch_full<CF, A_KC, B_KC, E_C | E_RES>(g, p, s); break;
+      case E_C | E_RS | E_RES: launch_full<CF, A_KC, B_KC, E_C | E_RS | E_RES>(g, p, s); break;
+      case E_P | E_GELUG: launch_full<CF, A_KC, B_KC, E_P | E_GELUG>(g, p, s); break;
+      case E_P | E_MULAUX: launch_full<CF, A_KC, B_KC, E_P | E_MULAUX>(g, p, s); break;
+      case E_P: launch_full<CF, A_KC, B_KC, E_P>(g, p, s); break;
+      default: launch_full<CF, A_KC, B_KC, E_ANY>(g, p, s); break;
+    }
+  }
+  if (p.R > 0) {
+    hipLaunchKernelGGL((gemm_h_kernel<CF, A_KC, B_KC, true, 0>), dim3(p.W), dim3(CF::NT), 0, s, g, p);
+    hipLaunchKernelGGL(gemm_h_fixup_kernel<CF>, dim3(p.R, CF::BM / 4), dim3(CF::BN), 0, s, g, p);
+  }
+  return ofb_launch_status();
+}
+
+template <class CF>
+int run_h(const ofb_gemm_h_args& g, hipStream_t s) {
+  const Plan p = plan_h<CF>(g);
+  if ((long long)p.W * p.I > 0x7fffffffLL / 2) return OFB_ELIMIT;
+  if (p.R && (!g.workspace || g.workspace_bytes < (int64_t)2 * p.W * CF::BM * CF::BN * (int64_t)sizeof(float))) return OFB_EINVAL;
+  if (g.a_kc && g.b_kc) return launch_h<CF, true, true>(g, p, s);
+  if (g.a_kc) return launch_h<CF, true, false>(g, p, s);
+  return launch_h<CF, false, false>(g, p, s);
+}
+
+}  // namespace
+
+extern "C" int64_t ofb_hformat_bytes(int32_t R, int32_t C) {
+  if (R <= 0 || C <= 0) return 0;
+  // Tile-granular reads run past the matrix: mode KC reads whole 128- / 192- / 256-row tiles and one granule column past an odd K16
+  // count, so the row groups are allocated up to the next 256-row boundary plus one more 256-row tile; mode KR reads whole tiles of
+  // columns and up to 8 row groups per stage.  The slack is never initialised and only ever feeds accumulators that are not stored
+  // (rows / columns beyond the matrix) or MFMAs that are not issued (the second half of an odd last stage).
+  const int64_t ncb = (C + 15) / 16, rgs = (int64_t)((R + 255) / 256) * 64 + 64;
+  return OFB_HHDR + (rgs * ncb + 16) * GRAN;
+}
+
+extern "C" int ofb_to_hformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
+                              void* stream) {
+  if (!X || !P || R <= 0 || C <= 0 || ld < C) return OFB_EINVAL;
+  if (rowscale && rs_div <= 0) return OFB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4;
+  if (hipMemsetAsync(P, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
+  const int nb = ofb_cdiv(R, 4) < 512 ? ofb_cdiv(R, 4) : 512;
+  hipLaunchKernelGGL(hstat_kernel, dim3(nb), dim3(256), 0, s, X, R, C, ld, (ofb_hhdr*)P, rowscale, rs_div);
+  hipLaunchKernelGGL(to_hformat_kernel, dim3((ncb * 16 + 255) / 256, rgs), dim3(256), 0, s, X, R, C, ld, (char*)P, ncb, rowscale, rs_div);
+  return ofb_launch_status();
+}
+
+// img [B][Cin][H][W] -> planes of the patch matrix [B * (H/patch) * (W/patch)][Cin * patch * patch]
+extern "C" int ofb_patchify_hformat(const float* img, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* P, void* stream) {
+  if (!img || !P || B <= 0 || Cin <= 0 || H <= 0 || W <= 0 || patch <= 0 || H % patch || W % patch) return OFB_EINVAL;
+  const int64_t R = (int64_t)B * (H / patch) * (W / patch), Cc = (int64_t)Cin * patch * patch;
+  if (R > 0x7fffffff / 4 || Cc > 65536) return OFB_ELIMIT;
+  hipStream_t s = (hipStream_t)stream;
+  const int ncb = (int)((Cc + 15) / 16), rgs = (int)(((R + 15) / 16) * 4);
+  if (hipMemsetAsync(P, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
+  hipLaunchKernelGGL(hstat_flat_kernel, dim3(512), dim3(256), 0, s, img, (size_t)B * Cin * H * W, (ofb_hhdr*)P);
+  hipLaunchKernelGGL(patchify_hformat_kernel, dim3((ncb * 16 + 255) / 256, rgs), dim3(256), 0, s, img, B, Cin, H, W, patch, (char*)P, ncb);
+  return ofb_launch_status();
+}
+
+// jobs_dev: n_jobs descriptors in device memory; max_R / max_C: the largest R and C among them (grid extent); scratch: n_jobs * 64 floats
+extern "C" int ofb_to_hformat_multi(const ofb_pformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, float* scratch,
+                                    void* stream) {
+  if (!jobs_dev || !scratch || n_jobs <= 0 || n_jobs > 65535 || max_R <= 0 || max_C <= 0) return OFB_EINVAL;
+  const int ncb = (max_C + 15) / 16, rgs = ((max_R + 15) / 16) * 4;
+  hipLaunchKernelGGL(hstat_multi_kernel, dim3(HM_NB, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, scratch);
+  hipLaunchKernelGGL(to_hformat_multi_kernel, dim3((ncb * 16 + 255) / 256, rgs, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev, scratch);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_to_hformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
+                                     float* partial, void* stream) {
+  if (!X || !P || !partial || R <= 0 || C <= 0 || ld < C) return OFB_EINVAL;
+  if (rowscale && rs_div <= 0) return OFB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4, slabs = (rgs + CS_SLAB_RG - 1) / CS_SLAB_RG;
+  if (hipMemsetAsync(P, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
+  const int nb = ofb_cdiv(R, 4) < 512 ? ofb_cdiv(R, 4) : 512;
+  hipLaunchKernelGGL(hstat_kernel, dim3(nb), dim3(256), 0, s, X, R, C, ld, (ofb_hhdr*)P, rowscale, rs_div);
+  hipLaunchKernelGGL(to_hformat_colsum_kernel, dim3((ncb * 16 + 63) / 64, slabs), dim3(256), 0, s, X, R, C, ld, (char*)P, ncb, rgs, rowscale,
+                     rs_div, partial);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_from_hformat(const void* P, int32_t R, int32_t C, float* X, int32_t ld, void* stream) {
+  if (!X || !P || R <= 0 || C <= 0 || ld < C) return OFB_EINVAL;
+  const int ncb = (C + 15) / 16, rgs = (R + 3) / 4;
+  hipLaunchKernelGGL(from_hformat_kernel, dim3((C + 255) / 256, rgs), dim3(256), 0, (hipStream_t)stream, (const char*)P, ncb, X, R, C, ld);
+  return ofb_launch_status();
+}
+
+extern "C" int32_t ofb_colsum_h_slabs(int32_t R) { return R > 0 ? (((R + 15) / 16) * 4 + CS_SLAB_RG - 1) / CS_SLAB_RG : 0; }
+
+extern "C" int ofb_colsum_h(const void* P, int32_t R, int32_t C, float* partial, void* stream) {
+  if (!P || !partial || R <= 0 || C <= 0) return OFB_EINVAL;
+  const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4, slabs = ofb_colsum_h_slabs(R);
+  hipLaunchKernelGGL(colsum_h_kernel, dim3((ncb + 3) / 4, slabs), dim3(256), 0, (hipStream_t)stream, (const char*)P, ncb, rgs, partial, ncb * 16);
+  return ofb_launch_status();
+}
+
+extern "C" int64_t ofb_gemm_h_workspace_bytes(const ofb_gemm_h_args* args) {
+  if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+  const int tile = h_tile_choice(*args);
+  if (tile == 96) { const Plan p = plan_h<C96>(*args); return p.R ? (int64_t)2 * p.W * C96::BM * C96::BN * (int64_t)sizeof(float) : 0; }
+  const Plan p = plan_h<C128>(*args);
+  return p.R ? (int64_t)2 * p.W * C128::BM * C128::BN * (int64_t)sizeof(float) : 0;
+}
+
+extern "C" int32_t ofb_gemm_h_colpart_rows(const ofb_gemm_h_args* args) {
+  if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+  ofb_gemm_h_args g = *args;
+  if (!g.colpart) g.colpart = reinterpret_cast<float*>(16);
+  const Plan p = plan_h<C128>(g);
+  return p.R ? (p.mt - p.R / p.nt) + (p.R / p.nt) * (C128::BM / 4) : p.mt;
+}
+
+extern "C" int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream) {
+  if (!args) return OFB_EINVAL;
+  const ofb_gemm_h_args& g = *args;
+  if (!g.A || !g.B || (!g.C && !g.Cp) || g.M <= 0 || g.N <= 0 || g.K <= 0) return OFB_EINVAL;
+  if (g.a_kc == 0 && g.b_kc == 1) return OFB_ELIMIT;           // A^T * B^T is not on the path
+  if (g.colpart && C128::BM != 128) return OFB_ELIMIT;
+  if (g.rowscale && g.rs_div <= 0) return OFB_EINVAL;
+  if (g.act < OFB_ACT_NONE || g.act > OFB_ACT_MULAUX) return OFB_EINVAL;
+  if ((g.act == OFB_ACT_DGELU || g.act == OFB_ACT_GELU_GRAD || g.act == OFB_ACT_MULAUX) && !g.aux) return OFB_EINVAL;
+  if (g.C && g.ldc < g.N) return OFB_EINVAL;
+  if (g.Cp && g.c_ncb < (g.N + 15) / 16) return OFB_EINVAL;
+  if (g.Cp && g.resid && !g.out_bound) return OFB_ELIMIT;      // no bound for a residual sum without scanning it: the caller supplies one
+  if (g.a_ncb < ((g.a_kc ? g.K : g.M) + 15) / 16 || g.b_ncb < ((g.b_kc ? g.K : g.N) + 15) / 16) return OFB_EINVAL;
+  if (!ofb_aligned16(g.A) || !ofb_aligned16(g.B) || (g.Cp && !ofb_aligned16(g.Cp))) return OFB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  ofb_prof_pre(0, s, 2.0 * g.M * g.N * (double)g.K);
+  const int tile = h_tile_choice(g);
+#ifdef OFB_GEMM_H_LAB
+  const int rc = tile == 1281 ? run_h<C128K1>(g, s) : (tile == 96 ? run_h<C96>(g, s) : run_h<C128>(g, s));
+#else
+  const int rc = tile == 96 ? run_h<C96>(g, s) : run_h<C128>(g, s);
+#endif
+  ofb_prof_post(0, s);
+  return rc;
+}

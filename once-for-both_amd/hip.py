@@ -21,6 +21,7 @@ ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
+    'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs',
     'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_gemm_p_colpart_rows', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_patchify_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_fwd_p', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
@@ -481,6 +482,83 @@ def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bia
         ws = _workspace(A.buf.device, need)
         g.workspace, g.workspace_bytes = ptr(ws), ws.numel() * 4
     check(lib().ofb_gemm_p(C.byref(g), stream()), 'ofb_gemm_p')
+    if want_colpart:
+        return part
+    if part is not None:
+        colsum(part, N, part.shape[0], N, colsum_out)
+
+
+# ---- H-format GEMM (csrc/gemm_h.hip): operands as two f16 planes of a power-of-two scaled copy + a device-side header ----------
+class GemmHArgs(C.Structure):
+    _fields_ = GemmPArgs._fields_ + [('aux_bound', C.c_float), ('out_bound', C.c_void_p), ('cbound_out', C.c_void_p)]
+
+
+class HMat:
+    """A matrix X[R][C] in H-format (csrc/hformat.h).  `buf`: uint8 device tensor of ofb_hformat_bytes(R, C) bytes, header first."""
+    __slots__ = ('buf', 'R', 'C', 'ncb')
+
+    def __init__(self, R, C_, device, buf=None):
+        f = lib().ofb_hformat_bytes
+        f.restype = C.c_int64
+        self.R, self.C, self.ncb = int(R), int(C_), (int(C_) + 15) // 16
+        self.buf = buf if buf is not None else torch.empty(int(f(_i(R), _i(C_))), device=device, dtype=torch.uint8)
+
+    def to_f32(self):
+        out = torch.empty(self.R, self.C, device=self.buf.device, dtype=torch.float32)
+        check(lib().ofb_from_hformat(ptr(self.buf), _i(self.R), _i(self.C), ptr(out), _i(self.C), stream()), 'ofb_from_hformat')
+        return out
+
+    def header(self):
+        """(e, amax, rn2sq, cn2sq) - host copy for tests / diagnostics only (syncs)"""
+        h = self.buf[:16].cpu()
+        return int(h.view(torch.int32)[0]), float(h.view(torch.float32)[1]), float(h.view(torch.float32)[2]), float(h.view(torch.float32)[3])
+
+
+def to_hformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1, colsum_out=None, into=None):
+    if R is None:
+        R, Cc = x.shape
+    if ld is None:
+        ld = x.stride(0) if x.dim() == 2 else Cc
+    if x.dtype != torch.float32:
+        raise OfbError('to_hformat needs float32 input')
+    pm = into if into is not None else HMat(R, Cc, x.device)
+    if colsum_out is not None:
+        slabs, ldp = int(lib().ofb_colsum_h_slabs(_i(R))), pm.ncb * 16
+        part = torch.empty(slabs, ldp, device=x.device, dtype=torch.float32)
+        check(lib().ofb_to_hformat_colsum(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(part), stream()),
+              'ofb_to_hformat_colsum')
+        colsum(part, ldp, slabs, Cc, colsum_out)
+        return pm
+    check(lib().ofb_to_hformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), stream()), 'ofb_to_hformat')
+    return pm
+
+
+def gemm_h(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
+           resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, colsum_out=None, want_colpart=False, aux_bound=0.0, out_bound=None,
+           cbound_out=None):
+    """C[M][N] (f32 and / or H-format) = A * B on H-format operands (HMat); arguments as gemm_p."""
+    g = GemmHArgs()
+    g.A, g.B, g.a_kc, g.b_kc, g.a_ncb, g.b_ncb = ptr(A.buf), ptr(B.buf), int(a_kc), int(b_kc), A.ncb, B.ncb
+    g.M, g.N, g.K = M, N, K
+    g.C, g.ldc = ptr(C_out), ldc
+    if Cp is not None:
+        if Cp.R != M or Cp.C != N:
+            raise OfbError('H-format output must be [M][N]')
+        g.Cp, g.c_ncb = ptr(Cp.buf), Cp.ncb
+    g.alpha, g.bias, g.colscale, g.rowscale, g.rs_div = alpha, ptr(bias), ptr(colscale), ptr(rowscale), rs_div
+    g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
+    g.aux_bound, g.out_bound, g.cbound_out = aux_bound, ptr(out_bound), ptr(cbound_out)
+    part = None
+    if colsum_out is not None or want_colpart:
+        rows = int(lib().ofb_gemm_h_colpart_rows(C.byref(g)))
+        part = torch.empty(rows, N, device=A.buf.device, dtype=torch.float32)
+        g.colpart = ptr(part)
+    lib().ofb_gemm_h_workspace_bytes.restype = C.c_int64
+    need = lib().ofb_gemm_h_workspace_bytes(C.byref(g))
+    if need > 0:
+        ws = _workspace(A.buf.device, need)
+        g.workspace, g.workspace_bytes = ptr(ws), ws.numel() * 4
+    check(lib().ofb_gemm_h(C.byref(g), stream()), 'ofb_gemm_h')
     if want_colpart:
         return part
     if part is not None:
