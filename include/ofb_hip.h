@@ -27,91 +27,51 @@ extern "C" {
 #define OFB_ACT_NONE 0
 #define OFB_ACT_GELU 1      /* aux <- pre-activation (if aux), C <- gelu_erf(pre)            */
 #define OFB_ACT_DGELU 2     /* C <- value * gelu_erf'(aux[m][n])                              */
-/* ofb_gemm_p only: the forward saves the DERIVATIVE (it has Phi and phi in hand already), the backward epilogue is one multiply */
+/* the forward saves the DERIVATIVE (it has Phi and phi in hand already), the backward epilogue is one multiply */
 #define OFB_ACT_GELU_GRAD 3 /* aux <- gelu_erf'(pre) (aux required), C <- gelu_erf(pre)       */
 #define OFB_ACT_MULAUX 4    /* C <- value * aux[m][n]                                         */
 
 /* ---------------------------------------------------------------------------------------------
- * Dense f32 contraction on the bf16 matrix pipe (csrc/gemm_p.hip; v_mfma_f32_32x32x16_bf16, six product terms of an exact 3-way
- * operand split x = hi + mid + lo, f32 accumulation: fp32-class accuracy, tests/test_gpu_accuracy_class.py):
+ * Dense f32-class contraction on the f16 matrix pipe (csrc/gemm_h.hip, csrc/hformat.h):
  *   C[M,N] = A[M,K] * B[K,N], then  v = alpha*acc (+bias[n]) (*colscale[n]); act; (*rowscale[m / rs_div]); (+resid[m*ldr+n]).
- * The operands arrive ALREADY split into three bf16 planes ("P-format"): the split is done ONCE by the producer of each tensor
- * (LayerNorm, attention, GEMM epilogues, ofb_to_pformat* for everything else) instead of inside every GEMM tile that touches it,
- * and the K loop is LDS-DMA + fragment reads + MFMAs only.  Every nn.Linear / Conv2d-as-GEMM of the path and its autograd runs
- * here: x @ W^T (models/layers.py:491,515,845,863; patch embed :177; decoder 1x1 conv vision_transformer.py:723; head :744),
- * dY @ W (input gradient) and dY^T @ X (weight gradient, reduction over tokens).  (The round-1 entry point that split f32
- * operands inside the loop, ofb_gemm_f32, left the library in round 3: scripts/lab/gemm_split_engine_r1.hip.)
+ * Every operand value is held as TWO f16 numbers of a power-of-two scaled copy, X 2^e = h1 + h2 ("H-format": 22 explicit significand
+ * bits + the roundings' sign tricks, |X 2^e - h1 - h2| <= 2^-24 |X 2^e|), and every product is three v_mfma_f32_32x32x16_f16 terms
+ * (h2 h1, h1 h2, h1 h1; the dropped h2 h2 is <= 2^-24 of the product) with f32 accumulation: per-product error <= 3 2^-24, measured
+ * at or below a k-ordered f32 fma chain (tests/test_gpu_accuracy_class.py).  (Rounds 1-3 used an exact three-way bf16 split with six
+ * terms: twice the matrix-pipe work and 1.5x the operand bytes - on a power-limited chip 1.4-1.7x the time,
+ * profiles/r04_gemm_h_vs_p_step_shapes_v1.txt; scripts/lab/gemm_p_bf16x3_round3.hip.)
+ * The operands arrive ALREADY split: the split is done ONCE by the producer of each tensor (LayerNorm, attention, GEMM epilogues,
+ * ofb_to_hformat* for everything else) instead of inside every GEMM tile that touches it, and the K loop is LDS-DMA + fragment reads
+ * + MFMAs only.  Every nn.Linear / Conv2d-as-GEMM of the path and its autograd runs here: x @ W^T (models/layers.py:491,515,845,863;
+ * patch embed :177; decoder 1x1 conv vision_transformer.py:723; head :744), dY @ W (input gradient) and dY^T @ X (weight gradient,
+ * reduction over tokens).
  * Scheduling is hybrid stream-K over persistent workgroups (csrc/gemm_plan.h): tiles that do not fill a whole round of
  * workgroups are cut along K and summed in a fixed order by a fix-up launch (deterministic).  `workspace` must hold
- * ofb_gemm_p_workspace_bytes(args) bytes (0 when no tile is streamed); successive calls on ONE stream may share it.
+ * ofb_gemm_h_workspace_bytes(args) bytes (0 when no tile is streamed); successive calls on ONE stream may share it.
  *
- * P-format of X[R][C]: granules of 4 rows x 16 columns (384 B), stored [ceil(R/16)*4][ncb = ceil(C/16)]; a granule holds
- * [plane hi|mid|lo][c % 16][r % 4] bf16.  Rows >= R / columns >= C inside the last granules are ZERO (the reduction axis
- * relies on it).  A buffer needs ofb_pformat_bytes(R, C) bytes (tile-granular reads run past the matrix; that slack is never
- * initialised and only reaches accumulators that are not stored).
- * a_kc / b_kc = 1: the reduction runs along the columns C of that operand's P matrix (x[M][K], W[N][K]: nn.Linear forward,
+ * H-format of X[R][C] (ofb_hformat_bytes(R, C) bytes): [256-B header {int32 e; f32 amax, rn2sq, cn2sq}][granules of 4 rows x 16
+ * columns, 256 B, stored [ceil(R/16)*4][ncb = ceil(C/16)]; a granule holds [plane h1|h2][c % 16][r % 4] f16].  Rows >= R / columns
+ * >= C inside the last granules are ZERO (the reduction axis relies on it); tile-granular reads run past the matrix into slack that
+ * is never initialised and only reaches accumulators that are not stored.  The header is written and read on the DEVICE only: e is
+ * chosen by the producer from an upper bound b >= max|X| so that b 2^e lies in [2^14, 2^15); elements >= 2^-18 b keep the full
+ * relative accuracy, smaller ones an absolute accuracy of 2^-40 b.  amax / rn2sq / cn2sq (bounds of max|X| and of the largest
+ * squared row / column 2-norm; 0 = unknown) feed the Cauchy-Schwarz bound with which a GEMM that WRITES H-format chooses its output's
+ * exponent before its first tile is finished.
+ * a_kc / b_kc = 1: the reduction runs along the columns C of that operand's matrix (x[M][K], W[N][K]: nn.Linear forward,
  * models/layers.py:491,515,845,863); 0: along its rows R (W[K..][N] in dY @ W; dY[tokens][N], x[tokens][K] in dY^T @ x).
- * So the SAME P-format copy of an activation or weight feeds its forward, input-gradient and weight-gradient products.
- * Output: f32 C (ldc) and / or P-format Cp ([R = M][C = N], c_ncb granule columns) - e.g. gelu(fc1) leaves the kernel as the
- * P-format operand of fc2 plus the f32 pre-activation in aux.  Deterministic (fixed-order fix-up).
+ * So the SAME H-format copy of an activation or weight feeds its forward, input-gradient and weight-gradient products.
+ * Output: f32 C (ldc) and / or H-format Cp ([R = M][C = N], c_ncb granule columns) - e.g. gelu(fc1) leaves the kernel as the
+ * H-format operand of fc2 plus the f32 gelu'(pre-activation) in aux.  An H-format output needs its exponent first: a one-block
+ * pre-kernel bounds |output| from the operand headers and the epilogue inputs (bias, colscale, rowscale are scanned; aux_bound
+ * bounds |aux| of the multiplying activations, default 1.13 = max gelu'); out_bound (device scalar) overrides that bound and is
+ * required with resid.  cbound_out (optional device scalar) receives the bound of an f32 output for the consumer that will split
+ * it (attention).  colpart: optional [ofb_gemm_h_colpart_rows(args)][N] partial column sums of the OUTPUT (one row per 128-row
+ * tile row; 32 rows per tile row that runs in the streamed tail), each summed in a fixed order: the bias gradient of an
+ * H-format-only result, e.g. d(pre-activation) of fc1; add the rows with ofb_colsum.
  * ------------------------------------------------------------------------------------------- */
-typedef struct ofb_gemm_p_args {
-  const void* A; const void* B;
-  int32_t a_kc, b_kc;
-  int32_t a_ncb, b_ncb;      /* granule columns of each operand's P matrix */
-  int32_t M, N, K;
-  float* C; int32_t ldc;     /* f32 output or NULL */
-  void* Cp; int32_t c_ncb;   /* P-format output or NULL */
-  float alpha;
-  const float* bias;
-  const float* colscale;
-  const float* rowscale; int32_t rs_div;
-  const float* resid; int32_t ldr;
-  float* aux; int32_t ldaux;
-  int32_t act;
-  float* workspace; int64_t workspace_bytes;
-  float* colpart;            /* optional [ofb_gemm_p_colpart_rows(args)][N]: partial column sums of the OUTPUT (one row per 128-row tile
-                                row; 32 rows per tile row that runs in the streamed tail), each summed in a fixed order: the bias
-                                gradient of a P-format-only result, e.g. d(pre-activation) of fc1; add the rows with ofb_colsum */
-} ofb_gemm_p_args;
-int32_t ofb_gemm_p_colpart_rows(const ofb_gemm_p_args* args);
-
-int64_t ofb_pformat_bytes(int32_t R, int32_t C);
-/* X[R][C] (row-major, ld), optionally * rowscale[r / rs_div]  ->  P-format (zero padded).  Used for tensors whose producer is
- * not one of the kernels below (weights once per optimizer step, DropPath-scaled gradients, patchified pixels). */
-int ofb_to_pformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div, void* stream);
-/* The patch matrix of the patch-embedding conv (models/layers.py:177: Conv2d with kernel = stride = patch is patchify + Linear) written
- * as planes straight from the images: P[(b, py, px)][(c, i, j)] = img[b][c][py*patch + i][px*patch + j]; no f32 copy of it exists. */
-int ofb_patchify_pformat(const float* img, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* P, void* stream);
-/* Many conversions in one launch (the model's weights, once per optimizer step; the gate-scaled weights of one backward pass):
- * jobs_dev[n_jobs] in device memory, each {X (f32 [R][C], row stride ld), P (ofb_pformat_bytes(R, C) bytes), rowscale (optional:
- * row r is multiplied by rowscale[r]), R, C, ld}; max_R / max_C = the largest R / C among them. */
+/* one conversion job of ofb_to_hformat_multi: X (f32 [R][C], row stride ld) -> P (ofb_hformat_bytes(R, C) bytes), row r
+ * optionally multiplied by rowscale[r] */
 typedef struct ofb_pformat_job { const float* X; void* P; const float* rowscale; int32_t R, C, ld, pad_; } ofb_pformat_job;
-int ofb_to_pformat_multi(const ofb_pformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, void* stream);
-/* the same pass also leaves partial[ofb_colsum_p_slabs(R)][ceil(C/16)*16] = column sums per 256-row slab (sum them with ofb_colsum):
- * a bias gradient db = colsum(dY) rides on the conversion of dY */
-int ofb_to_pformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
-                          float* partial, void* stream);
-int ofb_from_pformat(const void* P, int32_t R, int32_t C, float* X, int32_t ld, void* stream);   /* exact: hi + mid + lo */
-/* column sums of a P-format matrix, first stage: partial[ofb_colsum_p_slabs(R)][ceil(C/16)*16] (rows of a 256-row slab added in
- * order); sum the slabs with ofb_colsum.  Bias gradients of tensors that exist only in P-format. */
-int32_t ofb_colsum_p_slabs(int32_t R);
-int ofb_colsum_p(const void* P, int32_t R, int32_t C, float* partial, void* stream);
-int64_t ofb_gemm_p_workspace_bytes(const ofb_gemm_p_args* args);
-int ofb_gemm_p(const ofb_gemm_p_args* args, void* stream);
-
-/* ---------------------------------------------------------------------------------------------
- * Round 4 engine: the same contraction on operands split into TWO f16 planes of a power-of-two scaled copy ("H-format",
- * csrc/hformat.h, csrc/gemm_h.hip): X 2^e = h1 + h2, three v_mfma_f32_32x32x16_f16 terms per product (h2 h1, h1 h2, h1 h1), f32
- * accumulation.  Per-product error <= 3 2^-24; half the matrix-pipe work and two thirds of the operand bytes of the six-term bf16
- * form.  A buffer = [256-B header {int32 e; f32 amax, rn2sq, cn2sq}][granules of 4 rows x 16 columns, 256 B: [h1 | h2][c % 16][r % 4]
- * f16]; the header is written and read on the DEVICE only (the exponent of a tensor follows from data the host never sees).
- * Same modes, epilogues, outputs and stream-K scheduling as ofb_gemm_p.  An H-format OUTPUT needs its exponent before the first
- * tile is finished: a one-block pre-kernel bounds |output| by Cauchy-Schwarz from the operand headers and the epilogue inputs
- * (bias, colscale, rowscale are scanned; aux_bound bounds |aux| of the multiplying activations, default 1.13 = max gelu');
- * out_bound (device scalar) overrides that bound; with resid it is required.  cbound_out (optional, device scalar) receives the
- * bound of an f32 output for the consumer that will split it (attention).
- * ------------------------------------------------------------------------------------------- */
 typedef struct ofb_gemm_h_args {
   const void* A; const void* B;
   int32_t a_kc, b_kc;
@@ -134,12 +94,14 @@ typedef struct ofb_gemm_h_args {
 } ofb_gemm_h_args;
 int32_t ofb_gemm_h_colpart_rows(const ofb_gemm_h_args* args);
 int64_t ofb_hformat_bytes(int32_t R, int32_t C);
-int ofb_to_hformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div, void* stream);
+/* bound (optional device scalar >= max |X * rowscale|): skips the statistics pass that otherwise measures amax / row norms first */
+int ofb_to_hformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div, const float* bound,
+                   void* stream);
 int ofb_patchify_hformat(const float* img, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* P, void* stream);
 /* scratch: n_jobs * 64 floats (two-stage maxima of every job) */
 int ofb_to_hformat_multi(const ofb_pformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, float* scratch, void* stream);
 int ofb_to_hformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
-                          float* partial, void* stream);
+                          float* partial, const float* bound, void* stream);
 int ofb_from_hformat(const void* P, int32_t R, int32_t C, float* X, int32_t ld, void* stream);   /* (h1 + h2) 2^-e */
 int32_t ofb_colsum_h_slabs(int32_t R);
 int ofb_colsum_h(const void* P, int32_t R, int32_t C, float* partial, void* stream);
@@ -169,19 +131,21 @@ int ofb_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, void* stream);
  * ------------------------------------------------------------------------------------------- */
 int ofb_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                       int32_t rows, int32_t D, float eps, void* stream);
-/* y (optional, may be NULL) and the same rows as P-format planes y_p[rows][D] (the operand form of the following GEMM, see
- * ofb_gemm_p; ofb_pformat_bytes(rows, D) bytes).  Row groups 0 .. ceil(rows/4)-1 are written whole (padding as zeros); the caller
- * zeroes what is left of the last 16-row group when rows % 16 is in 1..12. */
-int ofb_layernorm_fwd_p(const float* x, const float* gamma, const float* beta, float* y, void* y_p, float* mean, float* rstd,
+/* y (optional, may be NULL) and the same rows as H-format planes y_h[rows][D] (the operand form of the following GEMM, see
+ * ofb_gemm_h; ofb_hformat_bytes(rows, D) bytes, header included: its exponent follows from gamma / beta alone, |y_i| <= sqrt(D)
+ * |gamma_i| + |beta_i|).  Row groups 0 .. ceil(rows/4)-1 are written whole (padding as zeros); the caller zeroes what is left of
+ * the last 16-row group when rows % 16 is in 1..12. */
+int ofb_layernorm_fwd_h(const float* x, const float* gamma, const float* beta, float* y, void* y_h, float* mean, float* rstd,
                         int32_t rows, int32_t D, float eps, void* stream);
 int32_t ofb_layernorm_bwd_blocks(int32_t rows);
 int ofb_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                       const float* dres, float* dx, float* partials, int32_t rows, int32_t D, void* stream);
 /* Same, and dx * rowscale[row / rs_div] (rowscale optional: the DropPath factor of the branch this gradient flows into) also as
- * P-format planes dx_p[rows][D]; partials is then [ofb_layernorm_bwd_blocks(rows)][3][D]: dgamma | dbeta | column sums of the
- * scaled dx rows (that branch's output-bias gradient). */
-int ofb_layernorm_bwd_p(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                        const float* dres, float* dx, float* partials, void* dx_p, const float* rowscale, int32_t rs_div,
+ * H-format planes dx_h[rows][D]; partials is then [ofb_layernorm_bwd_blocks(rows)][3][D]: dgamma | dbeta | column sums of the
+ * scaled dx rows (that branch's output-bias gradient).  The planes' exponent comes from a bound formed by a pass over dy before
+ * the main kernel: |dx_row|_2 <= rstd |gamma * dy_row|_2 (LayerNorm's Jacobian is rstd times an orthogonal projection). */
+int ofb_layernorm_bwd_h(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                        const float* dres, float* dx, float* partials, void* dx_h, const float* rowscale, int32_t rs_div,
                         int32_t rows, int32_t D, void* stream);
 
 /* out[N] = column sums of x[M][ld] (optionally rows scaled by rowscale[m / rs_div]): bias gradients of every
@@ -212,22 +176,21 @@ int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const 
  * further) its rounding residue (m - lse) + log l - the backward recomputes P = exp((S - lse) - residue) at fp32-softmax accuracy.
  * Limits: N <= 208 (13 tiles of 16 tokens), dh <= 64, dh % 4 == 0 (covers DeiT-T/S/B and every pruned d in {16,24,..,64}).
  * bwd writes dqkv in the same packing (dq | dk | dv).
+ * Both kernels split their operands into two f16 planes of a power-of-two scaled copy (csrc/hformat.h) and therefore need upper
+ * bounds of |qkv| and |dout| as DEVICE scalars: the cbound_out of the GEMMs that produced them (ofb_gemm_h), or ofb_amax.
  * ------------------------------------------------------------------------------------------- */
+int ofb_amax(const float* x, int64_t n, float* out, void* stream);     /* out[0] = max |x[i]| */
 int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32_t N, int32_t H, int32_t dh, float scale,
-                      void* stream);
+                      const float* qkv_bound, void* stream);
+/* dqkv_amax (optional device scalar) receives max |dqkv|: the bound for the H-format copy ofb_to_hformat_colsum makes of it */
 int ofb_attention_bwd(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv, int32_t B,
-                      int32_t N, int32_t H, int32_t dh, float scale, void* stream);
-/* Forward that also writes the output rows as P-format planes out_p[B*N][H*dh] (the operand of the projection GEMM; the values
- * of `out` exactly).  The caller zeroes out_p beforehand when B*N or H*dh is not a multiple of 16; needs N + (b*N mod 4) <= 208. */
-int ofb_attention_fwd_p(const float* qkv, float* out, void* out_p, float* lse, int32_t B, int32_t N, int32_t H, int32_t dh,
-                        float scale, void* stream);
-/* The same gradient written as P-format planes of the [B*N][3*H*dh] matrix (ofb_pformat_bytes(B*N, 3*H*dh) bytes; the operand form
- * of the qkv gradient GEMMs, see ofb_gemm_p) - exactly the f32 values ofb_attention_bwd writes - plus colpart[B][3*H*dh], the
- * column sums over each image's tokens (their sum over B is the raw qkv bias gradient).  The kernel writes the
- * B*N x 3*H*dh elements only: when B*N or 3*H*dh is not a multiple of 16 the caller zeroes the buffer beforehand (padding rows
- * and columns of a P-format matrix are zero). */
-int ofb_attention_bwd_p(const float* qkv, const float* out, const float* lse, const float* dout, void* dqkv_p, float* colpart,
-                        int32_t B, int32_t N, int32_t H, int32_t dh, float scale, void* stream);
+                      int32_t N, int32_t H, int32_t dh, float scale, const float* qkv_bound, const float* dout_bound,
+                      float* dqkv_amax, void* stream);
+/* Forward that also writes the output rows as H-format planes out_h[B*N][H*dh] (the operand of the projection GEMM; the values
+ * of `out`; |out| <= max |v|, so the planes take the qkv exponent).  The caller zeroes out_h beforehand when B*N or H*dh is not a
+ * multiple of 16; needs N + (b*N mod 4) <= 208. */
+int ofb_attention_fwd_h(const float* qkv, float* out, void* out_h, float* lse, int32_t B, int32_t N, int32_t H, int32_t dh,
+                        float scale, const float* qkv_bound, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Bi-mask gates of ALL searchable modules in one launch + adaptive one-hot (sparsity) loss + FLOPs loss.

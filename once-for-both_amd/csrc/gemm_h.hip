@@ -101,6 +101,10 @@ __global__ __launch_bounds__(256) void hstat_flat_kernel(const float* __restrict
   if (threadIdx.x == 0) ofb_atomic_max_pos(&hdr->amax, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
+__global__ void hhdr_from_bound_kernel(ofb_hhdr* __restrict__ hdr, const float* __restrict__ bound) {
+  hdr->e = 0; hdr->amax = bound[0]; hdr->rn2sq = 0.f; hdr->cn2sq = 0.f;
+}
+
 // Stage 2: X[R][C] row-major (ld) -> planes; e from hdr.amax (every thread reads the same word; block (0,0) records e)
 __global__ void to_hformat_kernel(const float* __restrict__ X, int R, int C, int ld, char* __restrict__ P, int ncb,
                                   const float* __restrict__ rowscale, int rs_div) {
@@ -899,15 +903,27 @@ extern "C" int64_t ofb_hformat_bytes(int32_t R, int32_t C) {
   return OFB_HHDR + (rgs * ncb + 16) * GRAN;
 }
 
+namespace {
+// header.amax for the conversion kernels: measured (memset + statistics pass) or the caller's bound
+int h_prepare_header(const float* X, int R, int C, int ld, void* P, const float* rowscale, int rs_div, const float* bound, hipStream_t s) {
+  if (bound) {
+    hipLaunchKernelGGL(hhdr_from_bound_kernel, dim3(1), dim3(1), 0, s, (ofb_hhdr*)P, bound);
+    return 0;
+  }
+  if (hipMemsetAsync(P, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
+  const int nb = ofb_cdiv(R, 4) < 512 ? ofb_cdiv(R, 4) : 512;
+  hipLaunchKernelGGL(hstat_kernel, dim3(nb), dim3(256), 0, s, X, R, C, ld, (ofb_hhdr*)P, rowscale, rs_div);
+  return 0;
+}
+}  // namespace
+
 extern "C" int ofb_to_hformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
-                              void* stream) {
+                              const float* bound, void* stream) {
   if (!X || !P || R <= 0 || C <= 0 || ld < C) return OFB_EINVAL;
   if (rowscale && rs_div <= 0) return OFB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4;
-  if (hipMemsetAsync(P, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
-  const int nb = ofb_cdiv(R, 4) < 512 ? ofb_cdiv(R, 4) : 512;
-  hipLaunchKernelGGL(hstat_kernel, dim3(nb), dim3(256), 0, s, X, R, C, ld, (ofb_hhdr*)P, rowscale, rs_div);
+  if (int rc = h_prepare_header(X, R, C, ld, P, rowscale, rs_div, bound, s)) return rc;
   hipLaunchKernelGGL(to_hformat_kernel, dim3((ncb * 16 + 255) / 256, rgs), dim3(256), 0, s, X, R, C, ld, (char*)P, ncb, rowscale, rs_div);
   return ofb_launch_status();
 }
@@ -936,14 +952,12 @@ extern "C" int ofb_to_hformat_multi(const ofb_pformat_job* jobs_dev, int32_t n_j
 }
 
 extern "C" int ofb_to_hformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
-                                     float* partial, void* stream) {
+                                     float* partial, const float* bound, void* stream) {
   if (!X || !P || !partial || R <= 0 || C <= 0 || ld < C) return OFB_EINVAL;
   if (rowscale && rs_div <= 0) return OFB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4, slabs = (rgs + CS_SLAB_RG - 1) / CS_SLAB_RG;
-  if (hipMemsetAsync(P, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
-  const int nb = ofb_cdiv(R, 4) < 512 ? ofb_cdiv(R, 4) : 512;
-  hipLaunchKernelGGL(hstat_kernel, dim3(nb), dim3(256), 0, s, X, R, C, ld, (ofb_hhdr*)P, rowscale, rs_div);
+  if (int rc = h_prepare_header(X, R, C, ld, P, rowscale, rs_div, bound, s)) return rc;
   hipLaunchKernelGGL(to_hformat_colsum_kernel, dim3((ncb * 16 + 63) / 64, slabs), dim3(256), 0, s, X, R, C, ld, (char*)P, ncb, rgs, rowscale,
                      rs_div, partial);
   return ofb_launch_status();

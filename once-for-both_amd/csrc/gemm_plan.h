@@ -1,5 +1,4 @@
-// Hybrid stream-K work plan shared by the GEMM kernels (gemm.hip: f32 operands split in the loop; gemm_p.hip: pre-split
-// P-format operands).  W persistent workgroups; output tiles that fill whole rounds of W run data-parallel with the epilogue
+// Hybrid stream-K work plan of the GEMM kernel (gemm_h.hip: pre-split H-format operands).  W persistent workgroups; output tiles that fill whole rounds of W run data-parallel with the epilogue
 // fused; the R = tiles mod W remaining tiles are cut along K, written as raw partial tiles and summed in a FIXED order.
 #pragma once
 #include "ofb_common.h"

@@ -17,32 +17,7 @@ static inline int ofb_cdiv(int a, int b) { return (a + b - 1) / b; }
 void ofb_prof_pre(int tag, hipStream_t s, double work);
 void ofb_prof_post(int tag, hipStream_t s);
 
-// ---- P-format (csrc/gemm_p.hip): a matrix as three bf16 planes in granules of 4 rows x 16 columns, 384 B each, stored
-// [rows / 4][ncb = ceil(C / 16)]; inside a granule [plane hi | mid | lo][c % 16][r % 4] ----
-#define OFB_PGRAN 384
-typedef __bf16 ofb_bf16x2 __attribute__((ext_vector_type(2)));
 typedef float ofb_f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned ofb_pk_bf16(float a, float b) {      // v_cvt_pk_bf16_f32: a -> low half, b -> high half (RNE)
-  ofb_f32x2 v = {a, b};
-  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, ofb_bf16x2));
-}
-// x = hi + mid + lo, each a bf16 (24 significant bits in total: exact for finite f32 in the normal range); two values at a time
-__device__ __forceinline__ void ofb_split_pair(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
-  hi = ofb_pk_bf16(a, b);
-  const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
-  mid = ofb_pk_bf16(ra, rb);
-  lo = ofb_pk_bf16(ra - __uint_as_float(mid << 16), rb - __uint_as_float(mid & 0xffff0000u));
-}
-// rows 4 rg .. 4 rg + 3 of column c -> the 8-byte column slot of each plane
-__device__ __forceinline__ void ofb_store_p4(char* __restrict__ P, int ncb, int rg, int c, float v0, float v1, float v2, float v3) {
-  char* slot = P + ((size_t)rg * ncb + (c >> 4)) * OFB_PGRAN + (c & 15) * 8;
-  unsigned h0, m0, l0, h1, m1, l1;
-  ofb_split_pair(v0, v1, h0, m0, l0);
-  ofb_split_pair(v2, v3, h1, m1, l1);
-  *reinterpret_cast<uint2*>(slot) = make_uint2(h0, h1);
-  *reinterpret_cast<uint2*>(slot + 128) = make_uint2(m0, m1);
-  *reinterpret_cast<uint2*>(slot + 256) = make_uint2(l0, l1);
-}
 
 // GELU(erf) pieces from ONE exponential: Phi(x) = 0.5 (1 + erf(x / sqrt2)) via the Abramowitz-Stegun 7.1.26 erfc form
 // (|error| <= 1.5e-7 on erf; measured 4e-7 max abs error on gelu / gelu' in fp32, below torch's own fp32 gelu error of

@@ -1,6 +1,6 @@
 // HBM-bound row kernels: LayerNorm forward/backward (wave per token row, wavefront reductions),
 // column sums (bias gradients, partial reductions) and the small weight-sized gate-folding kernels.
-#include "ofb_common.h"
+#include "hformat.h"
 
 namespace {
 
@@ -35,7 +35,25 @@ __device__ __forceinline__ void ln_store(const float (&v)[LN_MAXE], float* __res
   }
 }
 
-// PF: the normalised rows also leave as P-format planes yP (operand form of the following GEMM, csrc/gemm_p.hip): the four waves of
+// Exponent of LayerNorm's H-format output WITHOUT a pass over it: |xhat_i| <= sqrt(D) for every row, so
+//   |y_i| <= sqrt(D) |gamma_i| + |beta_i|   and   |y|_2 <= sqrt(D) max|gamma| + |beta|_2 .
+// Every wave derives the same numbers from the gamma / beta values its lanes hold (elements beyond D are zero).
+template <int NE>
+__device__ __forceinline__ void ln_out_bound(const float (&g)[NE], const float (&b)[NE], int D, float& binf, float& rn2sq) {
+  const float sd = sqrtf((float)D);
+  float m = 0.f, gm = 0.f, bs = 0.f;
+#pragma unroll
+  for (int i = 0; i < NE; ++i) {
+    m = fmaxf(m, sd * fabsf(g[i]) + fabsf(b[i]));
+    gm = fmaxf(gm, fabsf(g[i]));
+    bs += b[i] * b[i];
+  }
+  binf = ofb_wave_max_pos(m) * 1.0001f;
+  const float r = sd * ofb_wave_max_pos(gm) + sqrtf(ofb_wave_sum(bs));
+  rn2sq = r * r * 1.0002f;
+}
+
+// PF: the normalised rows also leave as H-format planes yP (operand form of the following GEMM, csrc/gemm_h.hip): the four waves of
 // a block hold the four rows of one row group; they meet in LDS and every thread writes whole 8-byte plane slots of its columns.
 template <int V, bool PF>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -46,11 +64,19 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, row = blockIdx.x * 4 + w;
   if (!PF && row >= rows) return;
   float v[LN_MAXE];
+  float g[LN_MAXE], b[LN_MAXE];
+  ln_load<V>(g, gamma, D, lane);
+  ln_load<V>(b, beta, D, lane);
+  float hs = 1.f;
+  if (PF) {
+    float binf, rn2;
+    ln_out_bound<LN_MAXE>(g, b, D, binf, rn2);
+    const int e = ofb_h_exp(binf);
+    hs = ofb_h_pow2(e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { ofb_hhdr* h = reinterpret_cast<ofb_hhdr*>(yP); h->e = e; h->amax = binf; h->rn2sq = rn2; h->cn2sq = 0.f; }
+  }
   if (row < rows) {
-    float g[LN_MAXE], b[LN_MAXE];
     ln_load<V>(v, x + (size_t)row * D, D, lane);
-    ln_load<V>(g, gamma, D, lane);
-    ln_load<V>(b, beta, D, lane);
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < LN_MAXE; ++i) s += v[i];
@@ -80,14 +106,16 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
     }
     __syncthreads();
     for (int c = threadIdx.x; c < Dp; c += 256)
-      ofb_store_p4(yP, Dp >> 4, blockIdx.x, c, tile[c], tile[64 * LN_MAXE + c], tile[2 * 64 * LN_MAXE + c], tile[3 * 64 * LN_MAXE + c]);
+      ofb_store_h4(yP + OFB_HHDR, Dp >> 4, blockIdx.x, c, tile[c] * hs, tile[64 * LN_MAXE + c] * hs, tile[2 * 64 * LN_MAXE + c] * hs,
+                   tile[3 * 64 * LN_MAXE + c] * hs);
   }
 }
 
 // dx = rstd * (dy*gamma - mean(dy*gamma) - xhat * mean(dy*gamma*xhat)) (+ dres); per-block partial dgamma/dbeta
-// PF: dx * rowscale[row / rs_div] also leaves as P-format planes dxP (the gradient w.r.t. the previous branch's output is the dY
+// PF: dx * rowscale[row / rs_div] also leaves as H-format planes dxP (the gradient w.r.t. the previous branch's output is the dY
 // operand of that branch's gradient GEMMs, DropPath factor applied), and part gets a third [D] section per block: the column sums
-// of those scaled rows (that branch's last bias gradient).
+// of those scaled rows (that branch's last bias gradient).  The planes' exponent comes from dxP's header.amax, which
+// ln_bwd_stat_kernel left there just before.
 template <int V, bool PF>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -105,6 +133,13 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
 #pragma unroll
   for (int k = 0; k < (PF ? 4 : 1); ++k) cacc[k] = 0.f;
   const int Dp = (D + 15) & ~15;
+  float hs = 1.f;
+  if (PF) {
+    ofb_hhdr* h = reinterpret_cast<ofb_hhdr*>(dxP);
+    const int e = ofb_h_exp(h->amax);
+    hs = ofb_h_pow2(e);
+    if (blockIdx.x == 0 && threadIdx.x == 0) h->e = e;
+  }
   for (int row0 = blockIdx.x * 4; row0 < rows; row0 += gridDim.x * 4) {
     const int row = row0 + w;
     float v[LN_MAXE];
@@ -153,7 +188,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
         if (c < Dp) {
           const float a0 = red[c], a1 = red[1024 + c], a2 = red[2048 + c], a3 = red[3072 + c];
           cacc[k] += (a0 + a1) + (a2 + a3);
-          ofb_store_p4(dxP, Dp >> 4, row0 >> 2, c, a0, a1, a2, a3);
+          ofb_store_h4(dxP + OFB_HHDR, Dp >> 4, row0 >> 2, c, a0 * hs, a1 * hs, a2 * hs, a3 * hs);
         }
       }
     }
@@ -182,25 +217,24 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   }
 }
 
-// ---- P-format variants for even D: one WAVE per row group (4 rows), lane owns the column pairs 2 (64 j + lane) + {0, 1}, j < NJ: the
+// ---- H-format variants for even D: one WAVE per row group (4 rows), lane owns the column pairs 2 (64 j + lane) + {0, 1}, j < NJ: the
 // four rows of a column sit in one lane's registers and leave as whole plane slots (two adjacent slots = one 16-byte store per
-// plane), with no LDS and no block barrier ----
+// plane), with no LDS and no block barrier.  P: the planes' base (behind the header); hs = 2^e ----
 template <int NJ>
-__device__ __forceinline__ void ln_p_store(char* __restrict__ P, int ncb, int rg, int lane, int Dp, const float (&v)[4][2 * NJ]) {
+__device__ __forceinline__ void ln_p_store(char* __restrict__ P, int ncb, int rg, int lane, int Dp, const float (&v)[4][2 * NJ], float hs) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = (j * 64 + lane) * 2;
     if (c < Dp) {
-      unsigned h[4], m[4], l[4];                            // [column e][row pair]
+      unsigned h[4], l[4];                                  // [column e][row pair]
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        ofb_split_pair(v[0][2 * j + e], v[1][2 * j + e], h[2 * e], m[2 * e], l[2 * e]);
-        ofb_split_pair(v[2][2 * j + e], v[3][2 * j + e], h[2 * e + 1], m[2 * e + 1], l[2 * e + 1]);
+        ofb_hsplit_pair(v[0][2 * j + e] * hs, v[1][2 * j + e] * hs, h[2 * e], l[2 * e]);
+        ofb_hsplit_pair(v[2][2 * j + e] * hs, v[3][2 * j + e] * hs, h[2 * e + 1], l[2 * e + 1]);
       }
-      char* slot = P + ((size_t)rg * ncb + (c >> 4)) * OFB_PGRAN + (c & 15) * 8;
+      char* slot = P + ((size_t)rg * ncb + (c >> 4)) * OFB_HGRAN + (c & 15) * 8;
       *reinterpret_cast<uint4*>(slot) = make_uint4(h[0], h[1], h[2], h[3]);
-      *reinterpret_cast<uint4*>(slot + 128) = make_uint4(m[0], m[1], m[2], m[3]);
-      *reinterpret_cast<uint4*>(slot + 256) = make_uint4(l[0], l[1], l[2], l[3]);
+      *reinterpret_cast<uint4*>(slot + 128) = make_uint4(l[0], l[1], l[2], l[3]);
     }
   }
 }
@@ -225,6 +259,10 @@ __global__ __launch_bounds__(256) void ln_fwd_p_kernel(const float* __restrict__
   float g[NE], b[NE], v[4][NE];
   ln_p_load<NJ>(g, gamma, D, lane);
   ln_p_load<NJ>(b, beta, D, lane);
+  float binf, rn2;
+  ln_out_bound<NE>(g, b, D, binf, rn2);
+  const int he = ofb_h_exp(binf);
+  if (blockIdx.x == 0 && threadIdx.x == 0) { ofb_hhdr* h = reinterpret_cast<ofb_hhdr*>(yP); h->e = he; h->amax = binf; h->rn2sq = rn2; h->cn2sq = 0.f; }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int row = 4 * rg + r;
@@ -262,7 +300,7 @@ __global__ __launch_bounds__(256) void ln_fwd_p_kernel(const float* __restrict__
     if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
   }
   const int Dp = (D + 15) & ~15;
-  ln_p_store<NJ>(yP, Dp >> 4, rg, lane, Dp, v);
+  ln_p_store<NJ>(yP + OFB_HHDR, Dp >> 4, rg, lane, Dp, v, ofb_h_pow2(he));
 }
 
 template <int NJ>
@@ -277,6 +315,10 @@ __global__ __launch_bounds__(256) void ln_bwd_p_kernel(const float* __restrict__
   const int Dp = (D + 15) & ~15;
   float g[NE], ag[NE], ab[NE], ac[NE];
   ln_p_load<NJ>(g, gamma, D, lane);
+  ofb_hhdr* hdr = reinterpret_cast<ofb_hhdr*>(dxP);       // amax (a bound) was left there by ln_bwd_stat_kernel
+  const int he = ofb_h_exp(hdr->amax);
+  if (blockIdx.x == 0 && threadIdx.x == 0) hdr->e = he;
+  const float hs = ofb_h_pow2(he);
 #pragma unroll
   for (int i = 0; i < NE; ++i) ag[i] = ab[i] = ac[i] = 0.f;
   for (int rg = blockIdx.x * 4 + w; 4 * rg < rows; rg += gridDim.x * 4) {
@@ -326,7 +368,7 @@ __global__ __launch_bounds__(256) void ln_bwd_p_kernel(const float* __restrict__
     }
 #pragma unroll
     for (int i = 0; i < NE; ++i) ac[i] += (o[0][i] + o[1][i]) + (o[2][i] + o[3][i]);
-    ln_p_store<NJ>(dxP, Dp >> 4, rg, lane, Dp, o);
+    ln_p_store<NJ>(dxP + OFB_HHDR, Dp >> 4, rg, lane, Dp, o, hs);
   }
   // cross-wave reduction of the per-lane column partials: dgamma | dbeta | column sums of the scaled rows
   constexpr int SEC = 128 * NJ;
@@ -344,6 +386,40 @@ __global__ __launch_bounds__(256) void ln_bwd_p_kernel(const float* __restrict__
       for (int k = 0; k < 4; ++k) sum += red[(k * 3 + sct) * SEC + c];
       part[(size_t)blockIdx.x * 3 * D + sct * D + c] = sum;
     }
+  }
+}
+
+// Bound of LayerNorm backward's scaled output BEFORE it is computed (the exponent of its H-format planes): dx = rstd P(gamma * dy)
+// with P an orthogonal projection (it removes the components along 1 and xhat), so per row
+//   |dx|_inf <= |dx|_2 <= rstd |gamma * dy|_2   (+ the residual gradient's own max / norm), times the row's DropPath factor.
+// One wave per row; header.amax / header.rn2sq (zeroed by a memset node) take the maxima over the rows.
+__global__ __launch_bounds__(256) void ln_bwd_stat_kernel(const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                          const float* __restrict__ rstd, const float* __restrict__ dres,
+                                                          const float* __restrict__ rowscale, int rs_div, int rows, int D,
+                                                          ofb_hhdr* __restrict__ hdr) {
+  __shared__ float red[2][4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float am = 0.f, rn = 0.f;
+  for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+    const float* d = dy + (size_t)row * D;
+    float ss = 0.f, rm = 0.f, rs2 = 0.f;
+    for (int c = lane; c < D; c += 64) {
+      const float t = d[c] * gamma[c];
+      ss += t * t;
+      if (dres) { const float r = dres[(size_t)row * D + c]; rm = fmaxf(rm, fabsf(r)); rs2 += r * r; }
+    }
+    const float n2 = rstd[row] * sqrtf(ofb_wave_sum(ss));
+    const float sc = rowscale ? fabsf(rowscale[rs_div == 1 ? row : row / rs_div]) : 1.f;
+    if (dres) { rm = ofb_wave_max_pos(rm); rs2 = sqrtf(ofb_wave_sum(rs2)); }
+    am = fmaxf(am, sc * (n2 + rm));
+    const float r2 = sc * (n2 + rs2);
+    rn = fmaxf(rn, r2 * r2);
+  }
+  if (lane == 0) { red[0][w] = am; red[1][w] = rn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ofb_atomic_max_pos(&hdr->amax, 1.0002f * fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
+    ofb_atomic_max_pos(&hdr->rn2sq, 1.0004f * fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
   }
 }
 
@@ -484,7 +560,7 @@ namespace {
 int ln_fwd_launch(const float* x, const float* gamma, const float* beta, float* y, char* yP, float* mean, float* rstd, int rows, int D,
                   float eps, hipStream_t s) {
   const dim3 grid(ofb_cdiv(rows, 4));
-  ofb_prof_pre(2, s, (yP ? 14.0 : 8.0) * rows * (double)D);
+  ofb_prof_pre(2, s, (yP ? 12.0 : 8.0) * rows * (double)D);
   if (yP && D % 2 == 0) {
     const dim3 gp(ofb_cdiv(rows, 16));
     const int nj = ofb_cdiv(D, 128);
@@ -510,9 +586,10 @@ extern "C" int ofb_layernorm_fwd(const float* x, const float* gamma, const float
   return ln_fwd_launch(x, gamma, beta, y, nullptr, mean, rstd, rows, D, eps, (hipStream_t)stream);
 }
 
-// y (optional) and the same rows as P-format planes y_p[rows][D] (ofb_pformat_bytes(rows, D) bytes).  Row groups 0 .. ceil(rows / 4) - 1
-// are written whole (padding rows and columns as zeros); the caller zeroes what is left of the last 16-row group (rows % 16 in 1..12).
-extern "C" int ofb_layernorm_fwd_p(const float* x, const float* gamma, const float* beta, float* y, void* y_p, float* mean,
+// y (optional) and the same rows as H-format planes y_h[rows][D] (ofb_hformat_bytes(rows, D) bytes, header included).  Row groups
+// 0 .. ceil(rows / 4) - 1 are written whole (padding rows and columns as zeros); the caller zeroes what is left of the last 16-row
+// group (rows % 16 in 1..12).
+extern "C" int ofb_layernorm_fwd_h(const float* x, const float* gamma, const float* beta, float* y, void* y_p, float* mean,
                                    float* rstd, int32_t rows, int32_t D, float eps, void* stream) {
   if (!x || !gamma || !beta || !y_p || !mean || !rstd || rows <= 0 || D <= 0) return OFB_EINVAL;
   if (D > 64 * LN_MAXE) return OFB_ELIMIT;
@@ -525,7 +602,12 @@ namespace {
 int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
                   float* partials, int rows, int D, char* dxP, const float* rowscale, int rs_div, hipStream_t s) {
   const dim3 grid(ofb_layernorm_bwd_blocks(rows));
-  ofb_prof_pre(3, s, (dxP ? 22.0 : 16.0) * rows * (double)D);
+  ofb_prof_pre(3, s, (dxP ? 24.0 : 16.0) * rows * (double)D);
+  if (dxP) {
+    if (hipMemsetAsync(dxP, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
+    const int nb = ofb_cdiv(rows, 4) < 1024 ? ofb_cdiv(rows, 4) : 1024;
+    hipLaunchKernelGGL(ln_bwd_stat_kernel, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
+  }
   if (dxP && D % 2 == 0) {
     const int nj = ofb_cdiv(D, 128);
     if (nj <= 2) hipLaunchKernelGGL(ln_bwd_p_kernel<2>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
@@ -550,9 +632,9 @@ extern "C" int ofb_layernorm_bwd(const float* dy, const float* x, const float* g
   return ln_bwd_launch(dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, nullptr, nullptr, 1, (hipStream_t)stream);
 }
 
-// Same, and dx * rowscale[row / rs_div] (rowscale optional) also as P-format planes dx_p[rows][D]; partials is then
+// Same, and dx * rowscale[row / rs_div] (rowscale optional) also as H-format planes dx_h[rows][D]; partials is then
 // [ofb_layernorm_bwd_blocks(rows)][3][D]: dgamma | dbeta | column sums of the scaled dx rows.
-extern "C" int ofb_layernorm_bwd_p(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+extern "C" int ofb_layernorm_bwd_h(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                                    const float* dres, float* dx, float* partials, void* dx_p, const float* rowscale, int32_t rs_div,
                                    int32_t rows, int32_t D, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || !dx || !partials || !dx_p || rows <= 0 || D <= 0) return OFB_EINVAL;

@@ -22,9 +22,9 @@ ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
     'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs',
-    'ofb_gemm_p', 'ofb_gemm_p_workspace_bytes', 'ofb_gemm_p_colpart_rows', 'ofb_pformat_bytes', 'ofb_to_pformat', 'ofb_patchify_pformat', 'ofb_to_pformat_colsum', 'ofb_to_pformat_multi', 'ofb_from_pformat', 'ofb_colsum_p', 'ofb_colsum_p_slabs', 'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
-    'ofb_layernorm_fwd', 'ofb_layernorm_fwd_p', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_p', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
-    'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_attention_fwd', 'ofb_attention_fwd_p', 'ofb_attention_bwd', 'ofb_attention_bwd_p',
+    'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
+    'ofb_layernorm_fwd', 'ofb_layernorm_fwd_h', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_h', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
+    'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_amax', 'ofb_attention_fwd', 'ofb_attention_fwd_h', 'ofb_attention_bwd',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
     'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
@@ -104,22 +104,22 @@ def gemm(A, B, C_out, M, N, K, lda, ldb, ldc, a_kc, b_kc, alpha=1.0, bias=None, 
          resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, kscale=None, ks_div=1, a_colsum=None):
     """Convenience form for callers that hold plain f32 matrices (tests, scripts): one conversion pass per operand, then the
     plane GEMM.  a_kc / b_kc = 1: operand stored K-contiguous (A[m*lda+k], B[n*ldb+k]); 0: MN-contiguous.  The model path hands
-    P-format tensors over directly (ops.py).  kscale (a_kc == 0): A's reduction rows scaled by kscale[k // ks_div]; a_colsum
+    H-format tensors over directly (ops.py).  kscale (a_kc == 0): A's reduction rows scaled by kscale[k // ks_div]; a_colsum
     (a_kc == 0): column sums of the stored (scaled) A, i.e. the bias gradient beside a weight gradient."""
     if not a_kc and b_kc:
-        raise OfbError('A^T * B^T is not a product of the path (ofb_gemm_p: OFB_ELIMIT)')
+        raise OfbError('A^T * B^T is not a product of the path (ofb_gemm_h: OFB_ELIMIT)')
     if kscale is not None and a_kc:
         raise OfbError('kscale applies to an operand stored along the reduction (a_kc == 0)')
-    Ap = to_pformat(A, M, K, lda) if a_kc else to_pformat(A, K, M, lda, rowscale=kscale, rs_div=ks_div)
-    Bp = to_pformat(B, N, K, ldb) if b_kc else to_pformat(B, K, N, ldb)
-    gemm_p(Ap, Bp, a_kc, b_kc, M, N, K, C_out=C_out, ldc=ldc, alpha=alpha, bias=bias, colscale=colscale, rowscale=rowscale,
+    Ap = to_hformat(A, M, K, lda) if a_kc else to_hformat(A, K, M, lda, rowscale=kscale, rs_div=ks_div)
+    Bp = to_hformat(B, N, K, ldb) if b_kc else to_hformat(B, K, N, ldb)
+    gemm_h(Ap, Bp, a_kc, b_kc, M, N, K, C_out=C_out, ldc=ldc, alpha=alpha, bias=bias, colscale=colscale, rowscale=rowscale,
            rs_div=rs_div, resid=resid, ldr=ldr, aux=aux, ldaux=ldaux, act=act)
     if a_colsum is not None:
         colsum(A, lda, K, M, a_colsum, rowscale=kscale, rs_div=ks_div)
 
 
-# ---- P-format GEMM (csrc/gemm_p.hip): operands pre-split into three bf16 planes -----------------------------------------
-class GemmPArgs(C.Structure):
+# ---- H-format GEMM (csrc/gemm_h.hip): operands as two f16 planes of a power-of-two scaled copy + a device-side header ----------
+class GemmHArgs(C.Structure):
     _fields_ = [
         ('A', C.c_void_p), ('B', C.c_void_p), ('a_kc', C.c_int32), ('b_kc', C.c_int32), ('a_ncb', C.c_int32), ('b_ncb', C.c_int32),
         ('M', C.c_int32), ('N', C.c_int32), ('K', C.c_int32),
@@ -127,78 +127,89 @@ class GemmPArgs(C.Structure):
         ('alpha', C.c_float), ('bias', C.c_void_p), ('colscale', C.c_void_p), ('rowscale', C.c_void_p), ('rs_div', C.c_int32),
         ('resid', C.c_void_p), ('ldr', C.c_int32), ('aux', C.c_void_p), ('ldaux', C.c_int32), ('act', C.c_int32),
         ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('colpart', C.c_void_p),
+        ('aux_bound', C.c_float), ('out_bound', C.c_void_p), ('cbound_out', C.c_void_p),
     ]
 
 
-class PMat:
-    """A matrix X[R][C] in P-format (three bf16 planes in 4 x 16 granules, include/ofb_hip.h).  `buf` is a uint8 device tensor of
-    ofb_pformat_bytes(R, C) bytes."""
+class HMat:
+    """A matrix X[R][C] in H-format (csrc/hformat.h: a 256-byte device-side header {e, amax, row / column norm bounds}, then two
+    f16 planes of X * 2^e in 4 x 16 granules).  `buf` is a uint8 device tensor of ofb_hformat_bytes(R, C) bytes."""
     __slots__ = ('buf', 'R', 'C', 'ncb')
 
     def __init__(self, R, C_, device, buf=None):
-        f = lib().ofb_pformat_bytes
+        f = lib().ofb_hformat_bytes
         f.restype = C.c_int64
         self.R, self.C, self.ncb = int(R), int(C_), (int(C_) + 15) // 16
         self.buf = buf if buf is not None else torch.empty(int(f(_i(R), _i(C_))), device=device, dtype=torch.uint8)
 
     @staticmethod
     def for_rows_written_by_kernel(R, C_, device):
-        """planes that a producer kernel fills element by element (attention backward): the padding rows / columns of the last
-        granules, which a reduction along the rows / columns would read, are zeroed here"""
-        pm = PMat(R, C_, device)
+        """planes that a producer kernel fills element by element: the padding rows / columns of the last granules, which a
+        reduction along the rows / columns would read, are zeroed here"""
+        pm = HMat(R, C_, device)
         if R % 16 or C_ % 16:
             pm.buf.zero_()
         return pm
 
     def to_f32(self):
         out = torch.empty(self.R, self.C, device=self.buf.device, dtype=torch.float32)
-        check(lib().ofb_from_pformat(ptr(self.buf), _i(self.R), _i(self.C), ptr(out), _i(self.C), stream()), 'ofb_from_pformat')
+        check(lib().ofb_from_hformat(ptr(self.buf), _i(self.R), _i(self.C), ptr(out), _i(self.C), stream()), 'ofb_from_hformat')
         return out
 
+    def header(self):
+        """(e, amax, rn2sq, cn2sq) - a host copy for tests / diagnostics only (synchronises)"""
+        h = self.buf[:16].cpu()
+        f = h.view(torch.float32)
+        return int(h.view(torch.int32)[0]), float(f[1]), float(f[2]), float(f[3])
 
-def to_pformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1, colsum_out=None):
-    """f32 [R][C] (row stride ld; default: the 2-D tensor's own shape / stride) -> PMat, optionally scaled per row by
-    rowscale[r // rs_div].  colsum_out [C]: also receives the column sums of the (scaled) matrix from the same pass."""
+
+def amax(x, out=None):
+    """out[0] = max |x| on the device (no host sync): a bound for tensors whose producer left none"""
+    if x.dtype != torch.float32 or not x.is_contiguous():
+        raise OfbError('amax needs a contiguous float32 tensor')
+    out = out if out is not None else torch.empty(1, device=x.device, dtype=torch.float32)
+    check(lib().ofb_amax(ptr(x), C.c_int64(x.numel()), ptr(out), stream()), 'ofb_amax')
+    return out
+
+
+def to_hformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1, colsum_out=None, bound=None, into=None):
+    """f32 [R][C] (row stride ld; default: the 2-D tensor's own shape / stride) -> HMat, optionally scaled per row by
+    rowscale[r // rs_div].  colsum_out [C]: also receives the column sums of the (scaled) matrix from the same pass.
+    bound: device scalar >= max |x * rowscale| (skips the statistics pass); into: existing planes (persistent weight planes)."""
     if R is None:
         R, Cc = x.shape
     if ld is None:
         ld = x.stride(0) if x.dim() == 2 else Cc
     if x.dtype != torch.float32:
-        raise OfbError('to_pformat needs float32 input')
-    pm = PMat(R, Cc, x.device)
+        raise OfbError('to_hformat needs float32 input')
+    pm = into if into is not None else HMat(R, Cc, x.device)
     if colsum_out is not None:
-        slabs, ldp = int(lib().ofb_colsum_p_slabs(_i(R))), pm.ncb * 16
+        slabs, ldp = int(lib().ofb_colsum_h_slabs(_i(R))), pm.ncb * 16
         part = torch.empty(slabs, ldp, device=x.device, dtype=torch.float32)
-        check(lib().ofb_to_pformat_colsum(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(part), stream()),
-              'ofb_to_pformat_colsum')
+        check(lib().ofb_to_hformat_colsum(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(part), ptr(bound),
+                                          stream()), 'ofb_to_hformat_colsum')
         colsum(part, ldp, slabs, Cc, colsum_out)
         return pm
-    check(lib().ofb_to_pformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), stream()), 'ofb_to_pformat')
+    check(lib().ofb_to_hformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(bound), stream()), 'ofb_to_hformat')
     return pm
 
 
-def to_pformat_into(x, R, Cc, ld, pm, rowscale=None, rs_div=1):
-    """the same conversion into existing planes `pm` (persistent weight planes)"""
-    check(lib().ofb_to_pformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), stream()), 'ofb_to_pformat')
-    return pm
-
-
-def patchify_pformat(imgs, patch):
-    """[B][Cin][H][W] f32 images -> PMat of the patch matrix [B * L][Cin * patch^2] (conv-as-GEMM operand), no f32 copy in between"""
+def patchify_hformat(imgs, patch):
+    """[B][Cin][H][W] f32 images -> HMat of the patch matrix [B * L][Cin * patch^2] (conv-as-GEMM operand), no f32 copy in between"""
     if imgs.dtype != torch.float32 or not imgs.is_contiguous() or imgs.dim() != 4:
-        raise OfbError('patchify_pformat needs a contiguous float32 [B][C][H][W] tensor')
+        raise OfbError('patchify_hformat needs a contiguous float32 [B][C][H][W] tensor')
     B, Cin, Hh, Ww = imgs.shape
-    pm = PMat(B * (Hh // patch) * (Ww // patch), Cin * patch * patch, imgs.device)
-    check(lib().ofb_patchify_pformat(ptr(imgs), _i(B), _i(Cin), _i(Hh), _i(Ww), _i(patch), ptr(pm.buf), stream()), 'ofb_patchify_pformat')
+    pm = HMat(B * (Hh // patch) * (Ww // patch), Cin * patch * patch, imgs.device)
+    check(lib().ofb_patchify_hformat(ptr(imgs), _i(B), _i(Cin), _i(Hh), _i(Ww), _i(patch), ptr(pm.buf), stream()), 'ofb_patchify_hformat')
     return pm
 
 
-def colsum_p(pm, out):
-    """out[C] = column sums of a P-format matrix (two deterministic stages)."""
-    slabs = int(lib().ofb_colsum_p_slabs(_i(pm.R)))
+def colsum_h(pm, out):
+    """out[C] = column sums of an H-format matrix (two deterministic stages)."""
+    slabs = int(lib().ofb_colsum_h_slabs(_i(pm.R)))
     ld = pm.ncb * 16
     part = torch.empty(slabs, ld, device=pm.buf.device, dtype=torch.float32)
-    check(lib().ofb_colsum_p(ptr(pm.buf), _i(pm.R), _i(pm.C), ptr(part), stream()), 'ofb_colsum_p')
+    check(lib().ofb_colsum_h(ptr(pm.buf), _i(pm.R), _i(pm.C), ptr(part), stream()), 'ofb_colsum_h')
     colsum(part, ld, slabs, pm.C, out)
 
 
@@ -264,7 +275,7 @@ def join_side():
         _side_keep.clear()
 
 
-# P-format copies of the weights.  They live in a registry keyed by id(tensor) with a weak reference (never as attributes of the
+# H-format copies of the weights.  They live in a registry keyed by id(tensor) with a weak reference (never as attributes of the
 # Parameter: torch pickles a Parameter's __dict__, so `torch.save(model)` - the reference's whole-object checkpoint format,
 # search.py:671-740 - would write the planes into every checkpoint).  An entry dies with its tensor.  A copy is fresh while
 #   * the weight epoch is unchanged: the optimizers / EMA / compress() / load_state_dict / the DP broadcast bump it after they
@@ -303,7 +314,7 @@ class _WEntry:
 
 
 # Every weight that has ever been asked for in P-format is registered.  The first request of a new epoch converts ALL registered
-# weights that are stale in ONE multi-tensor launch (ofb_to_pformat_multi): ~70 launches per DeiT search step become one.  The
+# weights that are stale in ONE multi-tensor launch (ofb_to_hformat_multi): ~70 launches per DeiT search step become one.  The
 # job table is re-uploaded only when the set of (pointer, shape) entries changed.
 _wp_reg = {}                 # id(W) -> _WEntry
 _wp_table = [None, None, 0, 0]   # key tuple, device table (kept alive), max_R, max_C
@@ -336,6 +347,18 @@ def _wp_fresh(W, ent):
             and ent.shape == tuple(W.shape))
 
 
+_scratch = {}
+
+
+def _multi_scratch(device, n_jobs):
+    """two-stage maxima of a multi-tensor conversion: 64 floats per job"""
+    device = torch.device(device)
+    t = _scratch.get(device)
+    if t is None or t.numel() < 64 * n_jobs:
+        t = _scratch[device] = torch.empty(64 * max(n_jobs, 256), device=device, dtype=torch.float32)
+    return t
+
+
 def _wp_refresh_all(device):
     jobs, live = [], []
     for key, ent in list(_wp_reg.items()):
@@ -358,8 +381,8 @@ def _wp_refresh_all(device):
             t.X, t.P, t.rowscale, t.R, t.C, t.ld = x, pp, None, R, Cc, Cc
         dev_tab, host = upload_structs(tab, device)
         _wp_table[:] = [key, (dev_tab, host), max(j[2] for j in jobs), max(j[3] for j in jobs)]
-    check(lib().ofb_to_pformat_multi(ptr(_wp_table[1][0]), _i(len(jobs)), _i(_wp_table[2]), _i(_wp_table[3]), stream()),
-          'ofb_to_pformat_multi')
+    check(lib().ofb_to_hformat_multi(ptr(_wp_table[1][0]), _i(len(jobs)), _i(_wp_table[2]), _i(_wp_table[3]), ptr(_multi_scratch(device, len(jobs))),
+                                     stream()), 'ofb_to_hformat_multi')
     for W, ent in live:
         ent.epoch, ent.version, ent.ptr = _weight_epoch, W._version, W.data_ptr()
 
@@ -375,8 +398,8 @@ def _param_of(W):
     return W
 
 
-def weight_p(W, shape2d=None):
-    """P-format copy of a weight viewed as W[N][K] (shape2d: the 2-D view of a conv weight)."""
+def weight_h(W, shape2d=None):
+    """H-format copy of a weight viewed as W[N][K] (shape2d: the 2-D view of a conv weight)."""
     if shape2d is None:
         shape2d = tuple(W.shape)
     W = _param_of(W)
@@ -385,24 +408,24 @@ def weight_p(W, shape2d=None):
     if ent is not None and _wp_fresh(W, ent) and (ent.pm.R, ent.pm.C) == (N, K):
         return ent.pm
     if not W.is_contiguous():
-        raise OfbError('weight_p needs a contiguous weight')
+        raise OfbError('weight_h needs a contiguous weight')
     if ent is None:
-        return to_pformat(W, N, K, K)                    # an object that takes no weak references: convert in place
+        return to_hformat(W, N, K, K)                    # an object that takes no weak references: convert in place
     if not _WP_MULTI:
-        ent.pm = to_pformat(W, N, K, K)
+        ent.pm = to_hformat(W, N, K, K)
         ent.epoch, ent.version, ent.ptr, ent.shape = _weight_epoch, W._version, W.data_ptr(), tuple(W.shape)
         return ent.pm
     if ent.pm is None or ent.shape != tuple(W.shape) or (ent.pm.R, ent.pm.C) != (N, K):
-        ent.pm, ent.shape, ent.epoch = PMat(N, K, W.device), tuple(W.shape), -1     # persistent planes; stale until converted
+        ent.pm, ent.shape, ent.epoch = HMat(N, K, W.device), tuple(W.shape), -1     # persistent planes; stale until converted
     _wp_refresh_all(W.device)
     if not _wp_fresh(W, ent):                            # e.g. another device's table was current: a single conversion
-        to_pformat_into(W, N, K, K, ent.pm)
+        to_hformat(W, N, K, K, into=ent.pm)
         ent.epoch, ent.version, ent.ptr = _weight_epoch, W._version, W.data_ptr()
     return ent.pm
 
 
 def weight_registry_size():
-    """number of live weights that hold P-format planes (tests)"""
+    """number of live weights that hold H-format planes (tests)"""
     return sum(1 for e in _wp_reg.values() if e.ref() is not None and e.pm is not None)
 
 
@@ -424,14 +447,14 @@ def _gw_fresh(W, gvec, ent):
             and g[5] == W.data_ptr())
 
 
-def gated_weight_p(W, gvec, N, K):
-    """P-format planes of gvec[n] * W[n][:] for W viewed as [N][K]"""
+def gated_weight_h(W, gvec, N, K):
+    """H-format planes of gvec[n] * W[n][:] for W viewed as [N][K]"""
     W = _param_of(W)
     if not _WP_MULTI or not W.is_contiguous():
-        return to_pformat(W, N, K, K, rowscale=gvec)
+        return to_hformat(W, N, K, K, rowscale=gvec)
     ent = _entry(W)
     if ent is None:
-        return to_pformat(W, N, K, K, rowscale=gvec)
+        return to_hformat(W, N, K, K, rowscale=gvec)
     if _gw_fresh(W, gvec, ent) and (ent.gw[4].R, ent.gw[4].C) == (N, K):
         return ent.gw[4]
     todo, seen = [], set()
@@ -440,7 +463,7 @@ def gated_weight_p(W, gvec, N, K):
         if e_ is None or id(W_) in seen or W_.device != W.device or _gw_fresh(W_, g_, e_):
             continue
         seen.add(id(W_))
-        pm = e_.gw[4] if e_.gw is not None and (e_.gw[4].R, e_.gw[4].C) == (N_, K_) else PMat(N_, K_, W_.device)
+        pm = e_.gw[4] if e_.gw is not None and (e_.gw[4].R, e_.gw[4].C) == (N_, K_) else HMat(N_, K_, W_.device)
         todo.append((W_, g_, N_, K_, pm, e_))
     key = tuple((w_.data_ptr(), g_.data_ptr(), pm.buf.data_ptr(), n_, k_) for (w_, g_, n_, k_, pm, _) in todo)
     if _gw_table[0] != key:
@@ -449,94 +472,22 @@ def gated_weight_p(W, gvec, N, K):
             t.X, t.P, t.rowscale, t.R, t.C, t.ld = w_.data_ptr(), pm.buf.data_ptr(), g_.data_ptr(), n_, k_, k_
         dev_tab, host = upload_structs(tab, W.device)
         _gw_table[:] = [key, (dev_tab, host), max(j[2] for j in todo), max(j[3] for j in todo)]
-    check(lib().ofb_to_pformat_multi(ptr(_gw_table[1][0]), _i(len(todo)), _i(_gw_table[2]), _i(_gw_table[3]), stream()),
-          'ofb_to_pformat_multi')
+    check(lib().ofb_to_hformat_multi(ptr(_gw_table[1][0]), _i(len(todo)), _i(_gw_table[2]), _i(_gw_table[3]), ptr(_multi_scratch(W.device, len(todo))),
+                                     stream()), 'ofb_to_hformat_multi')
     for (w_, g_, n_, k_, pm, e_) in todo:
         e_.gw = (_weight_epoch, w_._version, g_.data_ptr(), g_._version, pm, w_.data_ptr())
     return ent.gw[4]
 
 
-def gemm_p(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
-           resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, colsum_out=None, want_colpart=False):
-    """C[M][N] (f32 and / or P-format) = A * B on P-format operands (PMat); a_kc / b_kc: reduction along the operand's columns.
-    colsum_out [N]: also receives the column sums of the output (fused per-tile partial sums + one small reduction).
-    want_colpart: return the per-tile partial column sums [rows][N] themselves (the consumer adds them up)."""
-    g = GemmPArgs()
-    g.A, g.B, g.a_kc, g.b_kc, g.a_ncb, g.b_ncb = ptr(A.buf), ptr(B.buf), int(a_kc), int(b_kc), A.ncb, B.ncb
-    g.M, g.N, g.K = M, N, K
-    g.C, g.ldc = ptr(C_out), ldc
-    if Cp is not None:
-        if Cp.R != M or Cp.C != N:
-            raise OfbError('P-format output must be [M][N]')
-        g.Cp, g.c_ncb = ptr(Cp.buf), Cp.ncb
-    g.alpha, g.bias, g.colscale, g.rowscale, g.rs_div = alpha, ptr(bias), ptr(colscale), ptr(rowscale), rs_div
-    g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
-    part = None
-    if colsum_out is not None or want_colpart:
-        rows = int(lib().ofb_gemm_p_colpart_rows(C.byref(g)))
-        part = torch.empty(rows, N, device=A.buf.device, dtype=torch.float32)
-        g.colpart = ptr(part)
-    lib().ofb_gemm_p_workspace_bytes.restype = C.c_int64
-    need = lib().ofb_gemm_p_workspace_bytes(C.byref(g))
-    if need > 0:
-        ws = _workspace(A.buf.device, need)
-        g.workspace, g.workspace_bytes = ptr(ws), ws.numel() * 4
-    check(lib().ofb_gemm_p(C.byref(g), stream()), 'ofb_gemm_p')
-    if want_colpart:
-        return part
-    if part is not None:
-        colsum(part, N, part.shape[0], N, colsum_out)
-
-
-# ---- H-format GEMM (csrc/gemm_h.hip): operands as two f16 planes of a power-of-two scaled copy + a device-side header ----------
-class GemmHArgs(C.Structure):
-    _fields_ = GemmPArgs._fields_ + [('aux_bound', C.c_float), ('out_bound', C.c_void_p), ('cbound_out', C.c_void_p)]
-
-
-class HMat:
-    """A matrix X[R][C] in H-format (csrc/hformat.h).  `buf`: uint8 device tensor of ofb_hformat_bytes(R, C) bytes, header first."""
-    __slots__ = ('buf', 'R', 'C', 'ncb')
-
-    def __init__(self, R, C_, device, buf=None):
-        f = lib().ofb_hformat_bytes
-        f.restype = C.c_int64
-        self.R, self.C, self.ncb = int(R), int(C_), (int(C_) + 15) // 16
-        self.buf = buf if buf is not None else torch.empty(int(f(_i(R), _i(C_))), device=device, dtype=torch.uint8)
-
-    def to_f32(self):
-        out = torch.empty(self.R, self.C, device=self.buf.device, dtype=torch.float32)
-        check(lib().ofb_from_hformat(ptr(self.buf), _i(self.R), _i(self.C), ptr(out), _i(self.C), stream()), 'ofb_from_hformat')
-        return out
-
-    def header(self):
-        """(e, amax, rn2sq, cn2sq) - host copy for tests / diagnostics only (syncs)"""
-        h = self.buf[:16].cpu()
-        return int(h.view(torch.int32)[0]), float(h.view(torch.float32)[1]), float(h.view(torch.float32)[2]), float(h.view(torch.float32)[3])
-
-
-def to_hformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1, colsum_out=None, into=None):
-    if R is None:
-        R, Cc = x.shape
-    if ld is None:
-        ld = x.stride(0) if x.dim() == 2 else Cc
-    if x.dtype != torch.float32:
-        raise OfbError('to_hformat needs float32 input')
-    pm = into if into is not None else HMat(R, Cc, x.device)
-    if colsum_out is not None:
-        slabs, ldp = int(lib().ofb_colsum_h_slabs(_i(R))), pm.ncb * 16
-        part = torch.empty(slabs, ldp, device=x.device, dtype=torch.float32)
-        check(lib().ofb_to_hformat_colsum(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(part), stream()),
-              'ofb_to_hformat_colsum')
-        colsum(part, ldp, slabs, Cc, colsum_out)
-        return pm
-    check(lib().ofb_to_hformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), stream()), 'ofb_to_hformat')
-    return pm
-
-
 def gemm_h(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
            resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, colsum_out=None, want_colpart=False, aux_bound=0.0, out_bound=None,
            cbound_out=None):
-    """C[M][N] (f32 and / or H-format) = A * B on H-format operands (HMat); arguments as gemm_p."""
+    """C[M][N] (f32 and / or H-format) = A * B on H-format operands (HMat); a_kc / b_kc: reduction along the operand's columns.
+    colsum_out [N]: also receives the column sums of the output (fused per-tile partial sums + one small reduction).
+    want_colpart: return the per-tile partial column sums [rows][N] themselves (the consumer adds them up).
+    aux_bound: bound of |aux| for the multiplying activations (default 1.13 = max gelu'); out_bound: device scalar that IS the
+    bound of |output| for an H-format output (required with resid); cbound_out: device scalar that receives the bound of the
+    f32 output (the exponent the attention kernels split it with)."""
     g = GemmHArgs()
     g.A, g.B, g.a_kc, g.b_kc, g.a_ncb, g.b_ncb = ptr(A.buf), ptr(B.buf), int(a_kc), int(b_kc), A.ncb, B.ncb
     g.M, g.N, g.K = M, N, K
@@ -595,16 +546,16 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, D, eps):
                                   stream()), 'ofb_layernorm_fwd')
 
 
-def layernorm_fwd_p(x, gamma, beta, y, yP, mean, rstd, rows, D, eps):
-    """LayerNorm rows as f32 `y` (may be None) and as P-format planes `yP` (PMat [rows][D]) from one pass."""
-    check(lib().ofb_layernorm_fwd_p(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(yP.buf), ptr(mean), ptr(rstd), _i(rows), _i(D),
-                                    _f(eps), stream()), 'ofb_layernorm_fwd_p')
+def layernorm_fwd_h(x, gamma, beta, y, yP, mean, rstd, rows, D, eps):
+    """LayerNorm rows as f32 `y` (may be None) and as H-format planes `yP` (HMat [rows][D]) from one pass."""
+    check(lib().ofb_layernorm_fwd_h(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(yP.buf), ptr(mean), ptr(rstd), _i(rows), _i(D),
+                                    _f(eps), stream()), 'ofb_layernorm_fwd_h')
 
 
-def layernorm_bwd_p(dy, x, gamma, mean, rstd, dres, dx, partials, dxP, rowscale, rs_div, rows, D):
+def layernorm_bwd_h(dy, x, gamma, mean, rstd, dres, dx, partials, dxP, rowscale, rs_div, rows, D):
     """LayerNorm backward that also writes dx * rowscale[row // rs_div] as planes `dxP`; partials: [blocks][3][D]."""
-    check(lib().ofb_layernorm_bwd_p(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(partials),
-                                    ptr(dxP.buf), ptr(rowscale), _i(rs_div), _i(rows), _i(D), stream()), 'ofb_layernorm_bwd_p')
+    check(lib().ofb_layernorm_bwd_h(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(partials),
+                                    ptr(dxP.buf), ptr(rowscale), _i(rs_div), _i(rows), _i(D), stream()), 'ofb_layernorm_bwd_h')
 
 
 def layernorm_bwd_blocks(rows):
@@ -676,34 +627,34 @@ def _check_lse(lse, B, N, H):
         raise OfbError('lse must hold 2 * B * H * N floats (log-sum-exp and its rounding residue)')
 
 
-def attention_fwd(qkv, out, lse, B, N, H, dh, scale):
+def attention_fwd(qkv, out, lse, B, N, H, dh, scale, qkv_bound=None):
+    """qkv_bound: device scalar >= max |qkv| (the qkv GEMM's cbound_out); measured here when absent"""
     _check_lse(lse, B, N, H)
-    check(lib().ofb_attention_fwd(ptr(qkv), ptr(out), ptr(lse), _i(B), _i(N), _i(H), _i(dh), _f(scale), stream()),
+    qkv_bound = qkv_bound if qkv_bound is not None else amax(qkv)
+    check(lib().ofb_attention_fwd(ptr(qkv), ptr(out), ptr(lse), _i(B), _i(N), _i(H), _i(dh), _f(scale), ptr(qkv_bound), stream()),
           'ofb_attention_fwd')
+    return qkv_bound
 
 
-def attention_fwd_p(qkv, out, outP, lse, B, N, H, dh, scale):
-    """forward that also writes the output as P-format planes (PMat [B*N][H*dh])"""
+def attention_fwd_h(qkv, out, outP, lse, B, N, H, dh, scale, qkv_bound=None):
+    """forward that also writes the output as H-format planes (HMat [B*N][H*dh])"""
     if outP.R != B * N or outP.C != H * dh:
-        raise OfbError('attention_fwd_p: output shapes')
+        raise OfbError('attention_fwd_h: output shapes')
     _check_lse(lse, B, N, H)
-    check(lib().ofb_attention_fwd_p(ptr(qkv), ptr(out), ptr(outP.buf), ptr(lse), _i(B), _i(N), _i(H), _i(dh), _f(scale), stream()),
-          'ofb_attention_fwd_p')
+    qkv_bound = qkv_bound if qkv_bound is not None else amax(qkv)
+    check(lib().ofb_attention_fwd_h(ptr(qkv), ptr(out), ptr(outP.buf), ptr(lse), _i(B), _i(N), _i(H), _i(dh), _f(scale), ptr(qkv_bound),
+                                    stream()), 'ofb_attention_fwd_h')
+    return qkv_bound
 
 
-def attention_bwd(qkv, out, lse, dout, dqkv, B, N, H, dh, scale):
+def attention_bwd(qkv, out, lse, dout, dqkv, B, N, H, dh, scale, qkv_bound=None, dout_bound=None, dqkv_amax=None):
+    """qkv_bound: the bound the forward used; dout_bound: device scalar >= max |dout|; dqkv_amax: device scalar that receives
+    max |dqkv| (the bound for its H-format copy)"""
     _check_lse(lse, B, N, H)
-    check(lib().ofb_attention_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), _i(B), _i(N), _i(H), _i(dh),
-                                  _f(scale), stream()), 'ofb_attention_bwd')
-
-
-def attention_bwd_p(qkv, out, lse, dout, dqkvP, colpart, B, N, H, dh, scale):
-    """dq | dk | dv as P-format planes (PMat [B*N][3*H*dh]) + per-image column sums colpart [B][3*H*dh]."""
-    if dqkvP.R != B * N or dqkvP.C != 3 * H * dh or colpart.numel() < B * 3 * H * dh:
-        raise OfbError('attention_bwd_p: output shapes')
-    _check_lse(lse, B, N, H)
-    check(lib().ofb_attention_bwd_p(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkvP.buf), ptr(colpart), _i(B), _i(N), _i(H),
-                                    _i(dh), _f(scale), stream()), 'ofb_attention_bwd_p')
+    qkv_bound = qkv_bound if qkv_bound is not None else amax(qkv)
+    dout_bound = dout_bound if dout_bound is not None else amax(dout)
+    check(lib().ofb_attention_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), _i(B), _i(N), _i(H), _i(dh), _f(scale),
+                                  ptr(qkv_bound), ptr(dout_bound), ptr(dqkv_amax), stream()), 'ofb_attention_bwd')
 
 
 # ---- gates / losses -------------------------------------------------------------------------------

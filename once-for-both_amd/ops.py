@@ -21,48 +21,50 @@ def _c(t):
 
 
 # ---------------------------------------------------------------------------------------------------
-# P-format path (csrc/gemm_p.hip): every GEMM operand is handed over as three pre-split bf16 planes.  Producers on the path
-# (LayerNorm, the GELU epilogue of fc1, ...) attach the P-format copy of their output to the tensor object (`_ofb_p`); anything
-# that arrives without one is converted by one ofb_to_pformat pass.  Weights are converted once per optimizer step (hip.weight_p).
+# H-format path (csrc/gemm_h.hip, csrc/hformat.h): every GEMM operand is handed over as two pre-split f16 planes of a power-of-two
+# scaled copy, its exponent in a device-side header.  Producers on the path (LayerNorm, the GELU epilogue of fc1, ...) attach the
+# H-format copy of their output to the tensor object (`_ofb_p`); anything that arrives without one is converted by ofb_to_hformat
+# (a statistics pass + a conversion pass).  Weights are converted once per optimizer step (hip.weight_h).
 # ---------------------------------------------------------------------------------------------------
 def _P(t, M, K):
-    """P-format [M][K] copy of an activation (cached on the tensor object by its producer, else converted now)"""
+    """H-format [M][K] copy of an activation (cached on the tensor object by its producer, else converted now)"""
     pm = getattr(t, '_ofb_p', None)
     if pm is not None and pm.R == M and pm.C == K:
         return pm
-    return hip.to_pformat(t, M, K, K)
+    return hip.to_hformat(t, M, K, K)
 
 
 def _pm(buf, R, C):
-    return hip.PMat(R, C, buf.device, buf=buf)
+    return hip.HMat(R, C, buf.device, buf=buf)
 
 
 def p_linear_fwd(xP, M, K, WP, b, colscale=None, act=hip.ACT_NONE, aux=None, rowscale=None, rs_div=1, resid=None, want_f32=True,
-                 want_p=False):
-    """y[M,N] = x[M,K] @ W[N,K]^T (+ fused epilogue), WP = hip.weight_p(W); returns (f32 y or None, P-format y or None)"""
+                 want_p=False, cbound_out=None):
+    """y[M,N] = x[M,K] @ W[N,K]^T (+ fused epilogue), WP = hip.weight_h(W); returns (f32 y or None, H-format y or None).
+    cbound_out: device scalar that receives an upper bound of |y| (for a consumer that splits y itself: attention)"""
     N, dev = WP.R, WP.buf.device
     y = torch.empty(M, N, device=dev, dtype=torch.float32) if want_f32 else None
-    yP = hip.PMat(M, N, dev) if want_p else None
-    hip.gemm_p(xP, WP, 1, 1, M, N, K, C_out=y, ldc=N, Cp=yP, bias=b, colscale=colscale, act=act, aux=aux, ldaux=N,
-               rowscale=rowscale, rs_div=rs_div, resid=resid, ldr=N)
+    yP = hip.HMat(M, N, dev) if want_p else None
+    hip.gemm_h(xP, WP, 1, 1, M, N, K, C_out=y, ldc=N, Cp=yP, bias=b, colscale=colscale, act=act, aux=aux, ldaux=N,
+               rowscale=rowscale, rs_div=rs_div, resid=resid, ldr=N, cbound_out=cbound_out)
     return y, yP
 
 
 def p_linear_bwd_input(dyP, M, N, WP, K, resid=None, act=hip.ACT_NONE, aux=None, want_f32=True, want_p=False, colsum_out=None,
-                       want_colpart=False):
-    """dX[M,K] = dY[M,N] @ W[N,K]: dY reduced along its columns (KC), W along its rows (KR): the SAME P-format copy of W as forward.
+                       want_colpart=False, cbound_out=None):
+    """dX[M,K] = dY[M,N] @ W[N,K]: dY reduced along its columns (KC), W along its rows (KR): the SAME H-format copy of W as forward.
     want_colpart: third return value = the per-tile partial column sums of dX [rows][K]"""
     dx = torch.empty(M, K, device=dyP.buf.device, dtype=torch.float32) if want_f32 else None
-    dxP = hip.PMat(M, K, dyP.buf.device) if want_p else None
-    part = hip.gemm_p(dyP, WP, 1, 0, M, K, N, C_out=dx, ldc=K, Cp=dxP, resid=resid, ldr=K, act=act, aux=aux, ldaux=K, colsum_out=colsum_out,
-                      want_colpart=want_colpart)
+    dxP = hip.HMat(M, K, dyP.buf.device) if want_p else None
+    part = hip.gemm_h(dyP, WP, 1, 0, M, K, N, C_out=dx, ldc=K, Cp=dxP, resid=resid, ldr=K, act=act, aux=aux, ldaux=K, colsum_out=colsum_out,
+                      want_colpart=want_colpart, cbound_out=cbound_out)
     return (dx, dxP, part) if want_colpart else (dx, dxP)
 
 
 def p_linear_bwd_weight(dyP, xP, M, N, K, out=None):
     """dW[N,K] = dY[M,N]^T @ X[M,K]: both reduced along their rows (the tokens)"""
     dW = out if out is not None else torch.empty(N, K, device=dyP.buf.device, dtype=torch.float32)
-    hip.gemm_p(dyP, xP, 0, 0, N, K, M, C_out=dW, ldc=K)
+    hip.gemm_h(dyP, xP, 0, 0, N, K, M, C_out=dW, ldc=K)
     return dW
 
 
@@ -109,8 +111,8 @@ class _nullctx:
 
 
 def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None, fold=1):
-    """P-format backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None): dx (+resid fused), dW, db, dg.
-    WP: the forward's P-format copy of W; dy_colsum: callable giving colsum(dY) (the raw bias gradient) as a vector [N] or as
+    """H-format backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None): dx (+resid fused), dW, db, dg.
+    WP: the forward's H-format copy of W; dy_colsum: callable giving colsum(dY) (the raw bias gradient) as a vector [N] or as
     (partials [rows][N], rows) straight from the producing kernel - the gate-fold kernel adds partial rows up itself."""
     N, K = WP.R, WP.C
     side = _side_ok(W, b, tokens=M)                      # asked of the Parameter itself: a view's .grad is always None
@@ -122,7 +124,7 @@ def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None, fold=
         with (hip.side_work(W.device, keep=[dyP.buf, xP.buf]) if side else _nullctx()):
             p_linear_bwd_weight(dyP, xP, M, N, K, out=dW)
         return dx, dW, (_reduced(dy_colsum(), N) if b is not None else None), None
-    WeffP = hip.gated_weight_p(W, gvec, N, K)                            # g[n] * W[n][:] as planes (all gated layers in one launch)
+    WeffP = hip.gated_weight_h(W, gvec, N, K)                            # g[n] * W[n][:] as planes (all gated layers in one launch)
     dx, _ = p_linear_bwd_input(dyP, M, N, WeffP, K, resid=resid)
     dbraw, rows = None, 1
     if b is not None:
@@ -166,7 +168,7 @@ class Linear(torch.autograd.Function):
     def forward(ctx, x2d, W, b):
         x2d, W = _c(x2d), _c(W)
         M, K = x2d.shape
-        xP, WP = _P(x2d, M, K), hip.weight_p(W)
+        xP, WP = _P(x2d, M, K), hip.weight_h(W)
         ctx.save_for_backward(xP.buf, W, b)
         ctx.mk, ctx.wp = (M, K), WP
         return p_linear_fwd(xP, M, K, WP, b)[0]
@@ -177,18 +179,18 @@ class Linear(torch.autograd.Function):
         M, K = ctx.mk
         dy = _c(dy)
         db = _new(dy, W.shape[0]) if b is not None else None
-        dyP = hip.to_pformat(dy, M, W.shape[0], W.shape[0], colsum_out=db)
+        dyP = hip.to_hformat(dy, M, W.shape[0], W.shape[0], colsum_out=db)
         dx, dW, db, _ = _p_gated_linear_bwd(dyP, lambda: db, _pm(xbuf, M, K), M, W, ctx.wp, b, None)
         return dx, dW.view(W.shape), db
 
 
-# Hand-overs around LayerNorm on the P-format path (no extra kernels, no extra passes over the activations):
+# Hand-overs around LayerNorm on the H-format path (no extra kernels, no extra passes over the activations):
 #  * forward: the LN kernel writes its rows as planes too; the wrapper below hangs them on the output tensor (`_ofb_p`), where the
 #    branch that consumes it (AttnBranch / MlpBranch -> _P) finds them instead of converting.
 #  * backward: the gradient LN returns is the dY of the branch that produced LN's input.  That branch tags its output with its
 #    DropPath row scales (`_ofb_up`, see attn_branch / mlp_branch); LN's backward kernel then also writes dx * rowscale as planes
 #    and its column sums (the branch's output-bias gradient), parked in _grad_p under the gradient tensor's identity, where the
-#    branch's backward picks them up (_take_grad_p) instead of running ofb_to_pformat_colsum over the gradient.
+#    branch's backward picks them up (_take_grad_p) instead of running ofb_to_hformat_colsum over the gradient.
 _ln_pending = [None]
 _grad_p = {}
 
@@ -200,7 +202,7 @@ def _put_grad_p(dx, dxP, colsum, rowscale):
 
 
 def _take_grad_p(d2, rowscale, M, D):
-    """(PMat of d2 * rowscale, its column sums) if LayerNorm's backward already produced them for exactly this tensor"""
+    """(HMat of d2 * rowscale, its column sums) if LayerNorm's backward already produced them for exactly this tensor"""
     e = _grad_p.pop(d2.data_ptr(), None)
     if e is None:
         return None
@@ -221,8 +223,8 @@ class LayerNorm(torch.autograd.Function):
         D = x.shape[-1]
         rows = x.numel() // D
         y, mean, rstd = torch.empty_like(x), _new(x, rows), _new(x, rows)
-        yP = hip.PMat.for_rows_written_by_kernel(rows, D, x.device)
-        hip.layernorm_fwd_p(x, gamma, beta, y, yP, mean, rstd, rows, D, eps)
+        yP = hip.HMat.for_rows_written_by_kernel(rows, D, x.device)
+        hip.layernorm_fwd_h(x, gamma, beta, y, yP, mean, rstd, rows, D, eps)
         _ln_pending[0] = yP
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.fork = fork
@@ -243,8 +245,8 @@ class LayerNorm(torch.autograd.Function):
         if ctx.up is not None:
             rowscale = ctx.up[0]
             part = _new(x, nb, 3 * D)
-            dxP = hip.PMat.for_rows_written_by_kernel(rows, D, x.device)
-            hip.layernorm_bwd_p(_c(dy), x, gamma, mean, rstd, _c(dres) if dres is not None else None, dx, part, dxP, rowscale,
+            dxP = hip.HMat.for_rows_written_by_kernel(rows, D, x.device)
+            hip.layernorm_bwd_h(_c(dy), x, gamma, mean, rstd, _c(dres) if dres is not None else None, dx, part, dxP, rowscale,
                                 _rs_div(rowscale, rows), rows, D)
             dgb = _new(x, 3 * D)
             _ln_colsum(part, 3 * D, nb, dgb, ctx)
@@ -327,26 +329,27 @@ class AttnBranch(torch.autograd.Function):
             else:
                 g3 = g.reshape(-1).repeat(3).contiguous()
         r2d = x2d if resid is None else _c(resid).view(M, D)
-        xP, wqP, wpP = _P(x, M, D), hip.weight_p(wqkv), hip.weight_p(wproj)
+        xP, wqP, wpP = _P(x, M, D), hip.weight_h(wqkv), hip.weight_h(wproj)
         ctx.wp = (wqP, wpP)
-        qkv, _ = p_linear_fwd(xP, M, D, wqP, bqkv, colscale=g3)
+        qb = _new(x, 1)                                # device-side bound of |qkv| (Cauchy-Schwarz, from the qkv GEMM): the attention
+        qkv, _ = p_linear_fwd(xP, M, D, wqP, bqkv, colscale=g3, cbound_out=qb)    # kernels split q, k, v with its exponent
         if g3 is not None:
             hip.gated_register(wqkv, g3, wqkv.shape[0], D)
         o, lse = _new(x, M, Hd), _new(x, 2 * B * heads, N)          # lse travels as two floats (hip.attention_fwd)
         if _att_planes_ok(B, N):                       # the attention kernel writes the projection's operand planes too
-            oP = hip.PMat.for_rows_written_by_kernel(M, Hd, x.device)
-            hip.attention_fwd_p(qkv, o, oP, lse, B, N, heads, dh, scale)
+            oP = hip.HMat.for_rows_written_by_kernel(M, Hd, x.device)
+            hip.attention_fwd_h(qkv, o, oP, lse, B, N, heads, dh, scale, qb)
         else:
-            hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale)
-            oP = hip.to_pformat(o, M, Hd, Hd)
+            hip.attention_fwd(qkv, o, lse, B, N, heads, dh, scale, qb)
+            oP = hip.to_hformat(o, M, Hd, Hd, bound=qb)              # |softmax-weighted mean of v rows| <= max |v|
         out, _ = p_linear_fwd(oP, M, Hd, wpP, bproj, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
-        ctx.save_for_backward(xP.buf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, oP.buf)
+        ctx.save_for_backward(xP.buf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, oP.buf, qb)
         ctx.meta = (B, N, D, heads, dh, scale, resid is None, bproj is not None, gshape)
         return out.view(B, N, D)
 
     @staticmethod
     def backward(ctx, dout):
-        xbuf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, obuf = ctx.saved_tensors
+        xbuf, qkv, o, lse, wqkv, bqkv, wproj, g3, rowscale, obuf, qb = ctx.saved_tensors
         B, N, D, heads, dh, scale, self_resid, has_pb, gshape = ctx.meta
         M, Hd = B * N, heads * dh
         xP, oP = _pm(xbuf, M, D), _pm(obuf, M, Hd)
@@ -357,24 +360,20 @@ class AttnBranch(torch.autograd.Function):
             d2sP, dbp = hit[0], (hit[1] if has_pb else None)
         else:
             dbp = _new(d2, D) if has_pb else None
-            d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=dbp)
+            d2sP = hip.to_hformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=dbp)
         wqP, wpP = ctx.wp
-        do, _ = p_linear_bwd_input(d2sP, M, D, wpP, Hd)
+        dob = _new(d2, 1)                                       # bound of |dO| for the attention backward's split
+        do, _ = p_linear_bwd_input(d2sP, M, D, wpP, Hd, cbound_out=dob)
         dwp = grad_slot(wproj)
         dwp = dwp if dwp is not None else _new(d2, D, Hd)
         with (hip.side_work(d2.device, keep=[d2sP.buf, oP.buf]) if _side_ok(wproj, tokens=M) else _nullctx()):
             p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=dwp)
-        # dq | dk | dv leave the attention kernel as planes, with the per-image column sums the qkv bias gradient is made of
-        if _att_planes_ok(B, N):
-            dqkvP = hip.PMat.for_rows_written_by_kernel(M, 3 * Hd, d2.device)
-            colpart = _new(d2, B, 3 * Hd)
-            hip.attention_bwd_p(qkv, o, lse, do, dqkvP, colpart, B, N, heads, dh, scale)
-            dbq_raw = (colpart, B)                          # per-image partial sums: added up by their consumer (gate fold / colsum)
-        else:                                                   # sequence too long for the shifted tile origin: f32 rows + a conversion pass
-            dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
-            dqkv = torch.empty_like(qkv)
-            hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale)
-            dqkvP = hip.to_pformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw)
+        # dq | dk | dv leave the attention kernel as f32 rows together with their maximum (one atomic max per workgroup): the
+        # conversion pass takes its exponent from it and sums the columns (the raw qkv bias gradient) on the way
+        dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
+        dqkv, dq_amax = torch.empty_like(qkv), _new(d2, 1)
+        hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale, qb, dob, dq_amax)
+        dqkvP = hip.to_hformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw, bound=dq_amax)
         # fold = 3: the gate-fold kernel adds the q | k | v contributions to the gate gradient itself
         dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None, fold=3)
         dg = None
@@ -408,9 +407,9 @@ class MlpBranch(torch.autograd.Function):
         hid = w1.shape[0]
         hpre = _new(x, M, hid)
         r2d = x2d if resid is None else _c(resid).view(M, D)
-        xP, w1P, w2P = _P(x, M, D), hip.weight_p(w1), hip.weight_p(w2)
+        xP, w1P, w2P = _P(x, M, D), hip.weight_h(w1), hip.weight_h(w2)
         ctx.wp = (w1P, w2P)
-        # gelu(g * fc1(x)) leaves the kernel as the P-format operand of fc2 (and of the fc2 weight gradient); beside it only
+        # gelu(g * fc1(x)) leaves the kernel as the H-format operand of fc2 (and of the fc2 weight gradient); beside it only
         # GELU'(pre-activation) is kept in f32 (`hpre` holds the derivative here): the epilogue has Phi and phi in hand, and the
         # backward epilogue becomes a single multiply
         _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU_GRAD, aux=hpre, want_f32=False, want_p=True)
@@ -433,10 +432,10 @@ class MlpBranch(torch.autograd.Function):
             d2sP, db2 = hit[0], (hit[1] if has_b2 else None)
         else:
             db2 = _new(d2, D) if has_b2 else None
-            d2sP = hip.to_pformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=db2)
-        # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> P-format only
+            d2sP = hip.to_hformat(d2, M, D, D, rowscale=rowscale, rs_div=_rs_div(rowscale, M), colsum_out=db2)
+        # d(pre-activation) = (d2s @ W2) * gelu'(hpre): consumed only by the two fc1 gradient products -> H-format only
         w1P, w2P = ctx.wp
-        # the fc1 bias gradient (column sums of this P-format-only result) rides on the epilogue
+        # the fc1 bias gradient (column sums of this H-format-only result) rides on the epilogue
         if b1 is not None:
             _, dhP, part = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True,
                                               want_colpart=True)
@@ -477,8 +476,8 @@ class PatchEmbedTokens(torch.autograd.Function):
         # patchify is folded into the operand conversion: the planes of the patch matrix (rows (b, py, px), columns (c, i, j)) are
         # written straight from the images; the backward needs them only as a weight-gradient operand
         w2d = wconv.reshape(D, -1)
-        patchesP = hip.patchify_pformat(_c(imgs), patch)
-        conv, _ = p_linear_fwd(patchesP, B * L, w2d.shape[1], hip.weight_p(wconv, (D, w2d.shape[1])), bconv)
+        patchesP = hip.patchify_hformat(_c(imgs), patch)
+        conv, _ = p_linear_fwd(patchesP, B * L, w2d.shape[1], hip.weight_h(wconv, (D, w2d.shape[1])), bconv)
         patches = patchesP.buf
         tok = _new(imgs, B, L + 1, D)
         gv = None if g is None else _c(g.reshape(-1))
@@ -506,7 +505,7 @@ class PatchEmbedTokens(torch.autograd.Function):
         hip.colsum(part[2], D, chunks * (L + 1), D, dgm[1])
         Kp = w2d.shape[1]
         db = _new(dconv, D)
-        dw = p_linear_bwd_weight(hip.to_pformat(dconv, B * L, D, D, colsum_out=db), _pm(patches, B * L, Kp), B * L, D, Kp, out=grad_slot(w2d))
+        dw = p_linear_bwd_weight(hip.to_hformat(dconv, B * L, D, D, colsum_out=db), _pm(patches, B * L, Kp), B * L, D, Kp, out=grad_slot(w2d))
         dcls = dpos[0].reshape(cshape)
         return (None, dw.view(wshape), db, None if gshape is None else dgm[0].view(gshape), dpos.view(pshape), dcls,
                 None if mshape is None else dgm[1].view(mshape), None, None)

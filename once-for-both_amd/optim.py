@@ -88,7 +88,7 @@ class AdamW(Optimizer):
                 else:
                     hip.adamw_step(dev_tab, len(plist), maxn, group['lr'], b1, b2, group['eps'], group['weight_decay'], step)
                 self._keep = (dev_tab, host, keep)
-        hip.bump_weight_epoch()                  # the P-format copies of the weights (hip.weight_p) are stale now
+        hip.bump_weight_epoch()                  # the H-format copies of the weights (hip.weight_h) are stale now
         return loss
 
     def update(self, ori_w, cur_w, w_name, group_idx, keep_idx, dim, initialize=False):
