@@ -18,29 +18,48 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-GFLOP_PER_IMG = {'deit_small': 27.83, 'deit_tiny': 7.64, 'deit_base': 105.85}      # BASELINE.md section 2 (fwd+bwd)
+BASELINE_GFLOP_PER_IMG = {'deit_small': 27.83, 'deit_tiny': 7.64, 'deit_base': 105.85}      # BASELINE.md section 2 (fwd+bwd)
+# what the step really computes: the decoder GEMM (2 * 196 * 768 * D flops per image and pass, x3 for fwd + both gradients) runs on
+# the masked patches only - 5 % of the rows at keep ratio 0.95 (exact: unmasked patches contribute 0 to the PMIM loss)
+GFLOP_PER_IMG = {'deit_small': 27.49, 'deit_tiny': 7.48, 'deit_base': 105.19}
 PEAK_F32_MFMA_TFLOPS = 157.3                                                       # MI355X_MICROARCH.md, f32-input MFMA
-PEAK_BF16_MFMA_TFLOPS = 2500.0                                                     # MI355X_MICROARCH.md, dense bf16 MFMA
-# The GEMM computes every f32 product as six bf16 MFMA terms (exact 3-way operand split, f32 accumulate): the matrix pipe
-# executes 6 hardware flops per algorithmic flop, so the ceiling for ALGORITHMIC f32 flops is the bf16 peak / 6.
-GEMM_MFMA_TERMS = 6
+PEAK_F16_MFMA_TFLOPS = 2500.0                                                      # MI355X_MICROARCH.md, dense bf16 / f16 MFMA
+# The GEMM computes every f32 product as three f16 MFMA terms (two-plane operand split of a power-of-two scaled copy, f32
+# accumulate, csrc/hformat.h): the matrix pipe executes 3 hardware flops per algorithmic flop, so the ceiling for ALGORITHMIC f32
+# flops is the f16 peak / 3.  (Rounds 1-3: six bf16 terms, ceiling 416.7.)
+GEMM_MFMA_TERMS = 3
 INIT_STEPS = 6
-PEAK_GEMM_TFLOPS = PEAK_BF16_MFMA_TFLOPS / GEMM_MFMA_TERMS
+PEAK_GEMM_TFLOPS = PEAK_F16_MFMA_TFLOPS / GEMM_MFMA_TERMS
+
+
+def csrc_hash():
+    """sha256 over the kernel sources the library is built from: a profile summary under profiles/ names the build it was taken on"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, 'once-for-both_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'once-for-both_amd', 'csrc', '*.h'))
+                    + glob.glob(os.path.join(ROOT, 'include', '*.h'))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()[:16]
 PROF_TAGS = ['gemm_f32', 'attention_fwd', 'layernorm_fwd', 'layernorm_bwd', 'attention_bwd', 'norm_targets', 'adamw']
 
 
 def gemm_traffic_per_launch(launches_per_step):
-    """HBM-side bytes per ofb_gemm_p call from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    """HBM-side bytes per ofb_gemm_h call from the committed PMC summary (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
     passes over this same bench command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950; scripts/round_profiles.sh
     -> scripts/profile_summaries.py).  Hardware counters cannot be read from inside the process, so the figure is the newest
-    profiled one for configs[1]; `traffic_source` names the file."""
+    profiled one for configs[1] - and ONLY if that summary was taken on THIS build (its CSRC_SHA line = csrc_hash()): a summary of
+    other kernel sources yields traffic: null."""
     import glob
     import re
     files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*pmc_traffic_summary*.txt')),
                    key=lambda f: [int(x) for x in re.findall(r'\d+', os.path.basename(f))])
+    here = csrc_hash()
     for f in reversed(files):
-        m = re.search(r'GEMM_BYTES_PER_STEP (\d+)', open(f).read())
-        if m:
+        txt = open(f).read()
+        m, h = re.search(r'GEMM_BYTES_PER_STEP (\d+)', txt), re.search(r'CSRC_SHA (\w+)', txt)
+        if m and h and h.group(1) == here:
             return int(m.group(1)) / launches_per_step, os.path.relpath(f, ROOT)
     return None, None
 
@@ -375,11 +394,13 @@ def main():
         n, ms, work = prof[0]
         if n:
             ach = work / (ms * 1e-3) / 1e12
-            roof = dict(bound='mfma', kernel='gemm_p_kernel (f32 products as six v_mfma_f32_32x32x16_bf16 terms of operands pre-split into three bf16 planes, '
-                                             'LDS-DMA staged; main + stream-K tail + fix-up launches of all ofb_gemm_p calls)',
+            roof = dict(bound='mfma', kernel='gemm_h_kernel (f32 products as three v_mfma_f32_32x32x16_f16 terms of operands pre-split into two f16 planes '
+                                             'of a power-of-two scaled copy, LDS-DMA staged; bound pre-kernel + main + stream-K tail + fix-up launches of all '
+                                             'ofb_gemm_h calls)',
                         achieved=round(ach, 2), peak=round(PEAK_GEMM_TFLOPS, 1), unit='TFLOP/s', frac=round(ach / PEAK_GEMM_TFLOPS, 4),
-                        traffic=None, peak_basis='2500 TFLOP/s dense bf16 MFMA / 6 MFMA terms per f32 product (achieved = algorithmic '
-                                                 'f32 flops; the f32-input MFMA peak would be 157.3)',
+                        traffic=None, peak_basis='2500 TFLOP/s dense f16 MFMA / 3 MFMA terms per f32 product (achieved = algorithmic f32 flops; '
+                                                 'rounds 1-3 issued six bf16 terms: ceiling 416.7, against which this kernel reads '
+                                                 f'{ach / 416.7:.3f}; the f32-input MFMA peak would be 157.3)',
                         mfma_issued_tflops=round(ach * GEMM_MFMA_TERMS, 1),
                         launches_per_step=round(n / prof_steps, 1), avg_launch_us=round(ms / n * 1e3, 2),
                         share_of_step=round(ms / prof_steps / ms_step, 3), sampled_steps=prof_steps)
@@ -389,8 +410,8 @@ def main():
                     roof['traffic'] = round(tr)
                     roof['traffic_unit'] = 'bytes per GEMM call (FETCH_SIZE x2 + WRITE_SIZE of its kernels, PMC)'
                     roof['traffic_source'] = src
-                    roof['algorithmic_bytes_note'] = ('P-format operands (6 B / element) + outputs + epilogue side inputs of the 152 calls, each moved '
-                                                      'once: 37.8 GB per step = 249 MB per call')
+                    roof['algorithmic_bytes_note'] = ('H-format operands (4 B / element) + outputs + epilogue side inputs of the 152 calls, each moved '
+                                                      'once: 28.5 GB per step = 187 MB per call')
     step_tflops = value * gflop_img / 1e3 / world
     log(f'loss_total {loss_val:.4f}; step {ms_step:.2f} ms; whole-step {step_tflops:.1f} TFLOP/s/GPU '
         f'({step_tflops / PEAK_F32_MFMA_TFLOPS:.1%} of the f32 MFMA peak)')
@@ -411,7 +432,8 @@ def main():
                                            ranks=dist.get_world_size() if dist.is_initialized() else 1,
                                            buckets=len(reducer.buckets) if reducer is not None else 0), init_steps=INIT_STEPS,
                            hip_graph=bool(use_graph),
-                           step_tflops_per_gpu=round(step_tflops, 2), step_frac_of_f32_mfma_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4)),
+                           step_tflops_per_gpu=round(step_tflops, 2), step_frac_of_f32_mfma_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                           gflop_per_image=gflop_img, baseline_gflop_per_image=BASELINE_GFLOP_PER_IMG[args.model]),
                roofline=roof)
     if ft_info:
         res['config']['subnet'] = ft_info

@@ -34,10 +34,11 @@ extern "C" {
 /* ---------------------------------------------------------------------------------------------
  * Dense f32-class contraction on the f16 matrix pipe (csrc/gemm_h.hip, csrc/hformat.h):
  *   C[M,N] = A[M,K] * B[K,N], then  v = alpha*acc (+bias[n]) (*colscale[n]); act; (*rowscale[m / rs_div]); (+resid[m*ldr+n]).
- * Every operand value is held as TWO f16 numbers of a power-of-two scaled copy, X 2^e = h1 + h2 ("H-format": 22 explicit significand
- * bits + the roundings' sign tricks, |X 2^e - h1 - h2| <= 2^-24 |X 2^e|), and every product is three v_mfma_f32_32x32x16_f16 terms
- * (h2 h1, h1 h2, h1 h1; the dropped h2 h2 is <= 2^-24 of the product) with f32 accumulation: per-product error <= 3 2^-24, measured
- * at or below a k-ordered f32 fma chain (tests/test_gpu_accuracy_class.py).  (Rounds 1-3 used an exact three-way bf16 split with six
+ * Every operand value is held as TWO f16 numbers of a power-of-two scaled copy, X 2^e = h1 + h2 ("H-format": two 11-bit
+ * significands, the second signed against the first: 23 significant bits, |X 2^e - h1 - h2| <= 2^-23 |X 2^e|), and every product is
+ * three v_mfma_f32_32x32x16_f16 terms (h2 h1, h1 h2, h1 h1; the dropped h2 h2 is a zero-mean 2^-25 of the product in RMS, <= 2^-22
+ * worst case) with f32 accumulation: per-product error ~2^-24 RMS (f32's own product rounding), measured against fp64 3-10x below a
+ * k-ordered f32 fma chain on every operand class of tests/test_gpu_accuracy_class.py.  (Rounds 1-3 used an exact three-way bf16 split with six
  * terms: twice the matrix-pipe work and 1.5x the operand bytes - on a power-limited chip 1.4-1.7x the time,
  * profiles/r04_gemm_h_vs_p_step_shapes_v1.txt; scripts/lab/gemm_p_bf16x3_round3.hip.)
  * The operands arrive ALREADY split: the split is done ONCE by the producer of each tensor (LayerNorm, attention, GEMM epilogues,
@@ -54,7 +55,7 @@ extern "C" {
  * >= C inside the last granules are ZERO (the reduction axis relies on it); tile-granular reads run past the matrix into slack that
  * is never initialised and only reaches accumulators that are not stored.  The header is written and read on the DEVICE only: e is
  * chosen by the producer from an upper bound b >= max|X| so that b 2^e lies in [2^14, 2^15); elements >= 2^-18 b keep the full
- * relative accuracy, smaller ones an absolute accuracy of 2^-40 b.  amax / rn2sq / cn2sq (bounds of max|X| and of the largest
+ * relative accuracy, smaller ones an absolute accuracy of 2^-39 b.  amax / rn2sq / cn2sq (bounds of max|X| and of the largest
  * squared row / column 2-norm; 0 = unknown) feed the Cauchy-Schwarz bound with which a GEMM that WRITES H-format chooses its output's
  * exponent before its first tile is finished.
  * a_kc / b_kc = 1: the reduction runs along the columns C of that operand's matrix (x[M][K], W[N][K]: nn.Linear forward,

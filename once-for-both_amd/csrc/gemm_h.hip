@@ -2,9 +2,10 @@
 //
 // Why two f16 planes: the step runs at the package power cap, so its time is its energy.  Round 1-3 computed every f32
 // product as SIX v_mfma_f32_32x32x16_bf16 terms of an exact three-way bf16 split; a two-way f16 split of a power-of-two scaled copy
-// carries 22-24 significand bits in TWO planes and needs THREE terms (h2 h1, h1 h2, h1 h1; the dropped h2 h2 is <= 2^-24 of the
-// product): half the matrix-pipe work and two thirds of the operand bytes per product, at a per-product error of <= 3 2^-24 with the
-// accumulation still in f32 (measured against fp64: at or below a k-ordered f32 fma chain, tests/test_gpu_accuracy_class.py).
+// carries 23 significant bits in TWO planes and needs THREE terms (h2 h1, h1 h2, h1 h1; the dropped h2 h2 is a zero-mean 2^-25 of
+// the product in RMS, <= 2^-22 worst case): half the matrix-pipe work and two thirds of the operand bytes per product, at a
+// per-product error of ~2^-24 RMS with the accumulation still in f32 (measured against fp64: 3-10x BELOW a k-ordered f32 fma chain
+// on every operand class of tests/test_gpu_accuracy_class.py).
 // f16 has 5 exponent bits, so every tensor carries ONE power-of-two exponent e in its header (hformat.h); the kernel folds
 // 2^-(ea + eb) into alpha.
 //
@@ -333,6 +334,14 @@ __global__ __launch_bounds__(256) void gemm_h_bound_kernel(const ofb_gemm_h_args
   if (g.cbound_out) g.cbound_out[0] = bound;
 }
 
+#ifdef OFB_H_STAMPS
+// lab only (scripts/lab/stamp_gemm_h.py): s_memtime stamps of wave 0 of every workgroup: [wg][unit][4] = unit start, K loop start,
+// K loop end, epilogue end; [wg][7][0..1] = s_memrealtime at kernel start / end (100 MHz), [wg][7][2] = HW_ID
+__device__ unsigned long long ofb_h_stamps[1024 * 8 * 4];
+#define OFB_HSTAMP(slot) do { if (t == 0 && sidx < 7 && blockIdx.x < 1024) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); ofb_h_stamps[(blockIdx.x * 8 + sidx) * 4 + slot] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define OFB_HSTAMP(slot) do { } while (0)
+#endif
 #define OFB_VMW(N) case N: asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory"); break;
 __device__ __forceinline__ void vm_wait(int n) {           // n is wave-uniform
   switch (n) {
@@ -469,6 +478,15 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
   int sidx = 0;
   Seg cur = get_seg<TAIL>(p, v, 0);
   if (!cur.ok) return;
+#ifdef OFB_H_STAMPS
+  if (t == 0 && blockIdx.x < 1024) {
+    unsigned hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    ofb_h_stamps[(blockIdx.x * 8 + 7) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
+    ofb_h_stamps[(blockIdx.x * 8 + 7) * 4 + 2] = hw;
+    ofb_h_stamps[(blockIdx.x * 8 + 7) * 4 + 3] = __builtin_amdgcn_s_memtime();
+  }
+#endif
   // 2^-(ea + eb): the planes hold A 2^ea and B 2^eb
   const float alpha = TAIL ? 1.f : g.alpha * ofb_h_pow2(-(ofb_h_hdr(g.A)->e + ofb_h_hdr(g.B)->e));
   const char* Apl = ofb_h_planes(g.A);
@@ -486,12 +504,14 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
     const size_t a_step = a_k16 * KH, b_step = b_k16 * KH;
     const char* a_base = Apl + (A_KC ? (size_t)(cur.m0 / 4) * a_ncb * GRAN : (size_t)(cur.m0 / 16) * GRAN) + cur.it0 * a_k16;
     const char* b_base = Bpl + (B_KC ? (size_t)(cur.n0 / 4) * b_ncb * GRAN : (size_t)(cur.n0 / 16) * GRAN) + cur.it0 * b_k16;
+    OFB_HSTAMP(0);
     __builtin_amdgcn_s_barrier();                        // every wave is past the previous unit's LDS traffic
     issue(0, a_base, b_base);
     if (nst > 1) issue(1, a_base + a_step, b_base + b_step);
     if (NST > 2 && nst > 2) issue(2, a_base + 2 * a_step, b_base + 2 * b_step);
     vm_wait(((nst < NST ? nst : NST) - 1) * n_w);        // stage 0 landed; the other prologue stages may be in flight
     __builtin_amdgcn_s_barrier();
+    OFB_HSTAMP(1);
     rdA(alo, 0, 0, 0);
     rdB(bb[0], 0, 0);
     // the hand-over inside the LAST sub-step of stage i: this wave is done reading buf(i), its pieces of stage i+1 have landed
@@ -581,16 +601,18 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the trailing (unused) fragment reads
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (a half last stage leaves its own DMA unwaited)
+    OFB_HSTAMP(2);
 
     {
-      // Epilogue through LDS (the stage buffers are free now): the accumulators of HR rows of the tile are parked as
-      // T[col][HR rows (+4 pad)] f32 - a lane's four consecutive rows of a column are one ds_write_b128 - and all waves finish
-      // those rows together, one (4-row group, column) item per thread and trip: f32 loads / stores are coalesced along the
-      // columns, the H-format store is the item's two 8-byte plane slots.
-      constexpr int NC = (BN + 63) / 64, NRG = (HR / 4) / NW;
-      constexpr bool PART = (BN % 64) != 0;
-      static_assert((HR / 4) % NW == 0, "epilogue item map");
-      const bool lane_in_last = !PART || lane + 64 * (NC - 1) < BN;
+      // Epilogue through LDS (the stage buffers are free now).  The accumulators of HR rows of the tile are parked ROW-major as
+      // T[row][BN + 4] f32 and all waves finish those rows together.  WIDE form (interior tiles of launches whose f32 side tensors are
+      // 16-byte aligned with row strides that are multiples of 4): one item = (4-row group, 4 adjacent columns) per thread and trip:
+      // four ds_read_b128, every f32 load / store a dwordx4 (4 instead of 16 per 16 values), the H-format store two 16-byte stores per
+      // plane (4 adjacent 8-byte column slots are contiguous), bias / gate one float4.  The store tail of a 128 x 192 tile was
+      // issue-bound: 7 instructions per 4 outputs before, 10 per 16 now.  Edge tiles and unaligned launches take the
+      // NARROW form: one (4-row group, column) item per thread, dword accesses, per-element guards.
+      constexpr int TLD = BN + 4;
+      static_assert((HR + HR / 4) * TLD * 4 <= NST * STAGE, "epilogue patch + column-sum rows");
       constexpr bool ANY = (EPI & E_ANY) != 0;
       const bool has_c = ANY ? g.C != nullptr : (EPI & E_C) != 0, has_p = ANY ? g.Cp != nullptr : (EPI & E_P) != 0;
       const bool gelu = ANY ? g.act == OFB_ACT_GELU : (EPI & E_GELU) != 0, dg = ANY ? g.act == OFB_ACT_DGELU : (EPI & E_DGELU) != 0;
@@ -605,14 +627,9 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
       char* __restrict__ Cpl = g.Cp ? (char*)g.Cp + OFB_HHDR : nullptr;
       const float so = (!TAIL && has_p) ? ofb_h_pow2(reinterpret_cast<const ofb_hhdr*>(g.Cp)->e) : 1.f;   // written by the bound kernel
       const int rp_out = (g.M + 15) & ~15;
-      float biasv[NC], csv[NC], cacc[NC];
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        cacc[c] = 0.f;
-        const int col = cur.n0 + lane + 64 * c, colc = col < g.N ? col : g.N - 1;
-        biasv[c] = (!TAIL && g.bias) ? g.bias[colc] : 0.f;
-        csv[c] = (!TAIL && g.colscale) ? g.colscale[colc] : 1.f;
-      }
+      const bool interior = cur.m0 + BM <= g.M && cur.n0 + BN <= g.N;
+      const bool wide = TAIL || (interior && (p.stagger & 1) != 0);   // p.stagger bit 0: "wide epilogue allowed" (alignment checked on the host)
+      constexpr int NQ = BN / 4, NITEM = (HR / 4) * NQ, NIT = (NITEM + CF::NT - 1) / CF::NT;     // column quads per row; items per pass; per thread
       __builtin_amdgcn_s_barrier();                                 // every wave has finished its fragment reads / its LDS-DMA
 #pragma unroll
       for (int half = 0; half < BM / HR; ++half) {
@@ -622,111 +639,186 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
 #pragma unroll
             for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-              for (int gq = 0; gq < 4; ++gq) {
-                f32x4 q4 = {acc[mi][ni][4 * gq], acc[mi][ni][4 * gq + 1], acc[mi][ni][4 * gq + 2], acc[mi][ni][4 * gq + 3]};
-                *reinterpret_cast<f32x4*>(T + (wn0 + 32 * ni + l31) * TROW + (wm0 % HR) + 32 * mi + 8 * gq + 4 * h) = q4;
-              }
+              for (int r = 0; r < 16; ++r)
+                T[((wm0 % HR) + 32 * mi + 8 * (r >> 2) + 4 * h + (r & 3)) * TLD + wn0 + 32 * ni + l31] = acc[mi][ni][r];
         }
         __syncthreads();
-        if (TAIL) {                                                   // raw partial tile -> workspace[slot][BM][BN]
+        if (wide) {
+          float* S = T + HR * TLD;                                    // [HR / 4 row groups][TLD]: the items' column sums (colpart only)
+          // (one item at a time: with the items unrolled hipcc keeps three items' side inputs next to the other half's accumulators
+          // and spills)
+#pragma unroll 1
+          for (int k = 0; k < NIT; ++k) {
+            const int id = t + CF::NT * k;
+            const bool live = (NITEM % CF::NT == 0) || id < NITEM;
+            const int rgl = live ? id / NQ : 0, cq = live ? id - (id / NQ) * NQ : 0;
+            const int row0 = cur.m0 + HR * half + 4 * rgl, lcol = 4 * cq, col = cur.n0 + lcol;
+            f32x4 v[4];
 #pragma unroll
-          for (int k = 0; k < NRG; ++k) {
-            const int rgl = w + NW * k;
-#pragma unroll
-            for (int c = 0; c < NC; ++c) {
-              const int lcol = lane + 64 * c;
-              if (PART && c == NC - 1 && !lane_in_last) continue;
-              const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + lcol * TROW + 4 * rgl);
+            for (int tt = 0; tt < 4; ++tt) v[tt] = *reinterpret_cast<const f32x4*>(T + (4 * rgl + tt) * TLD + lcol);
+            if (TAIL) {                                               // raw partial tile -> workspace[slot][BM][BN]
               float* __restrict__ ws = g.workspace + (size_t)cur.slot * (BM * BN) + (size_t)(HR * half + 4 * rgl) * BN + lcol;
+              if (live) {
 #pragma unroll
-              for (int tt = 0; tt < 4; ++tt) ws[tt * BN] = q4[tt];
+                for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(ws + tt * BN) = v[tt];
+              }
+              continue;
+            }
+            // side inputs of the item first (one exposed latency), then arithmetic, then stores
+            f32x4 sa[4], sr[4];
+            float rsv[4];
+            f32x4 b4 = {0.f, 0.f, 0.f, 0.f}, c4 = {1.f, 1.f, 1.f, 1.f};
+            if (g.bias) b4 = *reinterpret_cast<const f32x4*>(g.bias + col);
+            if (g.colscale) c4 = *reinterpret_cast<const f32x4*>(g.colscale + col);
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+              const int row = row0 + tt;
+              rsv[tt] = has_rs ? rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
+              if (dg || mula) sa[tt] = *reinterpret_cast<const f32x4*>(auxr + (size_t)row * g.ldaux + col);
+              if (has_res) sr[tt] = *reinterpret_cast<const f32x4*>(resid + (size_t)row * g.ldr + col);
+            }
+            f32x4 o[4], ax[4];
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float val = (v[tt][e] * alpha + b4[e]) * c4[e];
+                if (gelu) {
+                  ax[tt][e] = val;
+                  val = ofb_gelu(val);
+                } else if (gelug) {
+                  float Phi, phi;
+                  ofb_gelu_parts(val, Phi, phi);
+                  ax[tt][e] = Phi + val * phi;
+                  val *= Phi;
+                } else if (dg) {
+                  val *= ofb_dgelu(sa[tt][e]);
+                } else if (mula) {
+                  val *= sa[tt][e];
+                }
+                val *= rsv[tt];
+                if (has_res) val += sr[tt][e];
+                o[tt][e] = val;
+              }
+            }
+            if (live) {
+              if ((gelu && auxw) || gelug) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(auxw + (size_t)(row0 + tt) * g.ldaux + col) = ax[tt];
+              }
+              if (has_c) {
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(Cout + (size_t)(row0 + tt) * g.ldc + col) = o[tt];
+              }
+              if (has_p) {
+                // column e of the quad: rows 0..3 -> one 8-byte slot per plane; the quad's four slots are 32 contiguous bytes per plane
+                unsigned h1[4][2], h2[4][2];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  ofb_hsplit_pair(o[0][e] * so, o[1][e] * so, h1[e][0], h2[e][0]);
+                  ofb_hsplit_pair(o[2][e] * so, o[3][e] * so, h1[e][1], h2[e][1]);
+                }
+                char* slot = Cpl + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8;
+                *reinterpret_cast<uint4*>(slot) = make_uint4(h1[0][0], h1[0][1], h1[1][0], h1[1][1]);
+                *reinterpret_cast<uint4*>(slot + 16) = make_uint4(h1[2][0], h1[2][1], h1[3][0], h1[3][1]);
+                *reinterpret_cast<uint4*>(slot + 128) = make_uint4(h2[0][0], h2[0][1], h2[1][0], h2[1][1]);
+                *reinterpret_cast<uint4*>(slot + 144) = make_uint4(h2[2][0], h2[2][1], h2[3][0], h2[3][1]);
+              }
+            }
+            if (g.colpart && live) {
+              f32x4 cs4;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) cs4[e] = (o[0][e] + o[1][e]) + (o[2][e] + o[3][e]);
+              *reinterpret_cast<f32x4*>(S + rgl * TLD + lcol) = cs4;
+            }
+          }
+          if (!TAIL && g.colpart) {
+            // column sums of this pass: one thread per column adds the row groups' sums in order; the passes of a tile in order too
+            __syncthreads();
+            if (t < BN) {
+              float sum = 0.f;
+#pragma unroll
+              for (int rg = 0; rg < HR / 4; ++rg) sum += S[rg * TLD + t];
+              float* cp = g.colpart + (size_t)(cur.m0 / BM) * g.N + cur.n0 + t;
+              if (half == 0) *cp = sum; else *cp += sum;
             }
           }
         } else {
-          auto pass = [&](auto GUARDED) __attribute__((always_inline)) {
-            constexpr bool GD = decltype(GUARDED)::value;
-            constexpr int KB = NRG > 4 ? NRG / 4 : NRG / 2, BI = KB * NC;
-            static_assert(NRG % 2 == 0 && NRG % KB == 0, "epilogue batches");
+          // NARROW form: thread = (column lane + 64 c, 4-row groups w, w + NW, ...), per-element guards
+          constexpr int NC = (BN + 63) / 64, NRG = (HR / 4) / NW;
+          static_assert((HR / 4) % NW == 0, "epilogue item map");
+          float cacc[NC];
 #pragma unroll
-            for (int k0 = 0; k0 < NRG; k0 += KB) {
-              f32x4 side[BI], side2[BI], rsv[KB];
+          for (int c = 0; c < NC; ++c) cacc[c] = 0.f;
+#pragma unroll 1
+          for (int k = 0; k < NRG; ++k) {
+            const int rgl = w + NW * k, row0 = cur.m0 + HR * half + 4 * rgl;
 #pragma unroll
-              for (int kk = 0; kk < KB; ++kk) {
-                const int row0 = cur.m0 + HR * half + 4 * (w + NW * (k0 + kk));
+            for (int c = 0; c < NC; ++c) {
+              const int lcol = lane + 64 * c, col = cur.n0 + lcol;
+              if (lcol >= BN) continue;
+              const bool colok = col < g.N;
+              const int colc = colok ? col : g.N - 1;
+              const float biasv = g.bias ? g.bias[colc] : 0.f, csv = g.colscale ? g.colscale[colc] : 1.f;
+              float pv[4];
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) {
-                  const int row = row0 + tt, rowc = (!GD || row < g.M) ? row : g.M - 1;
-                  rsv[kk][tt] = has_rs ? rowscale[g.rs_div == 1 ? rowc : rowc / g.rs_div] : 1.f;
-#pragma unroll
-                  for (int c = 0; c < NC; ++c) {
-                    const int col = cur.n0 + lane + 64 * c, colc = ((!GD && !PART) || col < g.N) ? col : g.N - 1;
-                    side[kk * NC + c][tt] = (dg || mula) ? auxr[(size_t)rowc * g.ldaux + colc] : 0.f;
-                    side2[kk * NC + c][tt] = has_res ? resid[(size_t)rowc * g.ldr + colc] : 0.f;
-                  }
+              for (int tt = 0; tt < 4; ++tt) {
+                const int row = row0 + tt;
+                const bool ok = colok && row < g.M;
+                const int rowc = row < g.M ? row : g.M - 1;
+                float val = (T[(4 * rgl + tt) * TLD + lcol] * alpha + biasv) * csv;
+                if (gelu) {
+                  if (auxw && ok) auxw[(size_t)row * g.ldaux + col] = val;
+                  val = ofb_gelu(val);
+                } else if (gelug) {
+                  float Phi, phi;
+                  ofb_gelu_parts(val, Phi, phi);
+                  if (ok) auxw[(size_t)row * g.ldaux + col] = Phi + val * phi;
+                  val *= Phi;
+                } else if (dg) {
+                  val *= ofb_dgelu(auxr[(size_t)rowc * g.ldaux + colc]);
+                } else if (mula) {
+                  val *= auxr[(size_t)rowc * g.ldaux + colc];
                 }
+                if (has_rs) val *= rowscale[g.rs_div == 1 ? rowc : rowc / g.rs_div];
+                if (has_res) val += resid[(size_t)rowc * g.ldr + colc];
+                if (has_c && ok) Cout[(size_t)row * g.ldc + col] = val;
+                pv[tt] = ok ? val : 0.f;
               }
-#pragma unroll
-              for (int kk = 0; kk < KB; ++kk) {
-                const int rgl = w + NW * (k0 + kk), row0 = cur.m0 + HR * half + 4 * rgl;
-#pragma unroll
-                for (int c = 0; c < NC; ++c) {
-                  const int lcol = lane + 64 * c, col = cur.n0 + lcol;
-                  if (PART && c == NC - 1 && !lane_in_last) continue;
-                  const f32x4 q4 = *reinterpret_cast<const f32x4*>(T + lcol * TROW + 4 * rgl);
-                  const bool colok = !GD || col < g.N;
-                  float pv[4];
-#pragma unroll
-                  for (int tt = 0; tt < 4; ++tt) {
-                    const int row = row0 + tt;
-                    const bool ok = !GD || (colok && row < g.M);
-                    float val = (q4[tt] * alpha + biasv[c]) * csv[c];
-                    if (gelu) {
-                      if (auxw && ok) auxw[(size_t)row * g.ldaux + col] = val;
-                      val = ofb_gelu(val);
-                    } else if (gelug) {
-                      float Phi, phi;
-                      ofb_gelu_parts(val, Phi, phi);
-                      if (ok) auxw[(size_t)row * g.ldaux + col] = Phi + val * phi;
-                      val *= Phi;
-                    } else if (dg) {
-                      val *= ofb_dgelu(side[kk * NC + c][tt]);
-                    } else if (mula) {
-                      val *= side[kk * NC + c][tt];
-                    }
-                    val = val * rsv[kk][tt] + side2[kk * NC + c][tt];
-                    if (has_c && ok) Cout[(size_t)row * g.ldc + col] = val;
-                    pv[tt] = ok ? val : 0.f;
-                  }
-                  cacc[c] += (pv[0] + pv[1]) + (pv[2] + pv[3]);
-                  if (has_p && (!GD || (row0 < rp_out && col < g.c_ncb * 16)))
-                    store_h4(Cpl + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8, pv[0] * so, pv[1] * so, pv[2] * so,
-                             pv[3] * so);
-                }
-              }
+              cacc[c] += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+              if (has_p && row0 < rp_out && col < g.c_ncb * 16)
+                store_h4(Cpl + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8, pv[0] * so, pv[1] * so, pv[2] * so,
+                         pv[3] * so);
             }
-          };
-          if (cur.m0 + BM <= g.M && cur.n0 + BN <= g.N) pass(std::false_type{});
-          else pass(std::true_type{});
+          }
+          if (g.colpart) {
+            __syncthreads();
+#pragma unroll
+            for (int c = 0; c < NC; ++c)
+              if (lane + 64 * c < BN) T[w * TLD + lane + 64 * c] = cacc[c];
+            __syncthreads();
+            if (t < BN && cur.n0 + t < g.N) {
+              float sum = 0.f;
+#pragma unroll
+              for (int ww = 0; ww < NW; ++ww) sum += T[ww * TLD + t];
+              float* cp = g.colpart + (size_t)(cur.m0 / BM) * g.N + cur.n0 + t;
+              if (half == 0) *cp = sum; else *cp += sum;
+            }
+          }
         }
         if (half + 1 < BM / HR) __syncthreads();                    // T is rewritten by the next pass (the next unit starts with a barrier)
       }
-      if (!TAIL && g.colpart) {
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < NC; ++c) T[w * BN + lane + 64 * c] = cacc[c];
-        __syncthreads();
-        if (t < BN && cur.n0 + t < g.N) {
-          float sum = 0.f;
-#pragma unroll
-          for (int ww = 0; ww < NW; ++ww) sum += T[ww * BN + t];
-          g.colpart[(size_t)(cur.m0 / BM) * g.N + cur.n0 + t] = sum;
-        }
-      }
     }
+    OFB_HSTAMP(3);
     const Seg nxt = get_seg<TAIL>(p, v, ++sidx);
     if (!nxt.ok) break;
     cur = nxt;
   }
+#ifdef OFB_H_STAMPS
+  if (t == 0 && blockIdx.x < 1024) {
+    ofb_h_stamps[(blockIdx.x * 8 + 7) * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
 }
 
 // Sums the partial tiles of each streamed tail tile in a fixed contributor order and applies the epilogue.
@@ -848,7 +940,13 @@ Plan plan_h(const ofb_gemm_h_args& g) {
     else if (bestS > 0) { p.S = bestS; p.qs = (p.I + bestS - 1) / bestS; }
     else { p.S = 0; p.qs = 0; }
   }
-  p.stagger = 0;
+  // "wide epilogue allowed" rides in plan.stagger: every f32 side tensor 16-byte aligned with a row stride that is a multiple of 4,
+  // N a multiple of 4 (so that tile-interior column quads stay aligned)
+  auto al = [](const void* q, int ld) { return q == nullptr || (ofb_aligned16(q) && (ld & 3) == 0); };
+  static int narrow = -1;
+  if (narrow < 0) { const char* e = getenv("OFB_GEMM_H_NARROW"); narrow = e ? atoi(e) : 0; }
+  p.stagger = (!narrow && (g.N & 3) == 0 && al(g.C, g.ldc) && al(g.aux, g.ldaux) && al(g.resid, g.ldr) && al(g.bias, 0) && al(g.colscale, 0) &&
+               (g.Cp == nullptr || (g.c_ncb * 16 >= g.N))) ? 1 : 0;
   return p;
 }
 
@@ -1020,3 +1118,9 @@ extern "C" int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream) {
   ofb_prof_post(0, s);
   return rc;
 }
+
+#ifdef OFB_H_STAMPS
+extern "C" int ofb_diag_h_stamps(unsigned long long* out_host) {      /* lab only, not part of the ABI */
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(ofb_h_stamps), sizeof(unsigned long long) * 1024 * 8 * 4);
+}
+#endif

@@ -392,7 +392,9 @@ __global__ __launch_bounds__(256) void ln_bwd_p_kernel(const float* __restrict__
 // Bound of LayerNorm backward's scaled output BEFORE it is computed (the exponent of its H-format planes): dx = rstd P(gamma * dy)
 // with P an orthogonal projection (it removes the components along 1 and xhat), so per row
 //   |dx|_inf <= |dx|_2 <= rstd |gamma * dy|_2   (+ the residual gradient's own max / norm), times the row's DropPath factor.
-// One wave per row; header.amax / header.rn2sq (zeroed by a memset node) take the maxima over the rows.
+// header.amax / header.rn2sq (zeroed by a memset node) take the maxima over the rows.  NJ > 0: even D, one wave per 4-row group, the
+// four rows' float2 loads in flight together (an HBM-bound pass over dy: 8-10 us for [25216][384]); NJ == 0: any D, a wave per row.
+template <int NJ>
 __global__ __launch_bounds__(256) void ln_bwd_stat_kernel(const float* __restrict__ dy, const float* __restrict__ gamma,
                                                           const float* __restrict__ rstd, const float* __restrict__ dres,
                                                           const float* __restrict__ rowscale, int rs_div, int rows, int D,
@@ -400,20 +402,58 @@ __global__ __launch_bounds__(256) void ln_bwd_stat_kernel(const float* __restric
   __shared__ float red[2][4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float am = 0.f, rn = 0.f;
-  for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
-    const float* d = dy + (size_t)row * D;
-    float ss = 0.f, rm = 0.f, rs2 = 0.f;
-    for (int c = lane; c < D; c += 64) {
-      const float t = d[c] * gamma[c];
-      ss += t * t;
-      if (dres) { const float r = dres[(size_t)row * D + c]; rm = fmaxf(rm, fabsf(r)); rs2 += r * r; }
+  if constexpr (NJ > 0) {
+    constexpr int NE = 2 * NJ;
+    float g[NE];
+    ln_p_load<NJ>(g, gamma, D, lane);
+    for (int rg = blockIdx.x * 4 + w; 4 * rg < rows; rg += gridDim.x * 4) {
+      float d[4][NE], rr[4][NE];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * rg + r;
+        if (row < rows) {
+          ln_p_load<NJ>(d[r], dy + (size_t)row * D, D, lane);
+          if (dres) ln_p_load<NJ>(rr[r], dres + (size_t)row * D, D, lane);
+        } else {
+#pragma unroll
+          for (int i = 0; i < NE; ++i) d[r][i] = 0.f;
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 4 * rg + r;
+        if (row >= rows) continue;
+        float ss = 0.f, rm = 0.f, rs2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+          const float t = d[r][i] * g[i];
+          ss += t * t;
+          if (dres) { rm = fmaxf(rm, fabsf(rr[r][i])); rs2 += rr[r][i] * rr[r][i]; }
+        }
+        const float n2 = rstd[row] * sqrtf(ofb_wave_sum(ss));
+        const float sc = rowscale ? fabsf(rowscale[rs_div == 1 ? row : row / rs_div]) : 1.f;
+        if (dres) { rm = ofb_wave_max_pos(rm); rs2 = sqrtf(ofb_wave_sum(rs2)); }
+        am = fmaxf(am, sc * (n2 + rm));
+        const float r2 = sc * (n2 + rs2);
+        rn = fmaxf(rn, r2 * r2);
+      }
     }
-    const float n2 = rstd[row] * sqrtf(ofb_wave_sum(ss));
-    const float sc = rowscale ? fabsf(rowscale[rs_div == 1 ? row : row / rs_div]) : 1.f;
-    if (dres) { rm = ofb_wave_max_pos(rm); rs2 = sqrtf(ofb_wave_sum(rs2)); }
-    am = fmaxf(am, sc * (n2 + rm));
-    const float r2 = sc * (n2 + rs2);
-    rn = fmaxf(rn, r2 * r2);
+  } else {
+    for (int row = blockIdx.x * 4 + w; row < rows; row += gridDim.x * 4) {
+      const float* d = dy + (size_t)row * D;
+      float ss = 0.f, rm = 0.f, rs2 = 0.f;
+      for (int c = lane; c < D; c += 64) {
+        const float t = d[c] * gamma[c];
+        ss += t * t;
+        if (dres) { const float r = dres[(size_t)row * D + c]; rm = fmaxf(rm, fabsf(r)); rs2 += r * r; }
+      }
+      const float n2 = rstd[row] * sqrtf(ofb_wave_sum(ss));
+      const float sc = rowscale ? fabsf(rowscale[rs_div == 1 ? row : row / rs_div]) : 1.f;
+      if (dres) { rm = ofb_wave_max_pos(rm); rs2 = sqrtf(ofb_wave_sum(rs2)); }
+      am = fmaxf(am, sc * (n2 + rm));
+      const float r2 = sc * (n2 + rs2);
+      rn = fmaxf(rn, r2 * r2);
+    }
   }
   if (lane == 0) { red[0][w] = am; red[1][w] = rn; }
   __syncthreads();
@@ -605,8 +645,17 @@ int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const flo
   ofb_prof_pre(3, s, (dxP ? 24.0 : 16.0) * rows * (double)D);
   if (dxP) {
     if (hipMemsetAsync(dxP, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
-    const int nb = ofb_cdiv(rows, 4) < 1024 ? ofb_cdiv(rows, 4) : 1024;
-    hipLaunchKernelGGL(ln_bwd_stat_kernel, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
+    const int nj = ofb_cdiv(D, 128);
+    if (D % 2 == 0) {
+      const int nb = ofb_cdiv(rows, 16) < 2048 ? ofb_cdiv(rows, 16) : 2048;
+      if (nj <= 2) hipLaunchKernelGGL(ln_bwd_stat_kernel<2>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
+      else if (nj <= 3) hipLaunchKernelGGL(ln_bwd_stat_kernel<3>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
+      else if (nj <= 6) hipLaunchKernelGGL(ln_bwd_stat_kernel<6>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
+      else hipLaunchKernelGGL(ln_bwd_stat_kernel<8>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
+    } else {
+      const int nb = ofb_cdiv(rows, 4) < 1024 ? ofb_cdiv(rows, 4) : 1024;
+      hipLaunchKernelGGL(ln_bwd_stat_kernel<0>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
+    }
   }
   if (dxP && D % 2 == 0) {
     const int nj = ofb_cdiv(D, 128);

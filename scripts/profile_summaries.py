@@ -24,10 +24,12 @@ def newest(pattern):
 
 def family(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
-    if n.startswith('gemm_p_fixup'):
-        return 'gemm_p (fix-up)'
-    if n.startswith('gemm_p_kernel'):
-        return 'gemm_p (main + tail)'
+    if n.startswith('gemm_h_fixup'):
+        return 'gemm_h (fix-up)'
+    if n.startswith('gemm_h_bound'):
+        return 'gemm_h (bound pre-kernel)'
+    if n.startswith('gemm_h_kernel'):
+        return 'gemm_h (main + tail)'
     if n.startswith('at::') or n.startswith('__amd'):
         return 'ATen / runtime'
     return n.split('(')[0].split('<')[0]
@@ -42,9 +44,9 @@ def kernel_summary(stats_csv, steps, out_name, extra=''):
     for r in rows:
         a = fam.setdefault(family(r['Name']), [0, 0.0])
         a[0] += int(r['Calls']); a[1] += float(r['TotalDurationNs'])
-    g = [v for k, v in fam.items() if k.startswith('gemm_p')]
+    g = [v for k, v in fam.items() if k.startswith('gemm_h')]
     if g:
-        lines.append(f'{"gemm_p (all)":60s} {sum(v[0] for v in g) / steps:7.1f}/step {sum(v[1] for v in g) / 1e6 / steps:8.3f} ms/step')
+        lines.append(f'{"gemm_h (all)":60s} {sum(v[0] for v in g) / steps:7.1f}/step {sum(v[1] for v in g) / 1e6 / steps:8.3f} ms/step')
     for k, (c, t) in sorted(fam.items(), key=lambda kv: -kv[1][1])[:32]:
         lines.append(f'{k[:60]:60s} {c / steps:7.1f}/step {t / 1e6 / steps:8.3f} ms/step  avg {t / c / 1e3:8.1f} us')
     open(os.path.join(S, out_name), 'w').write('\n'.join(lines) + '\n')
@@ -76,8 +78,8 @@ if f2:
     lines = [f'# {tag}: STEADY-STATE step = (20-step run - 12-step run) / 8 of rocprofv3 --kernel-trace --stats, OFB_SIDE_STREAM=0: model construction, '
              'optimizer-state allocation (2 fills per parameter) and first-step work cancel out',
              f'kernel time {sum(t for _, t in diff.values()) / 1e6 / ds:.2f} ms/step, {sum(c for c, _ in diff.values()) / ds:.0f} launches/step']
-    g = [v for k, v in diff.items() if k.startswith('gemm_p')]
-    lines.append(f'{"gemm_p (all)":60s} {sum(v[0] for v in g) / ds:7.1f}/step {sum(v[1] for v in g) / 1e6 / ds:8.3f} ms/step')
+    g = [v for k, v in diff.items() if k.startswith('gemm_h')]
+    lines.append(f'{"gemm_h (all)":60s} {sum(v[0] for v in g) / ds:7.1f}/step {sum(v[1] for v in g) / 1e6 / ds:8.3f} ms/step')
     for k, (c, t) in sorted(diff.items(), key=lambda kv: -kv[1][1])[:32]:
         if c > 0:
             lines.append(f'{k[:60]:60s} {c / ds:7.1f}/step {t / 1e6 / ds:8.3f} ms/step  avg {t / c / 1e3:8.1f} us')
@@ -98,8 +100,11 @@ for k in sorted(out['FETCH_SIZE'], key=lambda k: -out['FETCH_SIZE'][k][1])[:14]:
     n, fs = out['FETCH_SIZE'][k]
     ws = out['WRITE_SIZE'].get(k, [0, 0.0])[1]
     lines.append(f'{k[:44]:44s} launches/step {n / steps_pmc:7.1f}  read {2 * fs * 1024 / steps_pmc / 1e6:9.1f} MB/step  write {ws * 1024 / steps_pmc / 1e6:9.1f} MB/step')
-gb = sum(2 * out['FETCH_SIZE'][k][1] + out['WRITE_SIZE'].get(k, [0, 0.0])[1] for k in out['FETCH_SIZE'] if k.startswith('gemm_p')) * 1024 / steps_pmc
+gb = sum(2 * out['FETCH_SIZE'][k][1] + out['WRITE_SIZE'].get(k, [0, 0.0])[1] for k in out['FETCH_SIZE'] if k.startswith('gemm_h')) * 1024 / steps_pmc
 lines.append(f'GEMM_BYTES_PER_STEP {gb:.0f}   # all GEMM main / tail / fix-up launches of one step: FETCH_SIZE x2 + WRITE_SIZE (bench.py divides by its GEMM calls per step)')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench as _bench
+lines.append(f'CSRC_SHA {_bench.csrc_hash()}   # sha256 prefix of csrc/*.hip, csrc/*.h, include/*.h of the profiled build (bench.py quotes this file only for the same build)')
 open(os.path.join(S, f'{tag}_pmc_traffic_summary.txt'), 'w').write('\n'.join(lines) + '\n')
 print('\n'.join(lines[-3:]))
 

@@ -1,17 +1,21 @@
-"""The bench line says dtype "f32": these tests pin that the HIP GEMM and the attention forward deliver fp32-CLASS accuracy,
+"""The bench line says dtype "f32": these tests pin that the HIP GEMM and the attention kernels deliver fp32-CLASS accuracy,
 not merely "1e-3 of the reference".
 
-The GEMM computes each f32 product as six bf16 MFMA terms of an exact 3-way operand split (csrc/gemm.hip).  Dropping the three
-smallest kept terms (a "bf16x3" engine: hi*hi + hi*mid + mid*hi) would leave every model-level parity test green (they allow
-1e-3) while carrying only 16 significant bits per operand.  Two criteria, both applied to the three storage forms at
-K = 384 / 1536 / 25216:
+The engine (csrc/gemm_h.hip, csrc/hformat.h) holds every operand as two f16 numbers of a power-of-two scaled copy
+(x 2^e = h1 + h2: two 11-bit significands, the second signed against the first: 23 significant bits, residual <= 2^-23 |x|) and
+computes each f32 product as three f16 MFMA terms (h2 h1, h1 h2, h1 h1; the dropped h2 h2 is a zero-mean 2^-25 of the product in
+RMS) with f32 accumulation.  A cheaper engine - ONE 16-bit plane pair (8 + 8 significant
+bits, "bf16x3": hi*hi + hi*mid + mid*hi) - would leave every model-level parity test green (they allow 1e-3) while carrying only
+16 significant bits per operand.  Two criteria, both applied to the three storage forms at K = 384 / 1536 / 25216:
 
-1. EXACTNESS PROBE (deterministic): with one operand a selection matrix (one power of two per row, zeros elsewhere) every output
-   is a single product that fp32 represents exactly, so the result must be BIT-IDENTICAL to it: all 24 significant bits of the
-   other operand have to come through the matrix pipe.  A three-term engine returns 16-bit truncations and fails on ~every element.
+1. SINGLE-PRODUCT PROBE (deterministic): with one operand a selection matrix (one power of two per row, zeros elsewhere) every
+   output is a single product of a general value and a power of two; it must agree with the exact value to 3 * 2^-24 relative (the
+   operand's 2^-23 representation bound + the final f32 rounding) for every element inside the format's full-accuracy window
+   (>= 2^-18 of the tensor's maximum) and to 2^-39 of the maximum below it.
+   A 16-bit engine misses that on almost every element.
 2. STATISTICAL: the RMS error against fp64 may be at most 2x the RMS error of a k-ordered fp32 `fmaf` chain on the same data
    (what the f32-input MFMA / a scalar fp32 loop delivers), on random AND adversarial operands: wide dynamic range, values whose
-   information sits in the mid / lo planes, tiny magnitudes next to the flush-to-zero range, sign-constant data.
+   information sits below the leading 11 bits, tiny magnitudes, sign-constant data.
    `bf16x3_reference` emulates the cheaper engine on the CPU; wherever it is distinguishable from the chain (K <= 1536,
    cancelling data) the test asserts that it would FAIL, so the criterion is known to discriminate.
 """
@@ -112,20 +116,33 @@ def _selection(rows, K, seed):
     return s
 
 
+def _probe_ok(got, exact, amax_gen, sel_abs):
+    """per element: 3 * 2^-24 relative inside the full-accuracy window, 2^-39 of the general operand's maximum (times the selected
+    power of two of that row / column: sel_abs broadcasts against `exact`) below it"""
+    tol = 3 * 2.0 ** -24 * exact.abs() + 2.0 ** -39 * amax_gen * sel_abs.double()
+    return (got.double() - exact).abs() <= tol
+
+
 @pytest.mark.parametrize('form', FORMS)
 @pytest.mark.parametrize('M,N,K', CASES)
-def test_gemm_passes_all_24_bits(form, M, N, K):
-    """criterion 1: selection x general and general x selection are exact single products -> bit-identical results"""
+def test_gemm_single_products_keep_the_operand_bits(form, M, N, K):
+    """criterion 1: selection x general and general x selection are single products: every one within the engine's per-product bound"""
     gen_a, sel_b = _operands('wide_range', (M, K), 11), _selection(N, K, 12)
     got = _run(form, gen_a, sel_b)
-    exact = (gen_a.double() @ sel_b.double().t()).float()
-    assert torch.equal(got, exact), f'{form}: {(got != exact).sum().item()} of {got.numel()} selected values lost bits (A side)'
-    trunc = (bf16x3_reference(gen_a, sel_b).float() != exact).float().mean().item()
-    assert trunc > 0.9, 'the probe must be sensitive to a 16-bit engine'
+    exact = gen_a.double() @ sel_b.double().t()
+    sb = sel_b.abs().max(1).values.unsqueeze(0)                        # [1, N]: the power of two that column n selects with
+    ok = _probe_ok(got, exact, gen_a.abs().max().item(), sb)
+    assert ok.all(), f'{form}: {(~ok).sum().item()} of {ok.numel()} selected values outside the per-product bound (A side)'
+    cheap = _probe_ok(bf16x3_reference(gen_a, sel_b).float(), exact, gen_a.abs().max().item(), sb)
+    assert (~cheap).float().mean().item() > 0.3, 'the probe must be sensitive to a 16-bit engine'
     sel_a, gen_b = _selection(M, K, 13), _operands('low_planes', (N, K), 14)
     got = _run(form, sel_a, gen_b)
-    exact = (sel_a.double() @ gen_b.double().t()).float()
-    assert torch.equal(got, exact), f'{form}: {(got != exact).sum().item()} of {got.numel()} selected values lost bits (B side)'
+    exact = sel_a.double() @ gen_b.double().t()
+    sa = sel_a.abs().max(1).values.unsqueeze(1)                        # [M, 1]
+    ok = _probe_ok(got, exact, gen_b.abs().max().item(), sa)
+    assert ok.all(), f'{form}: {(~ok).sum().item()} of {ok.numel()} selected values outside the per-product bound (B side)'
+    cheap = _probe_ok(bf16x3_reference(sel_a, gen_b).float(), exact, gen_b.abs().max().item(), sa)
+    assert (~cheap).float().mean().item() > 0.8, 'the probe must be sensitive to a 16-bit engine'
 
 
 @pytest.mark.parametrize('form', FORMS)
@@ -146,7 +163,7 @@ def test_gemm_is_fp32_class(form, M, N, K, kind):
 def test_attention_forward_is_fp32_class(kind):
     """o = softmax(q k^T * scale) v at B=2, H=3, N=197, d=64 against fp64; the fp32-class criterion here is relative to an
     ordinary fp32 evaluation of the same expression (torch CPU): the kernel's error (RMS and worst case) may be at most 4x that
-    one's, and must be far below what 16-significant-bit operands would give (what a two-plane split keeps)."""
+    one's, and must be far below what 16-significant-bit operands would give (what a two-plane bf16 split keeps)."""
     from ofb_amd import hip
     B, H, N, d = 2, 3, 197, 64
     g = torch.Generator().manual_seed(7)
@@ -181,7 +198,7 @@ def test_attention_forward_is_fp32_class(kind):
 @pytest.mark.parametrize('kind', ['normal', 'sharp', 'low_planes'])
 def test_attention_backward_is_fp32_class(kind):
     """dq | dk | dv of o = softmax(q k^T * scale) v (reference models/layers.py:510-514 under autograd) from the split-engine
-    backward kernel (six bf16 MFMA terms per product) against fp64: per gradient the RMS error may be at most 4x that of an
+    backward kernel (three f16 MFMA terms per product) against fp64: per gradient the RMS error may be at most 4x that of an
     ordinary fp32 evaluation (torch CPU autograd in fp32), and a 16-significant-bit engine must be visible to the criterion."""
     from ofb_amd import hip
     B, H, N, d = 2, 3, 197, 64
@@ -210,17 +227,13 @@ def test_attention_backward_is_fp32_class(kind):
     dev = qkv.reshape(B * N, 3 * H * d).contiguous().cuda()
     out, lse = torch.empty(B * N, H * d, device='cuda'), torch.empty(2 * B * H, N, device='cuda')
     hip.attention_fwd(dev, out, lse, B, N, H, d, scale)
-    for form in ('f32', 'planes'):
-        if form == 'f32':
-            dq = torch.empty(B * N, 3 * H * d, device='cuda')
-            hip.attention_bwd(dev, out, lse, dout.cuda(), dq, B, N, H, d, scale)
-        else:
-            dP = hip.PMat.for_rows_written_by_kernel(B * N, 3 * H * d, 'cuda')
-            hip.attention_bwd_p(dev, out, lse, dout.cuda(), dP, torch.empty(B, 3 * H * d, device='cuda'), B, N, H, d, scale)
-            dq = dP.to_f32()
-        e_k = dq.cpu().double().reshape(B * N, 3, H * d) - exact
-        for i, name in enumerate(('dq', 'dk', 'dv')):
-            rk, rf, r16 = _rms(e_k[:, i]), _rms(e_f32[:, i]), _rms(e_16[:, i])
-            print(f'attention bwd {kind} {form} {name}: rms error kernel {rk:.2e}  fp32 cpu {rf:.2e}  16-bit operands {r16:.2e}')
-            assert r16 > 16 * rf, 'the criterion must be able to see a reduced-precision engine'
-            assert rk <= 4 * rf, f'attention backward {name} RMS error is not fp32-class'
+    dq = torch.empty(B * N, 3 * H * d, device='cuda')
+    amax = torch.zeros(1, device='cuda')
+    hip.attention_bwd(dev, out, lse, dout.cuda(), dq, B, N, H, d, scale, dqkv_amax=amax)
+    assert float(amax) == dq.abs().max().item(), 'the kernel reports the maximum of what it stored'
+    e_k = dq.cpu().double().reshape(B * N, 3, H * d) - exact
+    for i, name in enumerate(('dq', 'dk', 'dv')):
+        rk, rf, r16 = _rms(e_k[:, i]), _rms(e_f32[:, i]), _rms(e_16[:, i])
+        print(f'attention bwd {kind} {name}: rms error kernel {rk:.2e}  fp32 cpu {rf:.2e}  16-bit operands {r16:.2e}')
+        assert r16 > 16 * rf, 'the criterion must be able to see a reduced-precision engine'
+        assert rk <= 4 * rf, f'attention backward {name} RMS error is not fp32-class'

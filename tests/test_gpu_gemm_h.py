@@ -1,0 +1,239 @@
+"""H-format engine (csrc/gemm_h.hip, csrc/hformat.h) through the C ABI: f32 <-> plane conversion and its accuracy contract, the
+three operand-mode pairs, f32 and H-format outputs with the fused epilogues, ragged shapes and stream-K tails, against fp64 on the
+same seeded inputs."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float32) * scale
+
+
+def _close(got, exp, what, tol=3e-6):
+    err = (got.double().cpu() - exp).abs().max().item()
+    scale = exp.abs().max().item() + 1e-30
+    print(f'{what}: max abs err {err:.3e} (scale {scale:.3e})')
+    assert err <= tol * scale, what
+
+
+def _planes_close(pm, x, what='planes'):
+    """the format's contract: |X - (h1 + h2) 2^-e| <= 2^-23 |X| + 2^-39 bound per element, bound 2^e in [2^14, 2^15)"""
+    e, bound, _, _ = pm.header()
+    assert x.abs().max().item() <= bound and 2.0 ** 14 <= bound * 2.0 ** e < 2.0 ** 15, what
+    err = (pm.to_f32().double() - x.double()).abs()
+    tol = 2.0 ** -23 * x.double().abs() + 2.0 ** -39 * bound
+    assert (err <= tol).all(), f'{what}: {(err > tol).sum().item()} elements outside the format contract (max err {err.max().item():.3e})'
+
+
+@pytest.mark.parametrize('R,C', [(4, 16), (197, 384), (130, 70), (33, 17), (1000, 264)])
+def test_hformat_round_trip_contract(R, C):
+    """x 2^e = h1 + h2 with e from the measured maximum: 2^-23 relative inside the window, 2^-39 of the maximum below it; the header
+    holds the measured maximum and the largest squared row norm"""
+    from ofb_amd import hip
+    x = _mk((R, C), 1)
+    x[0, 0], x[-1, -1] = 0.0, -3.0e-20
+    x = (x * torch.pow(torch.tensor(2.0), torch.randint(-30, 30, (R, C)).float())).cuda()
+    pm = hip.to_hformat(x)
+    _planes_close(pm, x)
+    e, amax, rn2sq, _ = pm.header()
+    assert amax == x.abs().max().item()
+    assert abs(rn2sq - x.double().pow(2).sum(1).max().item()) <= 1e-5 * rn2sq
+    # narrow-range data (what the model produces): plain 2^-23 relative
+    y = (_mk((R, C), 3) + 3.0 * torch.sign(_mk((R, C), 4))).cuda()
+    back = hip.to_hformat(y).to_f32()
+    assert ((back - y).abs() <= 2.0 ** -23 * y.abs()).all()
+    rs = _mk(((R + 6) // 7,), 2).cuda()
+    pm = hip.to_hformat(x, rowscale=rs, rs_div=7)
+    _planes_close(pm, x * rs[torch.arange(R, device='cuda') // 7].unsqueeze(1), 'row-scaled planes')
+    # a caller-supplied (loose) bound instead of the statistics pass
+    b = (x.abs().max() * 7.0).reshape(1)
+    pm = hip.to_hformat(x, bound=b)
+    assert pm.header()[1] == float(b)
+    _planes_close(pm, x, 'planes under a loose bound')
+    # all-zero and non-finite-free corner: zeros stay zeros
+    z = torch.zeros(R, C, device='cuda')
+    assert torch.equal(hip.to_hformat(z).to_f32(), z)
+
+
+def test_hformat_with_column_sums():
+    """the conversion pass of a gradient also yields its column sums (bias gradient), DropPath row scale included"""
+    from ofb_amd import hip
+    R, C = 1970, 264
+    x = _mk((R, C), 5).cuda()
+    rs = _mk((10,), 6).cuda()
+    out = torch.full((C,), float('nan'), device='cuda')
+    pm = hip.to_hformat(x, rowscale=rs, rs_div=197, colsum_out=out)
+    scaled = x * rs[torch.arange(R, device='cuda') // 197].unsqueeze(1)
+    _planes_close(pm, scaled)
+    _close(out, scaled.double().sum(0).cpu(), 'column sums', tol=2e-6)
+    out2 = torch.empty(C, device='cuda')
+    hip.colsum_h(pm, out2)
+    _close(out2, scaled.double().sum(0).cpu(), 'column sums of an H-format matrix', tol=2e-6)
+
+
+SHAPES = [(256, 256, 64), (394, 384, 384), (591, 1152, 384), (130, 70, 36), (128, 1000, 384), (77, 13, 5), (591, 264, 200),
+          (2600, 520, 48), (8192, 1024, 80),
+          # widths that pad badly on 192 columns and M >= 1024: the 256 x 96 tile (C96) takes the token-row forms (kc,kc / kc,kr);
+          # the pruned / finetune widths of configs[4] (264, 480, 672, 160, 224, 576, 960) and odd ones
+          (1100, 264, 200), (2048, 480, 264), (1500, 96, 64), (1300, 672, 264), (1024, 100, 40), (5000, 224, 160), (1234, 77, 264),
+          (1027, 576, 264), (1500, 960, 264)]
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_gemm_h_modes_and_outputs(M, N, K):
+    from ofb_amd import hip
+    a, b = _mk((M, K), 3), _mk((N, K), 4)                       # logical A[M][K], B[N][K]
+    exact = a.double() @ b.double().t()
+    ad, bd = a.cuda(), b.cuda()
+    pa_kc, pb_kc = hip.to_hformat(ad), hip.to_hformat(bd)                                    # P matrices [rows][K]
+    pa_kr, pb_kr = hip.to_hformat(ad.t().contiguous()), hip.to_hformat(bd.t().contiguous())   # P matrices [K][rows]
+    for name, (A, B, akc, bkc) in {'kc,kc': (pa_kc, pb_kc, 1, 1), 'kc,kr': (pa_kc, pb_kr, 1, 0), 'kr,kr': (pa_kr, pb_kr, 0, 0)}.items():
+        out = torch.full((M, N), float('nan'), device='cuda')
+        outp = hip.HMat(M, N, 'cuda')
+        hip.gemm_h(A, B, akc, bkc, M, N, K, C_out=out, ldc=N, Cp=outp)
+        _close(out, exact, f'{name} {M}x{N}x{K} f32 out')
+        e, bound, _, _ = outp.header()
+        assert out.abs().max().item() <= bound, 'the Cauchy-Schwarz bound of the output'
+        assert (outp.to_f32() - out).abs().max().item() <= 2.0 ** -23 * bound, 'the H-format output carries the f32 result'
+        out2 = torch.empty(M, N, device='cuda')
+        hip.gemm_h(A, B, akc, bkc, M, N, K, C_out=out2, ldc=N)
+        assert torch.equal(out, out2), 'deterministic (fixed-order partial sums)'
+    # the zero padding of an H-format OUTPUT must be real zeros: feed it to a product that reduces over its padded rows
+    outp = hip.HMat(M, N, 'cuda')
+    outp.buf.fill_(0x7f)                                           # poison (NaN patterns) before the kernel writes it
+    hip.gemm_h(pa_kc, pb_kc, 1, 1, M, N, K, Cp=outp)
+    y = torch.empty(N, K, device='cuda')
+    hip.gemm_h(outp, pa_kc, 0, 0, N, K, M, C_out=y, ldc=K)          # y = out^T @ a   (reduction over M, padded to 16)
+    _close(y, exact.t() @ a.double(), 'H-format output as KR operand (zero padding)', tol=2e-5)
+
+
+@pytest.mark.parametrize('M,N,K', [(394, 384, 384), (300, 1536, 384), (130, 70, 36), (1200, 264, 72), (1400, 480, 264), (2100, 672, 100)])
+def test_gemm_h_epilogues(M, N, K):
+    from ofb_amd import hip
+    x, w, b = _mk((M, K), 5), _mk((N, K), 6, 0.1), _mk((N,), 7)
+    cs, res = _mk((N,), 8), _mk((M, N), 9)
+    rs = _mk(((M + 196) // 197,), 10)
+    xp, wp = hip.to_hformat(x.cuda()), hip.to_hformat(w.cuda())
+    bd, csd, resd, rsd = b.cuda(), cs.cuda(), res.cuda(), rs.cuda()
+    ref = x.double() @ w.double().t() + b.double()
+    pre = ref * cs.double()
+    # fc1 form: bias, gate column scale, GELU; f32 pre-activation to aux, gelu output as H-format only
+    aux, hp = torch.empty(M, N, device='cuda'), hip.HMat(M, N, 'cuda')
+    hip.gemm_h(xp, wp, 1, 1, M, N, K, Cp=hp, bias=bd, colscale=csd, aux=aux, ldaux=N, act=hip.ACT_GELU)
+    _close(aux, pre, 'gelu pre-activation')
+    _close(hp.to_f32(), torch.nn.functional.gelu(pre), 'gelu out (H-format)')
+    # proj / fc2 form: residual + per-sample row scale
+    out = torch.empty(M, N, device='cuda')
+    hip.gemm_h(xp, wp, 1, 1, M, N, K, C_out=out, ldc=N, bias=bd, rowscale=rsd, rs_div=197, resid=resd, ldr=N)
+    rows = torch.arange(M) // 197
+    _close(out, ref * rs.double()[rows].unsqueeze(1) + res.double(), 'residual + rowscale')
+    # dGELU form with H-format output
+    dp, cs_out = hip.HMat(M, N, 'cuda'), torch.full((N,), float('nan'), device='cuda')
+    hip.gemm_h(xp, wp, 1, 1, M, N, K, Cp=dp, aux=aux, ldaux=N, act=hip.ACT_DGELU, colsum_out=cs_out)
+    p = pre.clone().requires_grad_(True)
+    torch.nn.functional.gelu(p).sum().backward()
+    dref = (x.double() @ w.double().t()) * p.grad
+    _close(dp.to_f32(), dref, 'dgelu (H-format)')
+    _close(cs_out, dref.sum(0), 'column sums of the output from the fused epilogue', tol=1e-5)
+    # the pair the MLP branch uses: the forward saves GELU'(pre-activation), the backward epilogue multiplies by it
+    gaux, hp2 = torch.full((M, N), float('nan'), device='cuda'), hip.HMat(M, N, 'cuda')
+    hip.gemm_h(xp, wp, 1, 1, M, N, K, Cp=hp2, bias=bd, colscale=csd, aux=gaux, ldaux=N, act=hip.ACT_GELU_GRAD)
+    _close(gaux, p.grad, 'saved gelu derivative')
+    assert torch.equal(hp2.to_f32(), hp.to_f32())                       # same values, same bound, same exponent
+    dp2, cs2 = hip.HMat(M, N, 'cuda'), torch.full((N,), float('nan'), device='cuda')
+    hip.gemm_h(xp, wp, 1, 1, M, N, K, Cp=dp2, aux=gaux, ldaux=N, act=hip.ACT_MULAUX, colsum_out=cs2)
+    _close(dp2.to_f32(), dref, 'value x saved derivative (H-format)')
+    _close(cs2, dref.sum(0), 'column sums (saved-derivative form)', tol=1e-5)
+
+
+def test_gemm_h_deit_small_layer_shapes():
+    """the bs-128 DeiT-S shapes (25216 tokens): full rounds + streamed tail; strided row sample against fp64"""
+    from ofb_amd import hip
+    M, D = 128 * 197, 384
+    x = _mk((M, D), 11)
+    xp = hip.to_hformat(x.cuda())
+    rows = torch.arange(0, M, 97)
+    for N in (1152, 384, 1536):
+        w, b = _mk((N, D), 12, 0.05), _mk((N,), 13)
+        out = torch.empty(M, N, device='cuda')
+        hip.gemm_h(xp, hip.to_hformat(w.cuda()), 1, 1, M, N, D, C_out=out, ldc=N, bias=b.cuda())
+        _close(out[rows.cuda()], x[rows].double() @ w.double().t() + b.double(), f'deit-s N {N}')
+    # the fc2 input-gradient form at full size: 1576 tiles = 3 rounds + 5 whole tile rows in the streamed tail; the column sums of the
+    # H-format-only output come from both (fused epilogue of the rounds, fix-up kernel of the tail)
+    N = 1536
+    w, aux = _mk((N, D), 15, 0.05), _mk((M, N), 16)
+    dp, cs = hip.HMat(M, N, 'cuda'), torch.full((N,), float('nan'), device='cuda')
+    hip.gemm_h(xp, hip.to_hformat(w.cuda()), 1, 1, M, N, D, Cp=dp, aux=aux.cuda(), ldaux=N, act=hip.ACT_MULAUX, colsum_out=cs)
+    got = dp.to_f32()
+    _close(got[rows.cuda()], (x[rows].double() @ w.double().t()) * aux[rows].double(), 'value x aux, planes out, full size')
+    _close(cs, got.double().sum(0).cpu(), 'column sums over rounds + tail', tol=2e-6)
+    # weight gradient: dW[N][K] = dY^T X over all tokens (12 tiles, K = 25216: tail only)
+    dy = _mk((M, 1536), 14)
+    dw = torch.empty(1536, D, device='cuda')
+    hip.gemm_h(hip.to_hformat(dy.cuda()), xp, 0, 0, 1536, D, M, C_out=dw, ldc=D)
+    _close(dw, dy.double().t() @ x.double(), 'dW 1536x384x25216', tol=2e-5)
+
+
+def test_gemm_h_rejects_bad_arguments():
+    from ofb_amd import hip
+    a = hip.to_hformat(torch.zeros(32, 32, device='cuda'))
+    out = torch.zeros(32, 32, device='cuda')
+    with pytest.raises(hip.OfbError):
+        hip.gemm_h(a, a, 0, 1, 32, 32, 32, C_out=out, ldc=32)          # A^T B^T is not on the path
+    with pytest.raises(hip.OfbError):
+        hip.gemm_h(a, a, 1, 1, 32, 32, 32)                             # no output at all
+    with pytest.raises(hip.OfbError):
+        hip.gemm_h(a, a, 1, 1, 32, 32, 64, C_out=out, ldc=32)          # K beyond the operand's granule columns
+    with pytest.raises(hip.OfbError):
+        hip.gemm_h(a, a, 1, 1, 32, 32, 32, C_out=out, ldc=32, act=hip.ACT_DGELU)   # dGELU without aux
+    with pytest.raises(hip.OfbError):
+        hip.gemm_h(a, a, 1, 1, 32, 32, 32, C_out=out, ldc=32, act=hip.ACT_GELU_GRAD)   # save-derivative form without aux
+
+
+def test_weight_planes_are_refreshed_together():
+    """hip.weight_h: every registered weight is converted by ONE multi-tensor launch pair per epoch (ofb_to_hformat_multi); the planes
+    equal a single conversion, follow raw-pointer updates after bump_weight_epoch() and torch in-place edits (_version)"""
+    from ofb_amd import hip
+    shapes = [(1152, 384), (384, 384), (1536, 384), (384, 1536), (1000, 384), (70, 36), (33, 100)]
+    ws = [torch.nn.Parameter(_mk(s, 40 + i).cuda()) for i, s in enumerate(shapes)]
+    def same(pm, w):
+        return torch.equal(pm.to_f32(), hip.to_hformat(w.detach().contiguous()).to_f32()) and pm.header() == hip.to_hformat(w.detach().contiguous()).header()
+    for w in ws:
+        assert same(hip.weight_h(w), w)
+        assert ((hip.weight_h(w).to_f32() - w.detach()).abs() <= 2.0 ** -23 * w.detach().abs().max()).all()
+    bufs = [hip.weight_h(w).buf.data_ptr() for w in ws]
+    with torch.no_grad():
+        for w in ws:
+            w.mul_(1.5)                                       # torch in-place edit: _version moves
+    assert same(hip.weight_h(ws[3]), ws[3])
+    hip.lib().ofb_scale_rows                                  # (a raw-pointer edit below: only the epoch tells)
+    x = ws[0].detach().clone()
+    hip.scale_rows(x, torch.full((1152,), 2.0, device='cuda'), ws[0].data, 1152, 384)
+    assert not same(hip.weight_h(ws[0]), ws[0])      # stale by design until the epoch is bumped
+    hip.bump_weight_epoch()
+    for w, b in zip(ws, bufs):
+        pm = hip.weight_h(w)
+        assert same(pm, w) and pm.buf.data_ptr() == b                # same persistent planes, fresh content
+    # as GEMM operands (padding columns / rows of the multi-tensor conversion must be zero)
+    a = _mk((50, 36), 60).cuda()
+    out = torch.empty(50, 70, device='cuda')
+    hip.gemm_h(hip.to_hformat(a), hip.weight_h(ws[5]), 1, 1, 50, 70, 36, C_out=out, ldc=70)
+    _close(out, a.double().cpu() @ ws[5].detach().double().cpu().t(), 'multi-converted planes as GEMM operand', tol=2e-6)
+
+
+@pytest.mark.parametrize('B,Cin,S,patch', [(3, 3, 224, 16), (2, 3, 64, 16), (5, 1, 48, 8)])
+def test_patchify_planes_hold_the_patch_matrix(B, Cin, S, patch):
+    """ofb_patchify_hformat: the planes of the patch-embedding conv's GEMM operand written straight from the images hold exactly the
+    patch matrix of models/layers.py:177 (Conv2d with kernel = stride = patch): rows (b, py, px), columns (c, i, j)"""
+    from ofb_amd import hip
+    g = torch.Generator().manual_seed(B + S)
+    imgs = torch.randn(B, Cin, S, S, generator=g).cuda()
+    gh = S // patch
+    ref = imgs.reshape(B, Cin, gh, patch, gh, patch).permute(0, 2, 4, 1, 3, 5).reshape(B * gh * gh, Cin * patch * patch)
+    pm = hip.patchify_hformat(imgs, patch)
+    assert (pm.R, pm.C) == tuple(ref.shape)
+    assert pm.header()[1] == imgs.abs().max().item()
+    assert ((pm.to_f32() - ref).abs() <= 2.0 ** -23 * imgs.abs().max()).all()

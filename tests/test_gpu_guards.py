@@ -63,8 +63,8 @@ def test_whole_object_checkpoint_has_no_planes_and_reloads_on_the_fast_path():
     m2._forced = m._forced
     before = hip.weight_registry_size()
     singles = []
-    real_into = hip.to_pformat_into
-    hip.to_pformat_into = lambda *a, **k: (singles.append(1), real_into(*a, **k))[1]
+    real_into = hip.to_hformat
+    hip.to_hformat = lambda *a, **k: (singles.append(1) if k.get('into') is not None else None, real_into(*a, **k))[1]
     try:
         with torch.no_grad():
             l2 = m2(inputs['imgs'].cuda())[0]
@@ -72,7 +72,7 @@ def test_whole_object_checkpoint_has_no_planes_and_reloads_on_the_fast_path():
             l2 = m2(inputs['imgs'].cuda())[0]                                  # second forward: every weight is registered by now
             l1 = m(inputs['imgs'].cuda())[0]
     finally:
-        hip.to_pformat_into = real_into
+        hip.to_hformat = real_into
     assert torch.equal(l1, l2)
     assert hip.weight_registry_size() > before                                 # the reloaded weights hold their own planes
     assert len(singles) == n_first, 'registered weights fell back to per-tensor conversions instead of the multi-tensor refresh'

@@ -46,31 +46,35 @@ def test_layernorm_fwd_bwd(rows, D):
 
 
 @pytest.mark.parametrize('rows,D', [(394, 384), (197 * 8, 192), (33, 102), (200, 768), (7, 1024), (5000, 384), (20, 77), (64, 96)])
-def test_layernorm_pformat_outputs(rows, D):
-    """the P-format variants (planes written by the LayerNorm kernels themselves): same f32 rows as the plain kernels (up to the
-    compiler's fma contraction), planes == the kernel's own f32 rows (x the DropPath row scale in backward) exactly, third partial
-    section = their column sums"""
+def test_layernorm_hformat_outputs(rows, D):
+    """the H-format variants (planes written by the LayerNorm kernels themselves): same f32 rows as the plain kernels (up to the
+    compiler's fma contraction), planes == the kernel's own f32 rows (x the DropPath row scale in backward) to 2^-23 of the header's
+    bound, the bound really bounds, third partial section = the column sums of the scaled rows"""
     from ofb_amd import hip
     x, g, b = (_mk((rows, D), 1) * 2 + 0.3).cuda(), (_mk((D,), 2) * 0.2 + 1).cuda(), (_mk((D,), 3) * 0.1).cuda()
     dy, dres = _mk((rows, D), 4).cuda(), _mk((rows, D), 5).cuda()
     y0, y1 = torch.empty(rows, D, device='cuda'), torch.empty(rows, D, device='cuda')
     m0, r0, m1, r1 = (torch.empty(rows, device='cuda') for _ in range(4))
     hip.layernorm_fwd(x, g, b, y0, m0, r0, rows, D, 1e-6)
-    yP = hip.PMat.for_rows_written_by_kernel(rows, D, 'cuda')
-    hip.layernorm_fwd_p(x, g, b, y1, yP, m1, r1, rows, D, 1e-6)
-    _close(y1, y0.cpu(), 1e-6, 'ln fwd rows of the P variant')
+    yP = hip.HMat.for_rows_written_by_kernel(rows, D, 'cuda')
+    hip.layernorm_fwd_h(x, g, b, y1, yP, m1, r1, rows, D, 1e-6)
+    _close(y1, y0.cpu(), 1e-6, 'ln fwd rows of the H variant')
     _close(m1, m0.cpu(), 1e-6, 'mean')
     _close(r1, r0.cpu(), 1e-6, 'rstd')
-    assert torch.equal(yP.to_f32(), y1)
+    e, bound, rn2sq, _ = yP.header()
+    assert y1.abs().max().item() <= bound <= (D ** 0.5 * g.abs().max().item() + b.abs().max().item()) * 1.001, 'analytic bound of |LN(x)|'
+    assert y1.double().pow(2).sum(1).max().item() <= rn2sq, 'row-norm bound'
+    assert 2.0 ** 14 <= bound * 2.0 ** e < 2.0 ** 15
+    assert (yP.to_f32() - y1).abs().max().item() <= 2.0 ** -23 * bound
     y0 = y1
     # as a GEMM operand (reduction along the columns and along the rows): padding rows / columns must be zero
     w = _mk((48, D), 8).cuda()
     out = torch.empty(rows, 48, device='cuda')
-    hip.gemm_p(yP, hip.to_pformat(w), 1, 1, rows, 48, D, C_out=out, ldc=48)
+    hip.gemm_h(yP, hip.to_hformat(w), 1, 1, rows, 48, D, C_out=out, ldc=48)
     _close(out, y0.double().cpu() @ w.double().cpu().t(), 2e-6, 'LN planes as GEMM operand (K along columns)')
     out2 = torch.empty(D, 48, device='cuda')
     z = _mk((rows, 48), 9).cuda()
-    hip.gemm_p(yP, hip.to_pformat(z), 0, 0, D, 48, rows, C_out=out2, ldc=48)
+    hip.gemm_h(yP, hip.to_hformat(z), 0, 0, D, 48, rows, C_out=out2, ldc=48)
     _close(out2, y0.double().cpu().t() @ z.double().cpu(), 2e-6, 'LN planes as GEMM operand (K along rows)')
 
     nb = hip.layernorm_bwd_blocks(rows)
@@ -80,16 +84,20 @@ def test_layernorm_pformat_outputs(rows, D):
         part2, dx0 = torch.empty(nb, 2, D, device='cuda'), torch.empty(rows, D, device='cuda')
         hip.layernorm_bwd(dy, x, g, m0, r0, dr, dx0, part2, rows, D)
         part3, dx1 = torch.empty(nb, 3, D, device='cuda'), torch.empty(rows, D, device='cuda')
-        dxP = hip.PMat.for_rows_written_by_kernel(rows, D, 'cuda')
-        hip.layernorm_bwd_p(dy, x, g, m0, r0, dr, dx1, part3, dxP, rowscale, max(rs_div, 1), rows, D)
-        _close(dx1, dx0.cpu(), 2e-6, 'ln dx of the P variant')
+        dxP = hip.HMat.for_rows_written_by_kernel(rows, D, 'cuda')
+        hip.layernorm_bwd_h(dy, x, g, m0, r0, dr, dx1, part3, dxP, rowscale, max(rs_div, 1), rows, D)
+        _close(dx1, dx0.cpu(), 2e-6, 'ln dx of the H variant')
         sc = torch.ones(rows, device='cuda') if rowscale is None else rowscale[torch.arange(rows, device='cuda') // rs_div]
         scaled = dx1 * sc.unsqueeze(1)
-        assert torch.equal(dxP.to_f32(), scaled)
+        e, bound, rn2sq, _ = dxP.header()
+        amax = scaled.abs().max().item()
+        assert amax <= bound <= 64 * amax, f'the projection bound of |dx| must hold and stay useful: {bound:.3e} vs max {amax:.3e}'
+        assert scaled.double().pow(2).sum(1).max().item() <= rn2sq
+        assert (dxP.to_f32() - scaled).abs().max().item() <= 2.0 ** -23 * bound
         s2, s3 = torch.empty(2 * D, device='cuda'), torch.empty(3 * D, device='cuda')
         hip.colsum(part2, 2 * D, nb, 2 * D, s2)
         hip.colsum(part3, 3 * D, nb, 3 * D, s3)
-        _close(s3[:2 * D], s2.cpu(), 2e-6, 'dgamma | dbeta of the P variant')
+        _close(s3[:2 * D], s2.cpu(), 2e-6, 'dgamma | dbeta of the H variant')
         _close(s3[2 * D:], scaled.double().sum(0).cpu(), 1e-5, 'column sums of the scaled dx rows')
 
 
