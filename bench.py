@@ -182,6 +182,25 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)                     # the ranks inherit stdout: rank 0 prints the one JSON line
 
 
+def report_exchange(reducer, rank, world, dev, seconds, steps):
+    """every rank's view of the gradient exchange on stderr (rank order): buckets, collectives per step and the EXPOSED exchange
+    time per step - the host-side wait in finalize() that backward did not hide - next to its step time: the first real multi-GPU
+    run is diagnosable from the tail of its log"""
+    import torch.distributed as dist
+    if reducer is None or not dist.is_initialized():
+        return
+    n = max(reducer.finalized, 1)
+    mine = torch.tensor([rank, len(reducer.buckets), reducer.collectives / n, reducer.wait_seconds / n * 1e3, seconds / max(steps, 1) * 1e3],
+                        dtype=torch.float64, device=dev if dev is not None else 'cpu')
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(rows, mine)
+    if rank == 0:
+        for r in rows:
+            r = r.tolist()
+            print(f'[exchange] rank {int(r[0])}: {int(r[1])} buckets, {r[2]:.1f} collectives/step, exposed wait {r[3]:.3f} ms/step of '
+                  f'{r[4]:.3f} ms/step', file=sys.stderr, flush=True)
+
+
 def rehearsal(args, rank, world, real_stdout):
     """OFB_BENCH_REHEARSAL=gloo: the launcher, rendezvous, broadcast, bucketed exchange and JSON plumbing of the N-rank run on
     CPU tensors over gloo (no GPU in the build container; tests/test_dp_gloo.py drives it).  Not a benchmark."""
@@ -203,6 +222,10 @@ def rehearsal(args, rank, world, real_stdout):
         red.finalize()
     dt = time.perf_counter() - t0
     ok = same and all(torch.allclose(p.grad, torch.full_like(p, sum(range(1, world + 1)) / world)) for p in params)
+    # collective C4 (epoch statistics): the fused sum of every rank's running sums
+    tot, w = ofb_amd.dp.sum_across_ranks(torch.tensor([float(rank + 1), 1.0]))
+    ok = ok and w == world and tot.tolist() == [float(sum(range(1, world + 1))), float(world)]
+    report_exchange(red, rank, world, None, dt, args.steps)
     flag = torch.tensor([1.0 if ok else 0.0])
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
@@ -378,6 +401,7 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
     loss_val = float(out[3].detach())
+    report_exchange(reducer, rank, world, dev, dt, args.steps)
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()

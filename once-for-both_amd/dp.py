@@ -129,6 +129,7 @@ class GradAllReducer:
         # the exchange is a plain SUM, so no extra pass over the gradients is needed; prescaled=False divides afterwards.
         self.grad_scale = 1.0 / self.world
         self.prescaled = False
+        self.wait_seconds, self.collectives, self.finalized = 0.0, 0, 0
         # gradient accumulation: with sync = False a backward only accumulates into the local .grad (DDP's no_sync()); the
         # micro-step that closes the accumulation window exchanges the accumulated gradients once.  Exchanging every
         # micro-step (as the reference does, SURVEY D-7) would SUM the already-reduced part again, because .grad is re-pointed
@@ -218,15 +219,38 @@ class GradAllReducer:
         for bi in range(len(self.buckets)):
             if not self._launched[bi] and any(p.grad is not None for p in self.buckets[bi]):
                 self._launch(bi)
+        import time
+        t0 = time.perf_counter()
         for bi, work in self._works:
             if work is not None:
                 work.wait()
                 if not self.prescaled:
                     self._flat[bi].div_(self.world)
+        # host-side time spent waiting for the exchanges of this step (the EXPOSED part: what backward did not hide) and the number of
+        # collectives, for bench.py's per-rank report
+        self.wait_seconds += time.perf_counter() - t0
+        self.collectives += sum(1 for _, w in self._works if w is not None)
+        self.finalized += 1
+        if self._flat and self._flat[0].is_cuda:
+            # late bucket launches (above) and one-rank / no-collective runs finish their buckets on the side stream and nothing else
+            # joins it before the optimizer: whoever reads .grad after finalize() (clipping, a norm log, a test) must see them complete
+            from . import hip
+            hip.join_side()
         self._works = []
         self._ready = [0] * len(self.buckets)
         self._launched = [False] * len(self.buckets)
         self._handed.clear()
+
+
+def sum_across_ranks(vec, process_group=None):
+    """Collective C4 of SURVEY 2.2 (reference engine.py:216 / :70 `metric_logger.synchronize_between_processes()`, utils.py:41-52): the
+    epoch's running sums (losses, counts) of every rank in ONE fused all-reduce; returns (summed vector, world size).  A no-op
+    without a process group."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return vec, 1
+    out = vec.detach().clone()
+    dist.all_reduce(out, op=dist.ReduceOp.SUM, group=process_group)
+    return out, dist.get_world_size(process_group)
 
 
 def average_scalars(tensors, process_group=None):

@@ -142,6 +142,9 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
             opt.zero_grad(set_to_none=True)
     execute_pruned = False
     stats, t0 = {}, time.time()
+    if device is not None and torch.device(device).type == 'cuda':
+        from . import hip
+        hip.reset_nonfinite(device)                      # the device-side NaN gate is scoped to this epoch loop, not to the process
     # epoch statistics stay on the device (MetricLogger.global_avg of the reference, engine.py:87-90,186-199): running sums of
     # the four losses plus a count of non-finite totals; the host reads them at print points only
     sums = None
@@ -186,6 +189,11 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
                 print('Loss is {}, stopping training'.format(lv if not math.isfinite(lv) else 'non-finite in an earlier micro-step'))
                 sys.exit(1)
             n_seen = it + 1
+            if it == n_iter - 1:
+                # epoch end: the averages of ALL ranks (engine.py:216, utils.py:41-52): one fused all-reduce of the device vector
+                from .dp import sum_across_ranks
+                tot, w = sum_across_ranks(sums, reducer.group if reducer is not None else None)
+                host, n_seen = tot.tolist(), n_seen * w
             stats = dict(loss_total=host[0] / n_seen, loss_param=host[1] / n_seen, loss_arch=host[2] / n_seen,
                          loss_decoder=host[3] / n_seen, lr_param=optimizer_param.param_groups[0]['lr'])       # epoch global averages
             print(f'Epoch: [{epoch}] [{it}/{n_iter}] loss_total: {lv:.5f} ' + ' '.join(f'{k}(avg): {v:.5f}' for k, v in stats.items())
@@ -213,6 +221,9 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
     accum_iter = args.accum_iter
     optimizer.zero_grad(set_to_none=True)
     n_iter, stats = len(data_loader), {}
+    if device is not None and torch.device(device).type == 'cuda':
+        from . import hip
+        hip.reset_nonfinite(device)
     sums = None                                          # device-side [sum of losses, count of non-finite losses]
     for it, (samples, targets) in enumerate(data_loader):
         samples, targets = samples.to(device, non_blocking=True), targets.to(device, non_blocking=True)
@@ -244,7 +255,12 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
             if not math.isfinite(lv) or host[1] > 0:
                 print('Loss is {}, stopping training'.format(lv if not math.isfinite(lv) else 'non-finite in an earlier micro-step'))
                 sys.exit(1)
-            stats = dict(loss=host[0] / (it + 1), lr=optimizer.param_groups[0]['lr'])                    # epoch global average
+            n_seen = it + 1
+            if it == n_iter - 1:                         # epoch end: all ranks' average (engine.py:70, utils.py:41-52)
+                from .dp import sum_across_ranks
+                tot, w = sum_across_ranks(sums, reducer.group if reducer is not None else None)
+                host, n_seen = tot.tolist(), n_seen * w
+            stats = dict(loss=host[0] / n_seen, lr=optimizer.param_groups[0]['lr'])                    # epoch global average
     return stats
 
 

@@ -293,11 +293,16 @@ def bump_weight_epoch():
     _gw_jobs.clear()
 
 
+_forward_hooks = []          # callables run at the start of every model forward (ops.begin_step: leftovers of a backward that raised)
+
+
 def begin_forward():
-    """called by the models at the start of every forward pass: all registered weights are re-converted (one multi-tensor launch,
-    ~50 us for DeiT-S) by the first GEMM of the pass.  In a training step this coincides with the refresh the optimizer step
-    asks for anyway."""
+    """called by the models at the start of every forward pass: all registered weights are re-converted (one multi-tensor launch
+    pair, ~50 us for DeiT-S) by the first GEMM of the pass.  In a training step this coincides with the refresh the optimizer
+    step asks for anyway."""
     bump_weight_epoch()
+    for f in _forward_hooks:
+        f()
 
 
 class PformatJob(C.Structure):

@@ -94,15 +94,31 @@ def _side_ok(*params, tokens=None):
     return True
 
 
+_deferred_params = set()                  # id()s of the parameters that were handed an unreduced (deferred) gradient in this pass
+
+
 def _end_of_backward_callback():
     """once per backward pass: the side stream is joined and the queued column sums (hip.colsum_deferred) are reduced"""
     if not _cb_queued[0]:
         def _done():
             _cb_queued[0] = False
+            _deferred_params.clear()
             hip.join_side()
             hip.flush_deferred()
         torch.autograd.Variable._execution_engine.queue_callback(_done)
         _cb_queued[0] = True
+
+
+def begin_step():
+    """called at the start of every model forward: a backward pass that raised leaves its end-of-pass callback unqueued-but-flagged
+    and its deferred jobs behind; start clean"""
+    if _cb_queued[0] or _deferred_params or hip._deferred:
+        _cb_queued[0] = False
+        _deferred_params.clear()
+        hip._deferred.clear()
+
+
+hip._forward_hooks.append(begin_step)
 
 
 class _nullctx:
@@ -229,8 +245,11 @@ class LayerNorm(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.fork = fork
         ctx.up = up
-        # deferred parameter-gradient reductions need leaves that are not being accumulated into (see _ln_colsum)
-        ctx.defer_ok = gamma.is_leaf and beta.is_leaf and gamma.grad is None and beta.grad is None
+        # deferred parameter-gradient reductions need leaves that are not being accumulated into (see _ln_colsum); the upstream
+        # branch's output bias (the third section of the partials) is one of the consumers
+        ub = up[1] if (up is not None and len(up) > 1) else None
+        ctx.defer_params = (gamma, beta) + ((ub,) if ub is not None else ())
+        ctx.defer_ok = all(q.is_leaf and q.grad is None and not q._backward_hooks for q in ctx.defer_params)
         if fork:
             return y, x.view_as(x)
         return y
@@ -267,10 +286,16 @@ def _ln_colsum(part, width, nb, dgb, ctx):
     readers are the optimizer and the gradient exchange, so the reduction is queued and runs with all the others of this backward
     pass in ONE launch (hip.flush_deferred) - unless a gradient is being accumulated into right now (AccumulateGrad adds at once)
     or the consumer of the bias part is not a leaf (then ctx.defer_ok is False)."""
-    if _DEFER_COLSUM and ctx.defer_ok:
+    # ... and no parameter may receive a SECOND gradient in this pass while its first one is still unreduced (a LayerNorm module
+    # used twice in one graph: autograd would add the two buffers at once)
+    ids = [id(q) for q in getattr(ctx, 'defer_params', ())]
+    if _DEFER_COLSUM and ctx.defer_ok and not any(i in _deferred_params for i in ids):
+        _deferred_params.update(ids)
         hip.colsum_deferred(part, width, nb, width, dgb)
         _end_of_backward_callback()
     else:
+        if any(i in _deferred_params for i in ids):
+            hip.flush_deferred()                          # the earlier, still unreduced gradient of the shared parameter
         hip.colsum(part, width, nb, width, dgb)
 
 
@@ -454,13 +479,13 @@ class MlpBranch(torch.autograd.Function):
 
 def attn_branch(x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale):
     out = AttnBranch.apply(x, resid, wqkv, bqkv, wproj, bproj, g, rowscale, heads, scale, getattr(g, '_ofb_g3', None))
-    out._ofb_up = (rowscale,)                                # for the LayerNorm that reads this output (see LayerNorm)
+    out._ofb_up = (rowscale, bproj)                          # for the LayerNorm that reads this output (see LayerNorm)
     return out
 
 
 def mlp_branch(x, resid, w1, b1, w2, b2, g, rowscale):
     out = MlpBranch.apply(x, resid, w1, b1, w2, b2, g, rowscale)
-    out._ofb_up = (rowscale,)
+    out._ofb_up = (rowscale, b2)
     return out
 
 

@@ -148,6 +148,69 @@ def test_broadcast_and_rebuild_world2():
         assert dict(out) == {0: 1, 1: 1}
 
 
+def _worker_epoch_stats(rank, world, port, out):
+    """collective C4 (reference engine.py:216 / :70, utils.py:41-52): the epoch's loss averages are over ALL ranks.  Drives
+    engine.train_one_epoch on a CPU stand-in model over gloo: every rank sees different losses, all ranks must report the same
+    global average at the end of the epoch."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import types
+    import ofb_amd
+    from ofb_amd import engine
+    from ofb_amd.dp import GradAllReducer, sum_across_ranks
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(4, 1)
+    red = GradAllReducer(list(lin.parameters()), bucket_bytes=1024)
+
+    class Opt:
+        param_groups = [{'lr': 0.1}]
+        def step(self): pass
+        def zero_grad(self, set_to_none=True):
+            for p in lin.parameters():
+                p.grad = None
+
+    class Sched:
+        def step_update(self, k): pass
+
+    data = [(torch.full((2, 4), float(rank + 1 + i)), torch.zeros(2)) for i in range(3)]
+    crit = lambda x, y, t: y.mean() * 0 + x.mean()             # the loss IS the batch mean: rank r, iteration i -> r + 1 + i
+    stats = engine.train_one_epoch(lin, crit, data, Opt(), Sched(), torch.device('cpu'), 0, args=types.SimpleNamespace(accum_iter=1), reducer=red)
+    exp = sum(r + 1 + i for r in range(world) for i in range(3)) / (3 * world)
+    assert abs(stats['loss'] - exp) < 1e-6, (rank, stats, exp)
+    tot, w = sum_across_ranks(torch.tensor([1.0, float(rank)]))
+    assert w == world and tot.tolist() == [float(world), float(sum(range(world)))]
+    out[rank] = 1
+    dist.destroy_process_group()
+
+
+def test_epoch_statistics_are_averaged_over_ranks_world2():
+    mp.set_start_method('spawn', force=True)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_epoch_stats, args=(2, _free_port(), out), nprocs=2, join=True)
+        assert dict(out) == {0: 1, 1: 1}
+
+
+def test_bench_self_launch_four_ranks():
+    """the self-launch path with FOUR ranks (gloo rehearsal): rendezvous, broadcast, bucketed exchange, the fused statistics
+    collective and the per-rank exchange report"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OFB_BENCH_REHEARSAL'] = 'gloo'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1'], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    res = json.loads(lines[0])
+    assert res['n_gpus'] == 4 and res['config']['collective']['ranks'] == 4 and res['config']['exchange_ok'] is True
+    rep = [l for l in r.stderr.splitlines() if l.startswith('[exchange] rank')]
+    assert len(rep) == 4 and all('exposed wait' in l for l in rep), r.stderr[-1500:]
+
+
 def test_bench_self_launch_two_ranks():
     """`python bench.py --gpus 2` from a bare shell (no torchrun, WORLD_SIZE unset) must start two ranks that rendezvous, run the
     reducer and print ONE JSON line with n_gpus = 2; rehearsed on CPU / gloo (OFB_BENCH_REHEARSAL), on MI355X the same launcher

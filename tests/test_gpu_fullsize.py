@@ -1,26 +1,27 @@
-"""BASELINE configs[1] at full size (DeiT-S, bs 128): the oracle cannot run this in seconds, so the HIP step is checked through
+"""BASELINE configs[1]-[4] at FULL size (DeiT-S bs 128; the same under a one-rank RCCL exchange with the default 25-MB buckets;
+DeiT-B bs 64; the pruned finetune subnet at bs 256): the oracle cannot run these in seconds, so the HIP step is checked through
 size-independent properties - run-to-run bit-identity (every reduction has a fixed order), batch-chunk consistency of the
-forward, and central finite differences of the full search loss with respect to search parameters."""
+forward, and central finite differences of the full loss with respect to parameters."""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
 
-def _setup(seed=0, drop_path=0.1):
+def _setup(seed=0, drop_path=0.1, arch='deit_small', B=128):
     import ofb_amd
     from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
     torch.manual_seed(seed)
     dev = torch.device('cuda')
-    m = ofb_amd.create_model('deit_small_patch16_224_mim', method='search', num_classes=1000, drop_path_rate=drop_path,
+    m = ofb_amd.create_model(f'{arch}_patch16_224_mim', method='search', num_classes=1000, drop_path_rate=drop_path,
                              patch_search=False, mask_ratio=1.0).to(dev)
     m.correct_require_grad(0.5, 0.5, 0, 0.5)
     m.adjust_masking_ratio(0.0, 20, 100)
     crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, 0.5, 0.5, 0.0, 0.5, 5.0)
     g = torch.Generator(device=dev).manual_seed(1234)
-    imgs = torch.randn(128, 3, 224, 224, device=dev, generator=g)
-    labels = torch.randint(0, 1000, (128,), device=dev, generator=g)
-    B, L, depth = 128, 196, 12
+    imgs = torch.randn(B, 3, 224, 224, device=dev, generator=g)
+    labels = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    L, depth = 196, 12
     m._forced = dict(patch_noise=torch.rand(B, L, device=dev, generator=g), droppath_u=torch.rand(2 * depth, B, device=dev, generator=g))
     return m, crit, imgs, labels
 
@@ -84,3 +85,144 @@ def test_full_size_gradients_match_finite_differences():
         fd = (vals[0] - vals[1]) / (2 * eps)
         print(f'{name}{idx}: grad {g:.5e}  finite difference {fd:.5e}')
         assert abs(fd - g) <= 2e-2 * max(abs(g), abs(fd)) + 2e-4, name
+
+
+def test_deit_base_bs64_step_properties():
+    """configs[3] (reference search.py:617-620 with --model deit_base..., bs 64 per GPU): M = 12608 token rows, D = 768 - other
+    stream-K plans and tile counts than DeiT-S.  Bit-reproducible gradients, batch-separable forward, finite differences."""
+    m, crit, imgs, labels = _setup(arch='deit_base', B=64)
+    m.train()
+    grads = []
+    for _ in range(2):
+        for p in m.parameters():
+            p.grad = None
+        total, _ = _loss(m, crit, imgs, labels)
+        total.backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert len(grads[0]) > 190
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+        assert bool(torch.isfinite(grads[0][k]).all()), k
+    params = dict(m.named_parameters())
+    for name, idx in [('blocks.4.attn.alpha', (1, 2)), ('blocks.8.mlp.alpha', (0, 3)), ('patch_embed.alpha', (0, 7)), ('blocks.1.mlp.score', (0, 100))]:
+        p = params[name]
+        g = float(grads[0][name][idx])
+        eps = 2e-2 if 'alpha' in name else 1e-1
+        vals = []
+        for sgn in (1.0, -1.0):
+            with torch.no_grad():
+                p[idx] += sgn * eps
+                vals.append(float(_loss(m, crit, imgs, labels)[0]))
+                p[idx] -= sgn * eps
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        print(f'deit-b {name}{idx}: grad {g:.5e}  finite difference {fd:.5e}')
+        assert abs(fd - g) <= 2e-2 * max(abs(g), abs(fd)) + 2e-4, name
+    m.eval()
+    with torch.no_grad():
+        full = m(imgs)[0]
+        parts = torch.cat([m(imgs[i:i + 16])[0] for i in range(0, 64, 16)])
+    err = float((full - parts).norm() / full.norm())
+    print(f'deit-b batch-chunk rel err {err:.2e}')
+    assert err < 2e-6
+
+
+def test_finetune_subnet_bs256_step_properties():
+    """configs[4] (reference finetune.py:421-424, engine.py:18-72): the pruned OFB-DeiT-C-like subnet of bench.py --mode finetune
+    (embed 264, ragged heads / hidden widths) at bs 256: M = 50432 token rows on 264-wide tiles (the 256 x 96 tile and its tail
+    policy).  Bit-reproducible gradients, batch-separable forward, finite differences on weights."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    import ofb_amd
+    dev = torch.device('cuda')
+    torch.manual_seed(0)
+    model, macs, nparams = bench.build_finetune_subnet(ofb_amd, dev, 1000)
+    model.train(False)                                       # finetune.py:445: eval-mode semantics during finetune
+    g = torch.Generator(device=dev).manual_seed(4321)
+    imgs = torch.randn(256, 3, 224, 224, device=dev, generator=g)
+    target = torch.softmax(torch.randn(256, 1000, device=dev, generator=g) * 3, -1)
+    crit = ofb_amd.data.SoftTargetCrossEntropy()
+
+    def loss_of():
+        return crit(model(imgs), target)
+
+    grads = []
+    for _ in range(2):
+        for p in model.parameters():
+            p.grad = None
+        loss_of().backward()
+        torch.cuda.synchronize()
+        grads.append({k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None})
+    assert len(grads[0]) > 100
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+        assert bool(torch.isfinite(grads[0][k]).all()), k
+    params = dict(model.named_parameters())
+    from ofb_amd import hip
+    for name in ('blocks.3.mlp.fc1.weight', 'blocks.7.attn.qkv.weight', 'head.weight', 'blocks.0.norm1.weight'):
+        p = params[name]
+        idx = tuple(min(3, s - 1) for s in p.shape)
+        gnum = float(grads[0][name][idx])
+        eps = 0.05
+        vals = []
+        for sgn in (1.0, -1.0):
+            with torch.no_grad():
+                p[idx] += sgn * eps
+                hip.bump_weight_epoch()
+                vals.append(float(loss_of()))
+                p[idx] -= sgn * eps
+        hip.bump_weight_epoch()
+        fd = (vals[0] - vals[1]) / (2 * eps)
+        print(f'finetune {name}{idx}: grad {gnum:.5e}  finite difference {fd:.5e}')
+        assert abs(fd - gnum) <= 3e-2 * max(abs(gnum), abs(fd)) + 2e-5, name
+    with torch.no_grad():
+        full = model(imgs)
+        parts = torch.cat([model(imgs[i:i + 64]) for i in range(0, 256, 64)])
+    err = float((full - parts).norm() / full.norm())
+    print(f'finetune batch-chunk rel err {err:.2e}')
+    assert err < 2e-6
+
+
+def test_deit_small_bs128_one_rank_rccl_exchange_is_transparent():
+    """configs[2] (reference search.py:617-620: DistributedDataParallel around the model): DeiT-S bs 128 under a ONE-rank RCCL group with
+    the reducer's DEFAULT 25-MB buckets, side stream on, two optimizer steps - the parameters must be BIT-identical to the run
+    without a reducer (world size 1: the average IS the gradient)."""
+    import os
+    import socket
+    import torch.distributed as dist
+    import ofb_amd
+    from ofb_amd import engine, hip
+    dev = torch.device('cuda', 0)
+    created = False
+    if not dist.is_initialized():
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        hip.ensure_side_stream(dev)
+        dist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', world_size=1, rank=0, device_id=dev)
+        created = True
+    try:
+        finals = []
+        for use_reducer in (False, True):
+            m, crit, imgs, labels = _setup(seed=3)
+            m.train()
+            opts = engine.build_optimizers(m, 2.5e-4 * 128 / 256)
+            red = ofb_amd.dp.GradAllReducer(list(m.parameters()), force_collective=True) if use_reducer else None
+            if red is not None:
+                assert len(red.buckets) >= 3 and red.bucket_bytes == 25 * 1024 * 1024
+            for _ in range(2):
+                engine.search_step(m, crit, imgs, labels, 1.0, opts, reducer=red)
+            torch.cuda.synchronize()
+            if red is not None:
+                assert red.collectives >= 2 * len(red.buckets)
+                red.close()
+            finals.append({k: v.detach().clone() for k, v in m.state_dict().items()})
+        for k in finals[0]:
+            assert torch.equal(finals[0][k], finals[1][k]), k
+    finally:
+        if created:
+            torch.cuda.synchronize()
+            dist.destroy_process_group()

@@ -167,3 +167,46 @@ def test_nonfinite_loss_freezes_optimizer_and_ema():
         assert all(torch.equal(v, good_ema[k]) for k, v in ema.ema.state_dict().items())
     finally:
         hip.reset_nonfinite()
+
+
+def test_layernorm_module_used_twice_and_hooked_parameters_get_whole_gradients():
+    """LayerNorm's dgamma / dbeta (and the upstream branch's bias gradient) are normally handed to autograd UNREDUCED
+    and filled by one multi-job launch at the end of backward.  That is only legal while nobody reads them earlier: a module used
+    twice in one graph (autograd adds the two buffers at once), a parameter with a tensor hook, a parameter that already holds a
+    gradient - all must take the immediate reduction."""
+    from ofb_amd import hip, layers
+    torch.manual_seed(0)
+    D, rows = 96, 400
+    ln = layers.LayerNorm(D, eps=1e-6).cuda()
+    with torch.no_grad():
+        ln.weight.normal_(1.0, 0.2)
+        ln.bias.normal_(0.0, 0.1)
+    x1, x2 = torch.randn(rows, D, device='cuda'), torch.randn(rows, D, device='cuda') * 2 + 1
+    w1, w2 = torch.randn(rows, D, device='cuda'), torch.randn(rows, D, device='cuda')
+
+    def ref():
+        g, b = ln.weight.detach().double().requires_grad_(True), ln.bias.detach().double().requires_grad_(True)
+        y = (torch.nn.functional.layer_norm(x1.double(), (D,), g, b, 1e-6) * w1.double()).sum() + \
+            (torch.nn.functional.layer_norm(x2.double(), (D,), g, b, 1e-6) * w2.double()).sum()
+        y.backward()
+        return g.grad, b.grad
+
+    gw, gb = ref()
+    seen = []
+    for hooked in (False, True):
+        ln.weight.grad = ln.bias.grad = None
+        h = ln.weight.register_hook(lambda g_: seen.append(g_.clone())) if hooked else None
+        ((ln(x1) * w1).sum() + (ln(x2) * w2).sum()).backward()
+        torch.cuda.synchronize()
+        if h is not None:
+            h.remove()
+        assert (ln.weight.grad.double() - gw.cuda()).abs().max().item() < 1e-3 * gw.abs().max().item()
+        assert (ln.bias.grad.double() - gb.cuda()).abs().max().item() < 1e-3 * gb.abs().max().item()
+    # the hook saw complete gradients (their sum is the total), never an unfilled buffer
+    assert seen and (sum(seen).double() - gw.cuda()).abs().max().item() < 1e-3 * gw.abs().max().item()
+    # a backward that raises must not poison the next step: the queued jobs and the once-per-pass flag are dropped at the next forward
+    from ofb_amd import ops
+    ops._cb_queued[0] = True
+    hip._deferred.append((x1, 1, 1, 1, x1))
+    hip.begin_forward()
+    assert not ops._cb_queued[0] and not hip._deferred

@@ -104,7 +104,7 @@ def test_search_step_matches_reference_golden(tag):
         if e > worst:
             worst, worst_k = e, k
         assert abs(float(g.double().norm()) - gn) <= TOL * gn, (k, float(g.norm()), gn)
-        assert e < 3 * TOL, (k, e)
+        assert e < TOL, (k, e)                                   # north_star's 1e-3 (measured worst case 1.7e-5)
     print(f'  {tag}: worst grad rel err {worst:.2e} ({worst_k})')
 
     # one step of the three fused AdamW optimizers (search.py:486-559 grouping)
