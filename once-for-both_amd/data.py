@@ -554,18 +554,82 @@ class JpegDecoder:
     the Huffman stage of every file runs on a pool of host threads (csrc/jpeg.hip ofb_jpeg_decode_coefficients: plain C++, the
     ctypes call releases the GIL) straight into one pinned int16 staging buffer, ONE H2D copy moves the coefficients, two launches
     (IDCT per 8x8 block; chroma upsampling + YCbCr -> RGB per pixel) produce the pixels of the whole batch.  Arithmetic = libjpeg's
-    default path (JDCT_ISLOW, fancy upsampling), bit-exact with Pillow on the committed fixtures.  Scope: baseline / extended-
-    sequential Huffman files with 1 or 3 components; a progressive / CMYK / arithmetic-coded file raises hip.OfbError."""
+    default path (JDCT_ISLOW, fancy upsampling), bit-exact with Pillow on the committed fixtures.  Scope of the native stages:
+    baseline / extended-sequential Huffman files with 1 or 3 YCbCr components.  The files of a batch that fall outside it
+    (progressive, CMYK / YCCK, arithmetic-coded, 12-bit, RGB-stored Adobe files, PNGs with a .JPEG name - ImageNet-1k holds a few of
+    each) do NOT fail the batch: each one goes through `fallback(bytes) -> HxWx3 uint8 array` - by default exactly the reference's
+    loader, PIL `Image.open(...).convert('RGB')` (datasets.py:90-125 via torchvision's default_loader) - and its pixels are uploaded
+    into the same output buffer.  `fallback=None` and no Pillow: hip.OfbError naming the indices of the rejected files."""
 
-    def __init__(self, device='cuda', threads=None):
+    def __init__(self, device='cuda', threads=None, fallback='pil'):
         self.device = torch.device(device)
         self.threads = int(threads) if threads else max(1, min(16, _cpu_share()))
         self._pins, self._slot = [None, None], 0
+        self.fallback = fallback
+        self.n_fallback = 0                                   # files decoded by the fallback so far (statistics)
+
+    @staticmethod
+    def _pil(blob):
+        import io
+        from PIL import Image
+        with Image.open(io.BytesIO(blob)) as im:
+            return np.asarray(im.convert('RGB'))
+
+    def _split(self, blobs):
+        """(indices the native stages accept, indices they reject) from the per-file header parse"""
+        ok, bad = [], []
+        for i, b in enumerate(blobs):
+            try:
+                hip.jpeg_parse(bytes(b))
+                ok.append(i)
+            except hip.OfbError:
+                bad.append(i)
+        return ok, bad
 
     def decode(self, blobs):
         """-> (flat uint8 device tensor, byte offset of each image's [H][W][3] pixels, [(H, W)])"""
         if self.device.type != 'cuda':
             raise hip.OfbError('once-for-both_amd kernels need device tensors (no CPU fallback); JpegDecoder was built for ' + str(self.device))
+        try:
+            return self._decode_native(blobs)
+        except hip.OfbError:
+            ok, bad = self._split(blobs)
+            if not bad:
+                raise                                          # every header parses: a corrupt entropy stream - not a scope question
+        fb = self._pil if self.fallback == 'pil' else self.fallback
+        if fb is None:
+            raise hip.OfbError(f'JpegDecoder: files {bad} of the batch are outside the native decoder (progressive / CMYK / ...) and no '
+                               'fallback decoder was given')
+        try:
+            extra = [np.ascontiguousarray(fb(bytes(blobs[i]))) for i in bad]
+        except ImportError as e:
+            raise hip.OfbError(f'JpegDecoder: files {bad} need the fallback decoder, and Pillow is not importable') from e
+        for i, a in zip(bad, extra):
+            if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+                raise hip.OfbError(f'JpegDecoder: the fallback decoder must return HxWx3 uint8 (file {i})')
+        self.n_fallback += len(bad)
+        tail = sum((a.size + 15) // 16 * 16 for a in extra)
+        if ok:
+            out, offs_ok, sizes_ok = self._decode_native([blobs[i] for i in ok], tail_bytes=tail)
+            base = out.numel() - tail
+        else:
+            out, offs_ok, sizes_ok, base = torch.empty(tail, device=self.device, dtype=torch.uint8), [], [], 0
+        host = torch.empty(tail, dtype=torch.uint8, pin_memory=True)
+        hnp, offs_bad, o = host.numpy(), [], 0
+        for a in extra:
+            hnp[o:o + a.size] = a.reshape(-1)
+            offs_bad.append(base + o)
+            o += (a.size + 15) // 16 * 16
+        out[base:base + tail].copy_(host, non_blocking=True)
+        self._keep_fb = host
+        offs, sizes = [0] * len(blobs), [None] * len(blobs)
+        for i, oo, ss in zip(ok, offs_ok, sizes_ok):
+            offs[i], sizes[i] = oo, ss
+        for i, oo, a in zip(bad, offs_bad, extra):
+            offs[i], sizes[i] = oo, (int(a.shape[0]), int(a.shape[1]))
+        return out, offs, sizes
+
+    def _decode_native(self, blobs, tail_bytes=0):
         pb = hip.jpeg_plan_batch(blobs)                       # headers of all files, batch layout, device job records (native)
         self._slot ^= 1
         pin = self._pins[self._slot]
@@ -579,7 +643,8 @@ class JpegDecoder:
         done.record()
         jobs_dev, host = hip.upload_structs(pb.jobs, self.device)
         planes = torch.empty(pb.plane_total, device=self.device, dtype=torch.uint8)
-        out = torch.empty(pb.out_total, device=self.device, dtype=torch.uint8)
+        out_total = (pb.out_total + 15) // 16 * 16
+        out = torch.empty(out_total + tail_bytes, device=self.device, dtype=torch.uint8)       # + room for the fallback-decoded files
         hip.jpeg_decode_pixels(jobs_dev, pb.n, pb.max_blocks, pb.max_w, pb.max_h, coef, planes, out)
         self._keep = (jobs_dev, host, coef, planes)
         offs = [int(j.out_off) for j in pb.jobs]

@@ -55,6 +55,22 @@ def main():
     buf = io.BytesIO()
     Image.fromarray(picture(40, 40, 99)).save(buf, 'JPEG', quality=80, progressive=True)
     out['progressive.jpg'] = np.frombuffer(buf.getvalue(), np.uint8)
+    # files OUTSIDE the native decoder's scope that ImageNet-1k really contains (round 4): the loader must route them to its fallback
+    # (PIL, the reference's own loader) instead of failing the batch; 'oos_*.rgb' = Pillow's pixels
+    oos = {}
+    oos['oos_progressive'] = (picture(40, 40, 99), dict(quality=80, progressive=True), 'RGB')
+    oos['oos_cmyk'] = (picture(35, 51, 7), dict(quality=85), 'CMYK')
+    oos['oos_adobe_rgb'] = (picture(24, 40, 5), dict(quality=90, subsampling=0, keep_rgb=True), 'RGB')
+    for name, (img, kw, mode) in oos.items():
+        pil = Image.fromarray(img)
+        if mode == 'CMYK':
+            pil = pil.convert('CMYK')
+        buf = io.BytesIO()
+        pil.save(buf, 'JPEG', **kw)
+        data = buf.getvalue()
+        out[f'{name}.jpg'] = np.frombuffer(data, np.uint8)
+        out[f'{name}.rgb'] = np.asarray(Image.open(io.BytesIO(data)).convert('RGB'))
+        print(f'{name}: {len(data)} bytes -> {out[name + ".rgb"].shape}')
     path = os.path.join(HERE, 'jpeg_cases.npz')
     np.savez_compressed(path, **out)
     print(f'-> {path} {os.path.getsize(path) / 1024:.0f} KiB')

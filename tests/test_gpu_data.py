@@ -204,7 +204,7 @@ def test_jpeg_decode_matches_pillow_fixtures():
     import os
     import ofb_amd
     z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'jpeg_cases.npz'))
-    names = [k[:-4] for k in z.files if k.endswith('.jpg') and k != 'progressive.jpg']
+    names = [k[:-4] for k in z.files if k.endswith('.jpg') and k != 'progressive.jpg' and not k.startswith('oos_')]
     dec = ofb_amd.JpegDecoder('cuda', threads=4)
     for rnd in range(2):                                                       # second round reuses the staging buffers
         flat, offs, sizes = dec.decode([z[n + '.jpg'].tobytes() for n in names])
@@ -214,8 +214,20 @@ def test_jpeg_decode_matches_pillow_fixtures():
             exp = z[n + '.rgb']
             assert got.shape == exp.shape, n
             assert np.array_equal(got, exp), f'{n}: {int((got != exp).sum())} bytes differ, max {np.abs(got.astype(int) - exp).max()}'
-    with pytest.raises(ofb_amd.hip.OfbError):
-        dec.decode([z['progressive.jpg'].tobytes()])
+    # files outside the native stages' scope (progressive, CMYK, RGB-stored Adobe) do not fail the batch: each goes through the
+    # fallback - the reference's own loader, PIL convert('RGB') - and lands in the same buffer; the others stay native and bit-exact
+    mixed = ['q70_420_129x97', 'oos_progressive', 'q85_gray_45x33', 'oos_cmyk', 'oos_adobe_rgb', 'q90_422_64x48']
+    flat, offs, sizes = dec.decode([z[n + '.jpg'].tobytes() for n in mixed])
+    torch.cuda.synchronize()
+    assert dec.n_fallback == 3
+    for n, o, (h, w) in zip(mixed, offs, sizes):
+        got = flat[o:o + h * w * 3].view(h, w, 3).cpu().numpy()
+        assert np.array_equal(got, z[n + '.rgb']), n
+    flat, offs, sizes = dec.decode([z['oos_cmyk.jpg'].tobytes()])                 # a batch made of fallback files only
+    assert np.array_equal(flat[offs[0]:offs[0] + sizes[0][0] * sizes[0][1] * 3].view(*sizes[0], 3).cpu().numpy(), z['oos_cmyk.rgb'])
+    strict = ofb_amd.JpegDecoder('cuda', threads=2, fallback=None)
+    with pytest.raises(ofb_amd.hip.OfbError, match=r'files \[1\]'):
+        strict.decode([z['q90_422_64x48.jpg'].tobytes(), z['oos_progressive.jpg'].tobytes()])
 
 
 def test_device_transform_accepts_jpeg_files():

@@ -15,7 +15,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'jpe
 
 def _cases():
     z = np.load(GOLDEN)
-    return [(k[:-4], z[k].tobytes(), z[k[:-4] + '.rgb']) for k in z.files if k.endswith('.jpg') and k != 'progressive.jpg']
+    return [(k[:-4], z[k].tobytes(), z[k[:-4] + '.rgb']) for k in z.files if k.endswith('.jpg') and k != 'progressive.jpg' and not k.startswith('oos_')]
 
 
 @pytest.mark.parametrize('name,data,rgb', _cases(), ids=[c[0] for c in _cases()])
@@ -59,6 +59,9 @@ def test_out_of_scope_files_are_rejected():
     z = np.load(GOLDEN)
     with pytest.raises(hip.OfbError):
         hip.jpeg_parse(z['progressive.jpg'].tobytes())          # SOF2: OFB_ELIMIT
+    for k in ('oos_progressive.jpg', 'oos_cmyk.jpg', 'oos_adobe_rgb.jpg'):   # SOF2; four components; Adobe transform 0 = RGB planes
+        with pytest.raises(hip.OfbError):
+            hip.jpeg_parse(z[k].tobytes())
     with pytest.raises(hip.OfbError):
         hip.jpeg_parse(b'\x89PNG\r\n\x1a\n' + bytes(32))         # not a JPEG
     good = z['q75_420_53x37.jpg'].tobytes()
