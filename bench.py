@@ -163,6 +163,39 @@ def build_finetune_subnet(ofb_amd, dev, ncls):
     return model, macs, params
 
 
+def build_pruned_search(ofb_amd, dev, ncls):
+    """The SEARCH model as it looks for almost the whole search (reference engine.py:201-205 calls compress() three times per epoch
+    from epoch 0 on): the largest options of every module are dead and cut away, two cells per module are still competing.  The
+    alphas are forced (the shapes of the configs[4] subnet: embed 264, ragged heads / hidden widths), ONE compress() cuts weights,
+    gates and optimizer state; the step that is timed afterwards is the full search step (bi-mask gates, PMIM branch, arch loss)."""
+    import torch
+    search = ofb_amd.create_model('deit_small_patch16_224_mim', method='search', num_classes=ncls, drop_path_rate=0.1, attn_search=True,
+                                  mlp_search=True, embed_search=True, patch_search=False, mae=True, mask_ratio=1.0)
+    search.correct_require_grad(0.5, 0.5, 0, 0.5)
+    search.to(dev)
+
+    def force(mod, cells):
+        a = torch.full_like(mod.alpha.data, -12.0)
+        for (i, j) in cells:
+            a[i, j] = 0.0
+        mod.alpha.data.copy_(a)
+
+    pe = search.patch_embed
+    j = pe._chan_thr().index(FT_EMBED)
+    force(pe, [(0, j), (0, j - 1)])
+    for blk, (h, dh, hid) in zip(search.blocks, FT_BLOCKS):
+        i, jj = list(blk.attn.head_num_list).index(h), blk.attn._chan_thr().index(dh)
+        force(blk.attn, [(i, jj), (i, jj - 1)])
+        jm = blk.mlp._chan_thr().index(hid)
+        force(blk.mlp, [(0, jm), (0, jm - 1)])
+    finish, pruned, *_ = search.compress(0.2)
+    assert pruned and not finish, 'forced alphas must cut the weights and leave the search running'
+    shapes = dict(embed_dim=int(search.pos_embed.shape[-1]),
+                  blocks_heads_headdim_hidden=[(int(b.attn.num_heads), int(b.attn.qkv.weight.shape[0] // 3 // b.attn.num_heads), int(b.mlp.fc1.weight.shape[0]))
+                                               for b in search.blocks][:4], pattern_repeats=3)
+    return search, shapes
+
+
 def self_launch(n):
     """`python bench.py --gpus N` from a bare shell: start N ranks (one per GPU) under torch.distributed.run and hand their exit
     code back.  This parent never touches the GPU (no HIP call, not even torch.cuda.is_available()): a process that has
@@ -254,6 +287,8 @@ def main():
     ap.add_argument('--graph', action='store_true', help='search mode: capture the whole step (with N > 1: incl. the RCCL exchange) into a hipGraph and replay it '
                     '(engine.GraphedStep); for launch-bound sizes (small batches); the sampled profile steps stay eager')
     ap.add_argument('--force-dp', action='store_true', help='exercise the DP bucket path even with one rank (debug)')
+    ap.add_argument('--pruned', action='store_true', help='search mode: time the search step of a model that compress() has already cut '
+                    '(ragged shapes, what most of a real search runs on; reference engine.py:201-205) - NOT the BASELINE line')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:     # bare `python bench.py --gpus N`: become the launcher
@@ -303,10 +338,13 @@ def main():
     gflop_img = GFLOP_PER_IMG[args.model]
     ft_info = None
     if args.mode == 'search':
-        model = ofb_amd.create_model(f'{args.model}_patch16_224_mim', method='search', num_classes=ncls, drop_path_rate=0.1,
-                                     attn_search=True, mlp_search=True, embed_search=True, patch_search=False, mae=True,
-                                     mask_ratio=1.0)
-        model.correct_require_grad(0.5, 0.5, 0, 0.5)
+        if args.pruned:
+            model, ft_info = build_pruned_search(ofb_amd, dev, ncls)
+        else:
+            model = ofb_amd.create_model(f'{args.model}_patch16_224_mim', method='search', num_classes=ncls, drop_path_rate=0.1,
+                                         attn_search=True, mlp_search=True, embed_search=True, patch_search=False, mae=True,
+                                         mask_ratio=1.0)
+            model.correct_require_grad(0.5, 0.5, 0, 0.5)
         model.adjust_masking_ratio(0.0, 20, 100)             # epoch-0 state: keep ratio 0.95, w_p 0.99
         model.to(dev).train()
         lr = 2.5e-4 * eff_bs / 256
@@ -428,7 +466,7 @@ def main():
                         mfma_issued_tflops=round(ach * GEMM_MFMA_TERMS, 1),
                         launches_per_step=round(n / prof_steps, 1), avg_launch_us=round(ms / n * 1e3, 2),
                         share_of_step=round(ms / prof_steps / ms_step, 3), sampled_steps=prof_steps)
-            if args.mode == 'search' and (args.model, args.batch) == ('deit_small', 128):
+            if args.mode == 'search' and not args.pruned and (args.model, args.batch) == ('deit_small', 128):
                 tr, src = gemm_traffic_per_launch(n / prof_steps)
                 if tr:
                     roof['traffic'] = round(tr)
@@ -440,7 +478,12 @@ def main():
     log(f'loss_total {loss_val:.4f}; step {ms_step:.2f} ms; whole-step {step_tflops:.1f} TFLOP/s/GPU '
         f'({step_tflops / PEAK_F32_MFMA_TFLOPS:.1%} of the f32 MFMA peak)')
     cfg_tag = 'configs[1]' if (args.model, args.batch) == ('deit_small', 128) else ('configs[3]' if args.model == 'deit_base' else 'off-config size')
-    if args.mode == 'search':
+    if args.mode == 'search' and args.pruned:
+        metric = 'images/sec OFB-search step of a compress()-ed model (ragged shapes; NOT the BASELINE metric)'
+        workload = (f'deit_small OFB search step + PMIM branch AFTER one compress() (embed 264, ragged heads / hidden widths, two live cells per '
+                    f'module): bs {args.batch}/GPU, fwd + OFBSearchLOSS + bwd + 3x AdamW')
+        step_tflops = 0.0                                        # no FLOP model for the cut shapes: only the GEMM's own work counter is quoted
+    elif args.mode == 'search':
         metric = 'images/sec OFB-search step, DeiT-S bs=128/GPU @1/2/4/8 MI355X'
         workload = (f'{args.model} OFB search step + PMIM branch ({cfg_tag}): bs {args.batch}/GPU, 224x224 synthetic images, fwd + '
                     'OFBSearchLOSS + bwd + 3x AdamW, drop_path 0.1, w_p 0.99, keep ratio 0.95')
@@ -461,7 +504,7 @@ def main():
                roofline=roof)
     if ft_info:
         res['config']['subnet'] = ft_info
-    if world == 1 and not args.no_cpu_baseline and args.mode == 'search':
+    if world == 1 and not args.no_cpu_baseline and args.mode == 'search' and not args.pruned:
         res['cpu_baseline'] = cpu_baseline(log)
     sys.stdout.flush()
     os.write(real_stdout, (json.dumps(res) + '\n').encode())

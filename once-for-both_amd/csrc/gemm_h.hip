@@ -102,16 +102,17 @@ __global__ __launch_bounds__(256) void hstat_flat_kernel(const float* __restrict
   if (threadIdx.x == 0) ofb_atomic_max_pos(&hdr->amax, fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])));
 }
 
-__global__ void hhdr_from_bound_kernel(ofb_hhdr* __restrict__ hdr, const float* __restrict__ bound) {
-  hdr->e = 0; hdr->amax = bound[0]; hdr->rn2sq = 0.f; hdr->cn2sq = 0.f;
-}
-
 // Stage 2: X[R][C] row-major (ld) -> planes; e from hdr.amax (every thread reads the same word; block (0,0) records e)
+// (bound given: the caller's device scalar replaces the measured maximum; block (0,0) then writes the whole header)
 __global__ void to_hformat_kernel(const float* __restrict__ X, int R, int C, int ld, char* __restrict__ P, int ncb,
-                                  const float* __restrict__ rowscale, int rs_div) {
+                                  const float* __restrict__ rowscale, int rs_div, const float* __restrict__ bound) {
   ofb_hhdr* hdr = reinterpret_cast<ofb_hhdr*>(P);
-  const int e = ofb_h_exp(hdr->amax);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hdr->e = e;
+  const float amax = bound ? bound[0] : hdr->amax;
+  const int e = ofb_h_exp(amax);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    hdr->e = e;
+    if (bound) { hdr->amax = amax; hdr->rn2sq = 0.f; hdr->cn2sq = 0.f; }
+  }
   const float s = ofb_h_pow2(e);
   const int c = blockIdx.x * blockDim.x + threadIdx.x, rg = blockIdx.y;
   if (c >= ncb * 16) return;
@@ -207,11 +208,15 @@ __global__ void to_hformat_multi_kernel(const ofb_pformat_job* __restrict__ jobs
 // writes the planes AND partial[slab][c] = sum of the slab's (scaled, NOT 2^e-scaled) rows, added in row order.
 __global__ __launch_bounds__(256) void to_hformat_colsum_kernel(const float* __restrict__ X, int R, int C, int ld, char* __restrict__ P,
                                                                 int ncb, int rgs, const float* __restrict__ rowscale, int rs_div,
-                                                                float* __restrict__ partial) {
+                                                                float* __restrict__ partial, const float* __restrict__ bound) {
   __shared__ float red[4][64];
   ofb_hhdr* hdr = reinterpret_cast<ofb_hhdr*>(P);
-  const int e = ofb_h_exp(hdr->amax);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) hdr->e = e;
+  const float amax = bound ? bound[0] : hdr->amax;
+  const int e = ofb_h_exp(amax);
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    hdr->e = e;
+    if (bound) { hdr->amax = amax; hdr->rn2sq = 0.f; hdr->cn2sq = 0.f; }
+  }
   const float s = ofb_h_pow2(e);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, c = blockIdx.x * 64 + lane, slab = blockIdx.y;
   float sum = 0.f;
@@ -627,8 +632,9 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
       char* __restrict__ Cpl = g.Cp ? (char*)g.Cp + OFB_HHDR : nullptr;
       const float so = (!TAIL && has_p) ? ofb_h_pow2(reinterpret_cast<const ofb_hhdr*>(g.Cp)->e) : 1.f;   // written by the bound kernel
       const int rp_out = (g.M + 15) & ~15;
-      const bool interior = cur.m0 + BM <= g.M && cur.n0 + BN <= g.N;
-      const bool wide = TAIL || (interior && (p.stagger & 1) != 0);   // p.stagger bit 0: "wide epilogue allowed" (alignment checked on the host)
+      // WIDE also serves tiles that stick out of the matrix on the COLUMN side (N = 264, 480, ... on 192-wide tiles: half of all
+      // tiles of the pruned / finetune shapes): N is a multiple of 4 there, so a column quad lies wholly inside or wholly outside
+      const bool wide = TAIL || (cur.m0 + BM <= g.M && (p.stagger & 1) != 0);   // p.stagger bit 0: "wide epilogue allowed" (alignment checked on the host)
       constexpr int NQ = BN / 4, NITEM = (HR / 4) * NQ, NIT = (NITEM + CF::NT - 1) / CF::NT;     // column quads per row; items per pass; per thread
       __builtin_amdgcn_s_barrier();                                 // every wave has finished its fragment reads / its LDS-DMA
 #pragma unroll
@@ -650,9 +656,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
 #pragma unroll 1
           for (int k = 0; k < NIT; ++k) {
             const int id = t + CF::NT * k;
-            const bool live = (NITEM % CF::NT == 0) || id < NITEM;
-            const int rgl = live ? id / NQ : 0, cq = live ? id - (id / NQ) * NQ : 0;
-            const int row0 = cur.m0 + HR * half + 4 * rgl, lcol = 4 * cq, col = cur.n0 + lcol;
+            const bool initem = (NITEM % CF::NT == 0) || id < NITEM;
+            const int rgl = initem ? id / NQ : 0, cq = initem ? id - (id / NQ) * NQ : 0;
+            const int row0 = cur.m0 + HR * half + 4 * rgl, lcol = 4 * cq, col0 = cur.n0 + lcol;
+            const bool live = initem && (TAIL || col0 < g.N);                       // this quad's columns exist
+            const bool zpad = !TAIL && initem && !live && has_p && col0 < g.c_ncb * 16;      // padding columns of an H-format output: zeros
+            const int col = live ? col0 : 0;
             f32x4 v[4];
 #pragma unroll
             for (int tt = 0; tt < 4; ++tt) v[tt] = *reinterpret_cast<const f32x4*>(T + (4 * rgl + tt) * TLD + lcol);
@@ -701,6 +710,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
                 o[tt][e] = val;
               }
             }
+            if (zpad) {
+              char* slot = Cpl + ((size_t)(row0 >> 2) * g.c_ncb + (col0 >> 4)) * GRAN + (col0 & 15) * 8;
+              const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+              *reinterpret_cast<uint4*>(slot) = z; *reinterpret_cast<uint4*>(slot + 16) = z;
+              *reinterpret_cast<uint4*>(slot + 128) = z; *reinterpret_cast<uint4*>(slot + 144) = z;
+            }
             if (live) {
               if ((gelu && auxw) || gelug) {
 #pragma unroll
@@ -725,17 +740,17 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
                 *reinterpret_cast<uint4*>(slot + 144) = make_uint4(h2[2][0], h2[2][1], h2[3][0], h2[3][1]);
               }
             }
-            if (g.colpart && live) {
+            if (g.colpart && initem) {
               f32x4 cs4;
 #pragma unroll
-              for (int e = 0; e < 4; ++e) cs4[e] = (o[0][e] + o[1][e]) + (o[2][e] + o[3][e]);
+              for (int e = 0; e < 4; ++e) cs4[e] = live ? (o[0][e] + o[1][e]) + (o[2][e] + o[3][e]) : 0.f;
               *reinterpret_cast<f32x4*>(S + rgl * TLD + lcol) = cs4;
             }
           }
           if (!TAIL && g.colpart) {
             // column sums of this pass: one thread per column adds the row groups' sums in order; the passes of a tile in order too
             __syncthreads();
-            if (t < BN) {
+            if (t < BN && cur.n0 + t < g.N) {
               float sum = 0.f;
 #pragma unroll
               for (int rg = 0; rg < HR / 4; ++rg) sum += S[rg * TLD + t];
@@ -1004,10 +1019,7 @@ extern "C" int64_t ofb_hformat_bytes(int32_t R, int32_t C) {
 namespace {
 // header.amax for the conversion kernels: measured (memset + statistics pass) or the caller's bound
 int h_prepare_header(const float* X, int R, int C, int ld, void* P, const float* rowscale, int rs_div, const float* bound, hipStream_t s) {
-  if (bound) {
-    hipLaunchKernelGGL(hhdr_from_bound_kernel, dim3(1), dim3(1), 0, s, (ofb_hhdr*)P, bound);
-    return 0;
-  }
+  if (bound) return 0;                                 // the conversion kernel reads the caller's scalar itself
   if (hipMemsetAsync(P, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
   const int nb = ofb_cdiv(R, 4) < 512 ? ofb_cdiv(R, 4) : 512;
   hipLaunchKernelGGL(hstat_kernel, dim3(nb), dim3(256), 0, s, X, R, C, ld, (ofb_hhdr*)P, rowscale, rs_div);
@@ -1022,7 +1034,7 @@ extern "C" int ofb_to_hformat(const float* X, int32_t R, int32_t C, int32_t ld, 
   hipStream_t s = (hipStream_t)stream;
   const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4;
   if (int rc = h_prepare_header(X, R, C, ld, P, rowscale, rs_div, bound, s)) return rc;
-  hipLaunchKernelGGL(to_hformat_kernel, dim3((ncb * 16 + 255) / 256, rgs), dim3(256), 0, s, X, R, C, ld, (char*)P, ncb, rowscale, rs_div);
+  hipLaunchKernelGGL(to_hformat_kernel, dim3((ncb * 16 + 255) / 256, rgs), dim3(256), 0, s, X, R, C, ld, (char*)P, ncb, rowscale, rs_div, bound);
   return ofb_launch_status();
 }
 
@@ -1057,7 +1069,7 @@ extern "C" int ofb_to_hformat_colsum(const float* X, int32_t R, int32_t C, int32
   const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4, slabs = (rgs + CS_SLAB_RG - 1) / CS_SLAB_RG;
   if (int rc = h_prepare_header(X, R, C, ld, P, rowscale, rs_div, bound, s)) return rc;
   hipLaunchKernelGGL(to_hformat_colsum_kernel, dim3((ncb * 16 + 63) / 64, slabs), dim3(256), 0, s, X, R, C, ld, (char*)P, ncb, rgs, rowscale,
-                     rs_div, partial);
+                     rs_div, partial, bound);
   return ofb_launch_status();
 }
 
