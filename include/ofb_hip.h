@@ -72,7 +72,7 @@ extern "C" {
  * ------------------------------------------------------------------------------------------- */
 /* one conversion job of ofb_to_hformat_multi: X (f32 [R][C], row stride ld) -> P (ofb_hformat_bytes(R, C) bytes), row r
  * optionally multiplied by rowscale[r] */
-typedef struct ofb_pformat_job { const float* X; void* P; const float* rowscale; int32_t R, C, ld, pad_; } ofb_pformat_job;
+typedef struct ofb_hformat_job { const float* X; void* P; const float* rowscale; int32_t R, C, ld, pad_; } ofb_hformat_job;
 typedef struct ofb_gemm_h_args {
   const void* A; const void* B;
   int32_t a_kc, b_kc;
@@ -100,7 +100,7 @@ int ofb_to_hformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, co
                    void* stream);
 int ofb_patchify_hformat(const float* img, int32_t B, int32_t Cin, int32_t H, int32_t W, int32_t patch, void* P, void* stream);
 /* scratch: n_jobs * 64 floats (two-stage maxima of every job) */
-int ofb_to_hformat_multi(const ofb_pformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, float* scratch, void* stream);
+int ofb_to_hformat_multi(const ofb_hformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, float* scratch, void* stream);
 int ofb_to_hformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
                           float* partial, const float* bound, void* stream);
 int ofb_from_hformat(const void* P, int32_t R, int32_t C, float* X, int32_t ld, void* stream);   /* (h1 + h2) 2^-e */

@@ -154,9 +154,9 @@ __global__ void patchify_hformat_kernel(const float* __restrict__ img, int B, in
 // Many matrices in ONE launch pair (the weights of the model, once per optimizer step).  Stage 1: HM_NB blocks per job leave their
 // partial maxima in scratch[job][HM_NB][2] (no atomics, no memset); stage 2: every block of a job reduces those 2 x HM_NB words.
 constexpr int HM_NB = 32;
-__global__ __launch_bounds__(256) void hstat_multi_kernel(const ofb_pformat_job* __restrict__ jobs, float* __restrict__ scratch) {
+__global__ __launch_bounds__(256) void hstat_multi_kernel(const ofb_hformat_job* __restrict__ jobs, float* __restrict__ scratch) {
   __shared__ float red[2][4];
-  const ofb_pformat_job j = jobs[blockIdx.y];
+  const ofb_hformat_job j = jobs[blockIdx.y];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float am = 0.f, rn = 0.f;
   for (int r = blockIdx.x * 4 + w; r < j.R; r += HM_NB * 4) {
@@ -179,8 +179,8 @@ __global__ __launch_bounds__(256) void hstat_multi_kernel(const ofb_pformat_job*
     o[1] = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
   }
 }
-__global__ void to_hformat_multi_kernel(const ofb_pformat_job* __restrict__ jobs, const float* __restrict__ scratch) {
-  const ofb_pformat_job j = jobs[blockIdx.z];
+__global__ void to_hformat_multi_kernel(const ofb_hformat_job* __restrict__ jobs, const float* __restrict__ scratch) {
+  const ofb_hformat_job j = jobs[blockIdx.z];
   const int c = blockIdx.x * blockDim.x + threadIdx.x, rg = blockIdx.y, ncb = (j.C + 15) >> 4;
   if (blockIdx.x * blockDim.x >= ncb * 16 || rg >= ((j.R + 15) >> 4) * 4) return;
   float am = 0.f, rn = 0.f;
@@ -1052,7 +1052,7 @@ extern "C" int ofb_patchify_hformat(const float* img, int32_t B, int32_t Cin, in
 }
 
 // jobs_dev: n_jobs descriptors in device memory; max_R / max_C: the largest R and C among them (grid extent); scratch: n_jobs * 64 floats
-extern "C" int ofb_to_hformat_multi(const ofb_pformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, float* scratch,
+extern "C" int ofb_to_hformat_multi(const ofb_hformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, float* scratch,
                                     void* stream) {
   if (!jobs_dev || !scratch || n_jobs <= 0 || n_jobs > 65535 || max_R <= 0 || max_C <= 0) return OFB_EINVAL;
   const int ncb = (max_C + 15) / 16, rgs = ((max_R + 15) / 16) * 4;

@@ -305,7 +305,7 @@ def begin_forward():
         f()
 
 
-class PformatJob(C.Structure):
+class HformatJob(C.Structure):
     _fields_ = [('X', C.c_void_p), ('P', C.c_void_p), ('rowscale', C.c_void_p), ('R', C.c_int32), ('C', C.c_int32), ('ld', C.c_int32),
                 ('pad_', C.c_int32)]
 
@@ -381,7 +381,7 @@ def _wp_refresh_all(device):
         return
     key = tuple(jobs)
     if _wp_table[0] != key:
-        tab = (PformatJob * len(jobs))()
+        tab = (HformatJob * len(jobs))()
         for t, (x, pp, R, Cc) in zip(tab, jobs):
             t.X, t.P, t.rowscale, t.R, t.C, t.ld = x, pp, None, R, Cc, Cc
         dev_tab, host = upload_structs(tab, device)
@@ -472,7 +472,7 @@ def gated_weight_h(W, gvec, N, K):
         todo.append((W_, g_, N_, K_, pm, e_))
     key = tuple((w_.data_ptr(), g_.data_ptr(), pm.buf.data_ptr(), n_, k_) for (w_, g_, n_, k_, pm, _) in todo)
     if _gw_table[0] != key:
-        tab = (PformatJob * len(todo))()
+        tab = (HformatJob * len(todo))()
         for t, (w_, g_, n_, k_, pm, _) in zip(tab, todo):
             t.X, t.P, t.rowscale, t.R, t.C, t.ld = w_.data_ptr(), pm.buf.data_ptr(), g_.data_ptr(), n_, k_, k_
         dev_tab, host = upload_structs(tab, W.device)

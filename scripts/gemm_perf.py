@@ -1,4 +1,4 @@
-"""Micro-benchmark of the f32-MFMA GEMM on the DeiT-S bs=128 layer shapes (run on the GPU box)."""
+"""Micro-benchmark (conversion included) of hip.gemm and the attention kernels on the DeiT-S bs=128 layer shapes (run on the GPU box); scripts/gemm_step_shapes.py times the pre-split path the model uses."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
