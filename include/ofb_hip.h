@@ -175,7 +175,10 @@ int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const 
  * qkv: [B*N][3*H*dh] exactly as the qkv Linear writes it (q | k | v, head-major); out: [B*N][H*dh]
  * (the transpose(1,2).reshape of :514 is folded into the store); lse: [2][B*H][N]: row log-sum-exp fl(m + log l), then (B*H*N floats
  * further) its rounding residue (m - lse) + log l - the backward recomputes P = exp((S - lse) - residue) at fp32-softmax accuracy.
- * Limits: N <= 208 (13 tiles of 16 tokens), dh <= 64, dh % 4 == 0 (covers DeiT-T/S/B and every pruned d in {16,24,..,64}).
+ * Limits: dh <= 64, dh % 4 == 0 (covers DeiT-T/S/B and every pruned d in {16,24,..,64}); N <= 4096.  N <= 208 (13 tiles of 16 tokens;
+ * DeiT at 224 px) is the tuned case: one workgroup per (image, head).  Longer sequences (384 px: N = 577; patch 8: N = 785) run the same
+ * kernels chunked: the forward spreads the query tiles over ceil(N / 208) workgroups per (image, head), the backward is launched once
+ * per 224 keys and accumulates dq across the launches in stream order (deterministic).
  * bwd writes dqkv in the same packing (dq | dk | dv).
  * Both kernels split their operands into two f16 planes of a power-of-two scaled copy (csrc/hformat.h) and therefore need upper
  * bounds of |qkv| and |dout| as DEVICE scalars: the cbound_out of the GEMMs that produced them (ofb_gemm_h), or ofb_amax.
@@ -189,7 +192,7 @@ int ofb_attention_bwd(const float* qkv, const float* out, const float* lse, cons
                       float* dqkv_amax, void* stream);
 /* Forward that also writes the output rows as H-format planes out_h[B*N][H*dh] (the operand of the projection GEMM; the values
  * of `out`; |out| <= max |v|, so the planes take the qkv exponent).  The caller zeroes out_h beforehand when B*N or H*dh is not a
- * multiple of 16; needs N + (b*N mod 4) <= 208. */
+ * multiple of 16. */
 int ofb_attention_fwd_h(const float* qkv, float* out, void* out_h, float* lse, int32_t B, int32_t N, int32_t H, int32_t dh,
                         float scale, const float* qkv_bound, void* stream);
 

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   __shared__ __attribute__((aligned(16))) char smem[(2 * AF_STAGE > ATT_NT * 2560) ? 2 * AF_STAGE : ATT_NT * 2560];   // stages; later the PF patches
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, head = blockIdx.x % H;
+  const int wq = blockIdx.y * ATT_NT + w;                    // this wave's query tile (blockIdx.y > 0 only when N > 208)
   const int ldq = 3 * H * dh, ldo = H * dh;
   const float* qbase = qkv + (size_t)b * N * ldq + head * dh;
   const float* kbase = qbase + H * dh;
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   const float qb = qkv_bound[0];
   const int he = ofb_h_exp(qb);                              // q, k, v are split as x 2^he
   const float hs = ofb_h_pow2(he), s_inv = ofb_h_pow2(-2 * he);
-  if (PF && blockIdx.x == 0 && t == 0) { ofb_hhdr* h = reinterpret_cast<ofb_hhdr*>(oP); h->e = he; h->amax = qb; h->rn2sq = 0.f; h->cn2sq = 0.f; }
+  if (PF && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) { ofb_hhdr* h = reinterpret_cast<ofb_hhdr*>(oP); h->e = he; h->amax = qb; h->rn2sq = 0.f; h->cn2sq = 0.f; }
 
   // staging items: idx < 512 -> K float4 (key = idx/16, d = 4*(idx%16)); 512 <= idx < 1024 -> V float4, same coordinates
   f32x4 sreg[3];
@@ -164,7 +165,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   stage_store(0);
 
   // this lane's query row (pre-scaled), d-slices [8g, 8g+8) and [32 + 8g, 32 + 8g + 8), as B-operand planes
-  const int q = w * ATT_T + c - sft;
+  const int q = wq * ATT_T + c - sft;
   const bool qvalid = q >= 0 && q < N;
   att_hx8 qf[2][2];
 #pragma unroll
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   }
   __syncthreads();
 
-  const bool active = w * ATT_T < N + sft;
+  const bool active = wq * ATT_T < N + sft;
   const float p_sc = ofb_h_pow2(ATT_PE);
   for (int kb = 0; kb < nb; ++kb) {
     const char* st = smem + (kb & 1) * AF_STAGE;
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   if (PF) {
     // wave-private patch [32 ch][16 q + 4] f32 in the (now free) stage buffers: 2.5 KB per wave
     float* T = reinterpret_cast<float*>(smem) + w * (32 * 20);
-    const int row0 = (int)((size_t)b * N) - sft + w * ATT_T;                            // global row of tile position 0: row0 % 4 == 0
+    const int row0 = (int)((size_t)b * N) - sft + wq * ATT_T;                            // global row of tile position 0: row0 % 4 == 0
     char* oPl = oP + OFB_HHDR;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int pass = 0; pass < 2; ++pass) {
-        const int chl = lane & 31, qg = 2 * pass + (lane >> 5), ch = 32 * half + chl, p0 = w * ATT_T + 4 * qg;
+        const int chl = lane & 31, qg = 2 * pass + (lane >> 5), ch = 32 * half + chl, p0 = wq * ATT_T + 4 * qg;
         const f32x4 v = *reinterpret_cast<const f32x4*>(&T[chl * 20 + 4 * qg]);
         const int rlo = max(0, sft - p0), rhi = min(4, N + sft - p0);
         if (ch < dh && rlo < rhi) att_store_h_col4(oPl, p_ncb, row0 + 4 * qg, head * dh + ch, v, rlo, rhi);
@@ -373,11 +374,15 @@ __device__ unsigned long long ofb_att_stamps[8 * 64];
 #define AB_STAMP(slot) do { } while (0)
 #endif
 
+// LONG (N > 208): one launch per chunk of 224 keys (kc = chunk index, stream-ordered): the launch owns dK / dV of its keys, sweeps
+// ALL queries and adds its share of dQ to what the earlier launches left (plain read-modify-write: a fixed summation order, no
+// atomics); the per-position LDS arrays become a ring of seven query blocks that is filled block by block.
+template <bool LONG>
 __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ out,
                                                                  const float* __restrict__ lse, const float* __restrict__ dout,
                                                                  float* __restrict__ dqkv, int B, int N, int H, int dh, float scale,
                                                                  const float* __restrict__ qkv_bound, const float* __restrict__ dout_bound,
-                                                                 float* __restrict__ dqkv_amax) {
+                                                                 float* __restrict__ dqkv_amax, int kc) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kpl = smem;
   char* dSpl = smem + AB_OFF_DS;
@@ -401,13 +406,26 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
   const float* vbase = qbase + 2 * H * dh;
   const float* obase = out + tok0 * ldo + head * dh;
   const float* dobase = dout + tok0 * ldo + head * dh;
+  const int key0 = LONG ? kc * AB_NPOS : 0;                 // first key position of this launch
+  const int nkb = LONG ? min(AB_NKW, (npos - key0 + 31) >> 5) : nqb;      // 32-key blocks that hold keys
   auto valid = [&](int pos) { return pos < npos; };
+  auto ring = [&](int qb) { return LONG ? (qb % AB_NKW) * AB_QB : qb * AB_QB; };   // a query block's slot in the per-position arrays
   const int he = ofb_h_exp(qkv_bound[0]), hdo = ofb_h_exp(dout_bound[0]);      // q k v split as x 2^he, dO as x 2^hdo
   const float hs = ofb_h_pow2(he), hos = ofb_h_pow2(hdo), s_inv = ofb_h_pow2(-2 * he), dp_sc = ofb_h_pow2(hdo + he);
 
   // staging of a 32-position query block: thread t carries the Q, dO and O float4 of (row t / 16, d = 4 (t % 16))
   f32x4 sreg[3];
+  float lq_a = 0.f, lq_b = 0.f;                             // LONG: lse and its residue of the row this thread's 16-lane group stages
   auto stage_load = [&](int qb) {
+    if (LONG) {
+      const int pos = qb * AB_QB + (t >> 4);
+      lq_a = lq_b = 0.f;
+      if ((t & 15) == 0 && valid(pos)) {
+        const size_t li = ((size_t)b * H + head) * N + pos;
+        lq_a = lse[li];
+        lq_b = lse[(size_t)B * H * N + li];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 3; ++i) {                           // i = 0: Q, 1: dO, 2: O (512 threads = 512 items each)
       const float* base = i == 0 ? qbase : (i == 1 ? dobase : obase);
@@ -423,7 +441,11 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
       float n2 = sreg[1][0] * sreg[1][0] + sreg[1][1] * sreg[1][1] + sreg[1][2] * sreg[1][2] + sreg[1][3] * sreg[1][3];
       d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
       n2 += __shfl_xor(n2, 8, 64); n2 += __shfl_xor(n2, 4, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 1, 64);
-      if ((t & 15) == 0) { ndel[qb * AB_QB + (t >> 4)] = -d; ndo[qb * AB_QB + (t >> 4)] = sqrtf(n2); }
+      if ((t & 15) == 0) {
+        const int ri = ring(qb) + (t >> 4);
+        ndel[ri] = -d; ndo[ri] = sqrtf(n2);
+        if (LONG) { nlse[ri] = -lq_a; nres[ri] = -lq_b; }
+      }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -447,16 +469,16 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
   // workgroup is alone on its CU, nothing else hides them): K rows, lse, query block 0, this wave's V rows
   constexpr int NIT = AB_NPOS * 16 / AB_THREADS;
   static_assert(NIT * AB_THREADS == AB_NPOS * 16 && AB_NPOS <= AB_THREADS, "prologue items");
-  const bool has_keys = w < AB_NKW && 32 * w < npos;
+  const bool has_keys = w < AB_NKW && key0 + 32 * w < npos;
   f32x4 kv[NIT], vraw[2][2][2];
   float lse_a = 0.f, lse_b = 0.f;
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int idx = t + AB_THREADS * i, pos = idx >> 4, c4 = idx & 15;
     kv[i] = zero4();
-    if (valid(pos) && 4 * c4 < dh) kv[i] = *reinterpret_cast<const f32x4*>(kbase + (unsigned)(pos * ldq + 4 * c4));
+    if (valid(key0 + pos) && 4 * c4 < dh) kv[i] = *reinterpret_cast<const f32x4*>(kbase + (unsigned)((key0 + pos) * ldq + 4 * c4));
   }
-  if (t < AB_NPOS && valid(t)) {
+  if (!LONG && t < AB_NPOS && valid(t)) {
     const size_t li = ((size_t)b * H + head) * N + t;
     lse_a = lse[li];
     lse_b = lse[(size_t)B * H * N + li];                    // the forward's second float of lse (rounding residue)
@@ -464,7 +486,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
   stage_load(0);
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt) {
-    const int pos = 32 * w + 16 * kt + c;
+    const int pos = key0 + 32 * w + 16 * kt + c;
     const bool kv_ok = valid(pos);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
@@ -488,7 +510,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
     *reinterpret_cast<uint2*>(p + AB_KPL) = make_uint2(l0, l1);
   }
   AB_STAMP(59);
-  if (t < AB_NPOS) { nlse[t] = -lse_a; nres[t] = -lse_b; }
+  if (!LONG && t < AB_NPOS) { nlse[t] = -lse_a; nres[t] = -lse_b; }
   stage_store(0);
   AB_STAMP(61);
   // this wave's V rows as B operand of dP = dO V^T (lane: key 32 w + 16 kt + c, d = 32 ks + 8 g ..); the B operand of S' = (scale Q) K^T
@@ -519,7 +541,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
   AB_STAMP(62);
   bool kval[2];
 #pragma unroll
-  for (int kt = 0; kt < 2; ++kt) kval[kt] = valid(32 * w + 16 * kt + c);
+  for (int kt = 0; kt < 2; ++kt) kval[kt] = valid(key0 + 32 * w + 16 * kt + c);
 
   f32x4 dKa[2][4], dVa[2][4];
 #pragma unroll
@@ -538,7 +560,9 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
     float m = 0.f;
 #pragma unroll
     for (int i = 0; i < AB_NW; ++i) m = fmaxf(m, vmax[i]);
-    vnorm = sqrtf(m);
+    // the dS bound needs max |V_key|_2 over ALL keys of the head (|delta| = |dO . O|, and O mixes every key): a chunk sees 224 of
+    // them, so LONG takes the bound sqrt(dh) max|qkv| instead
+    vnorm = LONG ? sqrtf((float)dh) * qkv_bound[0] : sqrtf(m);
   }
 
   const bool has_tile = w < ntile;                        // this wave's dQ tile: (qt, ct) = (w / nct, w % nct)
@@ -555,7 +579,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
     // exponent of this block's dS: |P (dP - delta)| <= 2 max_q |dO_q|_2 max_key |V_key|_2 (every wave reads the same LDS words)
     int eds;
     {
-      float dm = ndo[qb * AB_QB + (lane & 31)];
+      float dm = ndo[ring(qb) + (lane & 31)];
       dm = fmaxf(dm, __shfl_xor(dm, 1, 64)); dm = fmaxf(dm, __shfl_xor(dm, 2, 64)); dm = fmaxf(dm, __shfl_xor(dm, 4, 64));
       dm = fmaxf(dm, __shfl_xor(dm, 8, 64)); dm = fmaxf(dm, __shfl_xor(dm, 16, 64));
       eds = __builtin_amdgcn_readfirstlane(ofb_h_exp(2.002f * dm * vnorm));
@@ -565,7 +589,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
       f32x4 S[2][2], dPa[2][2];
 #pragma unroll
       for (int qt = 0; qt < 2; ++qt) {
-        const f32x4 nd = *reinterpret_cast<const f32x4*>(&ndel[qb * AB_QB + 16 * qt + 4 * gl]) * dp_sc;   // dP accumulates in units 2^(hdo + he)
+        const f32x4 nd = *reinterpret_cast<const f32x4*>(&ndel[ring(qb) + 16 * qt + 4 * gl]) * dp_sc;   // dP accumulates in units 2^(hdo + he)
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) { S[qt][kt] = zero4(); dPa[qt][kt] = nd; }
       }
@@ -604,8 +628,8 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
         float p8[8], d8[8];
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt) {
-          const f32x4 nl = *reinterpret_cast<const f32x4*>(&nlse[qb * AB_QB + 16 * qt + 4 * gl]);
-          const f32x4 nr = *reinterpret_cast<const f32x4*>(&nres[qb * AB_QB + 16 * qt + 4 * gl]);
+          const f32x4 nl = *reinterpret_cast<const f32x4*>(&nlse[ring(qb) + 16 * qt + 4 * gl]);
+          const f32x4 nr = *reinterpret_cast<const f32x4*>(&nres[ring(qb) + 16 * qt + 4 * gl]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const float pv = kval[kt] ? __expf((S[qt][kt][r] * s_inv + nl[r]) + nr[r]) : 0.f;
@@ -678,9 +702,9 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
       rd(0, 0);
 #pragma unroll
       for (int kb = 0; kb < AB_NKW; ++kb) {
-        if (kb < nqb) {
+        if (kb < nkb) {
           __builtin_amdgcn_sched_barrier(0);
-          if (kb + 1 < nqb) rd(kb + 1, (kb + 1) & 1);
+          if (kb + 1 < nkb) rd(kb + 1, (kb + 1) & 1);
           if (kb & 1) acc1 = att_mfma3(af[kb & 1], bk[kb & 1], acc1);
           else acc = att_mfma3(af[kb & 1], bk[kb & 1], acc);
         }
@@ -694,7 +718,10 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
         float* dqp = dqkv + (tok0 + p0) * ldq + head * dh + ch;
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-          if (r < rhi) { dqp[(size_t)r * ldq] = acc[r]; omax = fmaxf(omax, fabsf(acc[r])); }
+          if (r < rhi) {
+            if (LONG && kc > 0) acc[r] += dqp[(size_t)r * ldq];          // the earlier key chunks' share (stream-ordered launches)
+            dqp[(size_t)r * ldq] = acc[r]; omax = fmaxf(omax, fabsf(acc[r]));
+          }
       }
     }
     AB_STAMP(7 + 8 * qb);
@@ -712,7 +739,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
     const int ch = 16 * ct + c;
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      const int p0 = 32 * w + 16 * kt + 4 * g;
+      const int p0 = key0 + 32 * w + 16 * kt + 4 * g;
       const int rhi = min(4, npos - p0);
       const f32x4 kq = dKa[kt][ct] * k_inv, vq = dVa[kt][ct] * v_inv;           // dK accumulated against the pre-scaled Q
       if (ch < dh && rhi > 0 && w < AB_NKW) {
@@ -742,9 +769,10 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
 
 constexpr size_t BWD_LDS = AB_LDS_BYTES;
 
+#define ATT_NLIMIT 4096     /* sequence lengths above one workgroup's 208 run chunked (forward: query chunks on blockIdx.y, backward: one launch per 224 keys) */
 int check_shape(int B, int N, int H, int dh) {
   if (B <= 0 || N <= 0 || H <= 0 || dh <= 0) return OFB_EINVAL;
-  if (N > ATT_NMAX || dh > ATT_DMAX || (dh & 3)) return OFB_ELIMIT;
+  if (N > ATT_NLIMIT || dh > ATT_DMAX || (dh & 3)) return OFB_ELIMIT;
   return OFB_OK;
 }
 
@@ -782,7 +810,8 @@ extern "C" int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32
   if (!ofb_aligned16(out) || ((H * dh) & 3)) return OFB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   ofb_prof_pre(1, s, 4.0 * B * H * (double)N * N * dh);
-  hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H), dim3(ATT_THREADS), 0, s, qkv, out, lse, (char*)nullptr, 0, B, N, H, dh, scale, qkv_bound);
+  hipLaunchKernelGGL(attn_fwd_kernel<false>, dim3(B * H, (N + ATT_NMAX - 1) / ATT_NMAX), dim3(ATT_THREADS), 0, s, qkv, out, lse, (char*)nullptr, 0,
+                     B, N, H, dh, scale, qkv_bound);
   ofb_prof_post(1, s);
   return ofb_launch_status();
 }
@@ -796,10 +825,9 @@ extern "C" int ofb_attention_fwd_h(const float* qkv, float* out, void* out_h, fl
   if (!ofb_aligned16(qkv) || !ofb_aligned16(out) || !ofb_aligned16(out_h) || ((H * dh) & 3)) return OFB_EINVAL;
   int smax = 0;
   for (int bb = 0; bb < B && bb < 4; ++bb) smax = ((bb * N) & 3) > smax ? ((bb * N) & 3) : smax;
-  if (N + smax > ATT_NMAX) return OFB_ELIMIT;
   hipStream_t s = (hipStream_t)stream;
   ofb_prof_pre(1, s, 4.0 * B * H * (double)N * N * dh);
-  hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H), dim3(ATT_THREADS), 0, s, qkv, out, lse, (char*)out_h, (H * dh + 15) / 16, B, N, H, dh,
+  hipLaunchKernelGGL(attn_fwd_kernel<true>, dim3(B * H, (N + smax + ATT_NMAX - 1) / ATT_NMAX), dim3(ATT_THREADS), 0, s, qkv, out, lse, (char*)out_h, (H * dh + 15) / 16, B, N, H, dh,
                      scale, qkv_bound);
   ofb_prof_post(1, s);
   return ofb_launch_status();
@@ -816,12 +844,19 @@ extern "C" int ofb_attention_bwd(const float* qkv, const float* out, const float
   hipStream_t s = (hipStream_t)stream;
   // the attribute is per device and the call is cheap: set it on every launch (a per-process flag would leave a second GPU
   // of the same process without it, and is not thread-safe)
-  if (hipFuncSetAttribute((const void*)attn_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS) != hipSuccess)
+  const bool lng = N > ATT_NMAX;
+  if (hipFuncSetAttribute(lng ? (const void*)attn_bwd_kernel<true> : (const void*)attn_bwd_kernel<false>,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS) != hipSuccess)
     return (int)hipGetLastError();
   if (dqkv_amax && hipMemsetAsync(dqkv_amax, 0, 4, s) != hipSuccess) return (int)hipGetLastError();
   ofb_prof_pre(4, s, 10.0 * B * H * (double)N * N * dh);
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3(B * H), dim3(AB_THREADS), BWD_LDS, s, qkv, out, lse, dout, dqkv, B, N, H, dh, scale, qkv_bound,
-                     dout_bound, dqkv_amax);
+  if (!lng)
+    hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * H), dim3(AB_THREADS), BWD_LDS, s, qkv, out, lse, dout, dqkv, B, N, H, dh, scale,
+                       qkv_bound, dout_bound, dqkv_amax, 0);
+  else
+    for (int kc = 0; kc * AB_NPOS < N; ++kc)               // dqkv_amax: the running dq sums are included, an upper bound of the final values
+      hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B * H), dim3(AB_THREADS), BWD_LDS, s, qkv, out, lse, dout, dqkv, B, N, H, dh, scale,
+                         qkv_bound, dout_bound, dqkv_amax, kc);
   ofb_prof_post(4, s);
   return ofb_launch_status();
 }

@@ -40,7 +40,7 @@ struct Cfg {
   static constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;          // 1-KB LDS-DMA pieces per stage
   static constexpr int QA = A_PIECES / NW, QB = (B_PIECES + NW - 1) / NW;             // pieces per wave (the last B piece only for some waves)
   static constexpr int HA = MI / 2;                                                   // row blocks per half step
-  static constexpr int HR = (NST * STAGE >= BN * 132 * 4) ? 128 : 64;                 // rows of the tile parked in LDS per epilogue pass
+  static constexpr int HR = (NST * STAGE >= (128 + 32) * (BN + 4) * 4) ? 128 : 64;    // rows of the tile parked in LDS per epilogue pass (+ a column-sum row per 4)
   static constexpr int TROW = HR + 4;
   static_assert(A_PIECES % NW == 0 && MI % 2 == 0 && BM % HR == 0 && (32 * MI) <= HR && HR % (32 * MI) == 0, "piece / epilogue schedule");
   static_assert(BN * TROW * 4 <= NST * STAGE && QA >= 1 && QA <= 8 && QB <= 8 && NST >= 2 && NST <= 3 && KH >= 1 && KH <= 2, "LDS budget / schedule");
@@ -50,6 +50,8 @@ using C128 = Cfg<2, 2, 2, 3, 2, 2, 2>;
 //   C96: 256 x 96, 4 waves stacked along M (the same 64 x 96 wave tile): output widths that pad badly on 192 columns (N mod 192 in
 //        (0, 96]: the pruned / finetune widths 264, 480, 672, ...)
 using C96 = Cfg<4, 1, 2, 3, 3, 1, 2>;     // K16 stages: two K32 stages of a 256 x 96 tile x two workgroups do not fit the LDS
+// (lab, round 4: Cfg<4, 2, 2, 3, 2, 2, 1> = 256 x 192 with EIGHT waves, one workgroup per CU, runs correctly and is 0-12 % slower than two
+//  independent 4-wave workgroups on every step shape: profiles/r04_gemm_8wave_tile_and_turnstiles.txt)
 #ifdef OFB_GEMM_H_LAB
 using C128K1 = Cfg<2, 2, 2, 3, 3, 1, 2>;          // lab: K16 stages, three of them
 #endif
@@ -488,7 +490,9 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
     unsigned hw;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
     ofb_h_stamps[(blockIdx.x * 8 + 7) * 4 + 0] = __builtin_amdgcn_s_memrealtime();
-    ofb_h_stamps[(blockIdx.x * 8 + 7) * 4 + 2] = hw;
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    ofb_h_stamps[(blockIdx.x * 8 + 7) * 4 + 2] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
     ofb_h_stamps[(blockIdx.x * 8 + 7) * 4 + 3] = __builtin_amdgcn_s_memtime();
   }
 #endif
@@ -960,8 +964,9 @@ Plan plan_h(const ofb_gemm_h_args& g) {
   auto al = [](const void* q, int ld) { return q == nullptr || (ofb_aligned16(q) && (ld & 3) == 0); };
   static int narrow = -1;
   if (narrow < 0) { const char* e = getenv("OFB_GEMM_H_NARROW"); narrow = e ? atoi(e) : 0; }
-  p.stagger = (!narrow && (g.N & 3) == 0 && al(g.C, g.ldc) && al(g.aux, g.ldaux) && al(g.resid, g.ldr) && al(g.bias, 0) && al(g.colscale, 0) &&
-               (g.Cp == nullptr || (g.c_ncb * 16 >= g.N))) ? 1 : 0;
+  const bool wide_ok = !narrow && (g.N & 3) == 0 && al(g.C, g.ldc) && al(g.aux, g.ldaux) && al(g.resid, g.ldr) && al(g.bias, 0) && al(g.colscale, 0) &&
+                       (g.Cp == nullptr || (g.c_ncb * 16 >= g.N));
+  p.stagger = wide_ok ? 1 : 0;
   return p;
 }
 

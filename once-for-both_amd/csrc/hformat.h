@@ -67,7 +67,12 @@ __device__ __forceinline__ const ofb_hhdr* ofb_h_hdr(const void* P) { return (co
 
 // max of non-negative floats through their bit patterns (ordered like unsigned integers).  (fmaxf drops NaN operands, so a NaN never
 // reaches a bound; the NaN element itself converts to a NaN f16 and stays loud in the planes.)
-__device__ __forceinline__ void ofb_atomic_max_pos(float* addr, float v) { atomicMax(reinterpret_cast<unsigned*>(addr), __float_as_uint(v)); }
+// The current value is read first: thousands of blocks fold their maxima into ONE word, the atomics on it serialise in its L2 channel
+// (1576 blocks x 2 words cost the LayerNorm-backward bound pass 30 of its 43 us), and after the first few arrivals almost nobody raises it.
+__device__ __forceinline__ void ofb_atomic_max_pos(float* addr, float v) {
+  unsigned* a = reinterpret_cast<unsigned*>(addr);
+  if (__float_as_uint(v) > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, __float_as_uint(v));
+}
 __device__ __forceinline__ float ofb_wave_max_pos(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

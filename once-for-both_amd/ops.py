@@ -318,9 +318,9 @@ def layer_norm_fork(x, gamma, beta, eps):
 
 
 def _att_planes_ok(B, N):
-    """the plane-writing attention kernels lay their 16-token tiles from position -(b N mod 4): N plus the largest shift must fit
-    the 208 tile positions"""
-    return N + max((b * N) & 3 for b in range(min(B, 4))) <= 208
+    """the plane-writing attention forward lays its 16-token tiles from position -(b N mod 4) and spreads them over as many workgroups
+    as they need: every sequence length the kernels take (csrc/attention.hip: ATT_NLIMIT) qualifies"""
+    return N <= 4096
 
 
 class AttnBranch(torch.autograd.Function):

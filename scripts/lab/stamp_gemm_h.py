@@ -54,3 +54,22 @@ for u, n, pro, kl, ep in units:
 last = np.max(st[:, :7, 3], axis=1)
 clk = (last - mt0) / np.maximum(rt1 - rt0, 1) * 100e6 / 1e9
 print(f'  in-kernel clock: median {np.median(clk):.2f} GHz (min {clk.min():.2f}, max {clk.max():.2f})')
+
+# co-residency: workgroups per CU key (XCC | SE, SH, CU of HW_ID) and how much of a pair's epilogues overlap in time
+key = ((hw >> 32) & 15) * 256 + ((hw >> 8) & 255)
+uniq, cnt = np.unique(key, return_counts=True)
+print(f'  CU keys: {len(uniq)} distinct; workgroups per key: ' + ', '.join(f'{c}: {int((cnt == c).sum())}' for c in sorted(set(cnt))))
+for u in range(min(len(units), 3)):
+    ov, tot = 0, 0
+    for k in uniq[cnt == 2]:
+        i, j = np.nonzero(key == k)[0]
+        a0, a1, b0, b1 = st[i, u, 2], st[i, u, 3], st[j, u, 2], st[j, u, 3]
+        if min(a0, b0) <= 0: continue
+        ov += max(0, min(a1, b1) - max(a0, b0)); tot += min(a1 - a0, b1 - b0)
+    if tot: print(f'  unit {u}: epilogue overlap inside a CU pair: {ov / tot:.2f} of the shorter epilogue')
+if os.environ.get('OFB_STAMP_DUMP'):
+    base = st[:, 0, 0].min()
+    for k in uniq[cnt == 2][:6]:
+        i, j = np.nonzero(key == k)[0]
+        for n in (i, j):
+            print(f'   key {k:4d} wg {n:3d}: ' + ' | '.join(' '.join(f'{int(st[n, u, s] - base):7d}' for s in range(4)) for u in range(3)))

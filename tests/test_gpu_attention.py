@@ -18,8 +18,9 @@ def _ref(qkv, B, N, H, dh, scale, dout):
 
 
 # (B, N, H, dh): DeiT-S/T/B head shapes, pruned head dims, short and maximal sequences
+# N > 208 runs chunked (forward: query chunks per workgroup, backward: one launch per 224 keys): 384 px (577), patch 8 (785), chunk edges
 CASES = [(2, 197, 6, 64), (3, 197, 3, 64), (2, 197, 4, 40), (1, 197, 2, 16), (2, 50, 2, 32), (1, 208, 2, 64), (2, 33, 1, 24),
-         (1, 1, 1, 8)]
+         (1, 1, 1, 8), (2, 577, 3, 64), (3, 785, 2, 40), (2, 209, 1, 64), (1, 224, 2, 32), (3, 225, 1, 16), (2, 448, 1, 64), (1, 1025, 1, 64)]
 
 
 @pytest.mark.parametrize('B,N,H,dh', CASES)
@@ -58,7 +59,11 @@ def test_attention_fwd_bwd(B, N, H, dh):
     # deterministic, and the reported maximum is the maximum of what was stored
     again, amax = torch.empty_like(dqkv), torch.zeros(1, device='cuda')
     hip.attention_bwd(qd, o, lse, dout.cuda(), again, B, N, H, dh, scale, dqkv_amax=amax)
-    assert torch.equal(again, dqkv) and float(amax) == dqkv.abs().max().item()
+    assert torch.equal(again, dqkv)
+    if N <= 208:
+        assert float(amax) == dqkv.abs().max().item()
+    else:                                                   # chunked: the running dq sums of the earlier launches are included (an upper bound)
+        assert dqkv.abs().max().item() <= float(amax) <= 4.0 * dqkv.abs().max().item()
     # a LOOSE bound (what the model hands over: Cauchy-Schwarz bounds, 4-30x the maximum) costs no accuracy
     loose_q, loose_d = hip.amax(qd) * 16.0, hip.amax(dout.cuda()) * 16.0
     o3, lse3, dq3 = torch.empty_like(o), torch.empty_like(lse), torch.empty_like(dqkv)
@@ -90,15 +95,18 @@ def test_attention_rejects_unsupported():
     from ofb_amd import hip
     t = torch.zeros(300 * 192, device='cuda')
     with pytest.raises(hip.OfbError):
-        hip.attention_fwd(t, t, t, 1, 300, 1, 64, 0.125)     # N > 208
+        hip.attention_fwd(t, t, t, 1, 5000, 1, 64, 0.125)    # N > 4096
+    with pytest.raises(hip.OfbError):
+        hip.attention_fwd(t, t, t, 1, 100, 1, 68, 0.125)     # dh > 64
     with pytest.raises(hip.OfbError):
         hip.attention_fwd(t, t, t, 1, 100, 1, 30, 0.125)     # dh % 4 != 0
 
 
-@pytest.mark.parametrize('B,N', [(3, 197), (2, 207), (2, 50)])
-def test_attention_branch_planes_and_fallback(B, N):
-    """ops.attn_branch end to end (qkv GEMM, attention, projection, residual) against fp64 autograd: N = 197 takes the kernels that
-    write P-format planes (shifted tile origin), N = 207 with two images does not fit the shift and takes the f32 + conversion path"""
+@pytest.mark.parametrize('B,N', [(3, 197), (2, 207), (2, 50), (2, 577)])
+def test_attention_branch_planes(B, N):
+    """ops.attn_branch end to end (qkv GEMM, attention, projection, residual) against fp64 autograd: the attention forward writes the
+    projection's operand planes (shifted tile origin; N = 207 with two images spills into a second query chunk, N = 577 is the
+    384-px sequence)"""
     from ofb_amd import ops
     H, dh, D = 2, 32, 64
     g = torch.Generator().manual_seed(N)
@@ -106,7 +114,7 @@ def test_attention_branch_planes_and_fallback(B, N):
     wq, bq = torch.randn(3 * H * dh, D, generator=g) * 0.1, torch.randn(3 * H * dh, generator=g) * 0.1
     wp, bp = torch.randn(D, H * dh, generator=g) * 0.1, torch.randn(D, generator=g) * 0.1
     dout = torch.randn(B, N, D, generator=g)
-    assert ops._att_planes_ok(B, N) == (N != 207)
+    assert ops._att_planes_ok(B, N)
     tens = [t.cuda().requires_grad_(True) for t in (x, wq, bq, wp, bp)]
     out = ops.attn_branch(tens[0], None, tens[1], tens[2], tens[3], tens[4], None, None, H, dh ** -0.5)
     out.backward(dout.cuda())
