@@ -97,7 +97,17 @@ __global__ __launch_bounds__(256) void hstat_kernel(const float* __restrict__ X,
 __global__ __launch_bounds__(256) void hstat_flat_kernel(const float* __restrict__ X, size_t n, ofb_hhdr* __restrict__ hdr) {
   __shared__ float red[4];
   float am = 0.f;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) am = fmaxf(am, fabsf(X[i]));
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, gsz = (size_t)gridDim.x * 256;
+  if ((reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+    const size_t n4 = n >> 2;
+    for (size_t i = gid; i < n4; i += gsz) {
+      const f32x4 v = reinterpret_cast<const f32x4*>(X)[i];
+      am = fmaxf(fmaxf(am, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    for (size_t i = 4 * n4 + gid; i < n; i += gsz) am = fmaxf(am, fabsf(X[i]));
+  } else {
+    for (size_t i = gid; i < n; i += gsz) am = fmaxf(am, fabsf(X[i]));
+  }
   am = ofb_wave_max_pos(am);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
   __syncthreads();
@@ -307,38 +317,41 @@ __device__ __forceinline__ float epi_value(const ofb_gemm_h_args& g, float alpha
 // the reduction: |sum_k a_k b_k| <= |a|_2 |b|_2, the operand norms from their headers (exact where the producer measured them,
 // else K amax^2); then the epilogue: + max|bias|, x max|colscale|, x aux_bound for the multiplying activations (|gelu(v)| <= |v|),
 // x max|rowscale|.  One block.  out_bound (device scalar) given: it IS the bound.
-__global__ __launch_bounds__(256) void gemm_h_bound_kernel(const ofb_gemm_h_args g) {
-  __shared__ float red[3][4];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+// (every thread of the block returns the same value: fixed reduction order, so every workgroup of a GEMM that folds this into its own
+// start - below - derives the same bits as the one-block kernel)
+template <int NWV>
+__device__ __forceinline__ float gemm_h_bound_block(const ofb_gemm_h_args& g, float* red /* [3][NWV] */) {
+  const int nthr = 64 * NWV, lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (g.out_bound) return g.out_bound[0];
   float mb = 0.f, mc = g.colscale ? 0.f : 1.f, mr = g.rowscale ? 0.f : 1.f;
-  if (!g.out_bound) {
-    if (g.bias) for (int i = threadIdx.x; i < g.N; i += 256) mb = fmaxf(mb, fabsf(g.bias[i]));
-    if (g.colscale) for (int i = threadIdx.x; i < g.N; i += 256) mc = fmaxf(mc, fabsf(g.colscale[i]));
-    if (g.rowscale) for (int i = threadIdx.x; i < (g.M + g.rs_div - 1) / g.rs_div; i += 256) mr = fmaxf(mr, fabsf(g.rowscale[i]));
-  }
+  if (g.bias) for (int i = threadIdx.x; i < g.N; i += nthr) mb = fmaxf(mb, fabsf(g.bias[i]));
+  if (g.colscale) for (int i = threadIdx.x; i < g.N; i += nthr) mc = fmaxf(mc, fabsf(g.colscale[i]));
+  if (g.rowscale) for (int i = threadIdx.x; i < (g.M + g.rs_div - 1) / g.rs_div; i += nthr) mr = fmaxf(mr, fabsf(g.rowscale[i]));
   mb = ofb_wave_max_pos(mb); mc = ofb_wave_max_pos(mc); mr = ofb_wave_max_pos(mr);
-  if (lane == 0) { red[0][w] = mb; red[1][w] = mc; red[2][w] = mr; }
+  if (lane == 0) { red[w] = mb; red[NWV + w] = mc; red[2 * NWV + w] = mr; }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  float bound;
-  if (g.out_bound) bound = g.out_bound[0];
-  else {
-    const ofb_hhdr ha = *ofb_h_hdr(g.A), hb = *ofb_h_hdr(g.B);
-    const float ka = (float)g.K * ha.amax * ha.amax, kb = (float)g.K * hb.amax * hb.amax;
-    const float sa = g.a_kc ? ha.rn2sq : ha.cn2sq, sb = g.b_kc ? hb.rn2sq : hb.cn2sq;
-    const float na = (sa > 0.f && sa < ka) ? sa : ka, nb = (sb > 0.f && sb < kb) ? sb : kb;
-    mb = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
-    mc = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
-    mr = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
-    bound = (sqrtf(na) * sqrtf(nb) * fabsf(g.alpha) * 1.0001f + mb) * mc;
-    if (g.act == OFB_ACT_DGELU || g.act == OFB_ACT_MULAUX) bound *= g.aux_bound > 0.f ? g.aux_bound : 1.13f;
-    bound *= mr;
-  }
+  mb = red[0]; mc = red[NWV]; mr = red[2 * NWV];
+#pragma unroll
+  for (int i = 1; i < NWV; ++i) { mb = fmaxf(mb, red[i]); mc = fmaxf(mc, red[NWV + i]); mr = fmaxf(mr, red[2 * NWV + i]); }
+  const ofb_hhdr ha = *ofb_h_hdr(g.A), hb = *ofb_h_hdr(g.B);
+  const float ka = (float)g.K * ha.amax * ha.amax, kb = (float)g.K * hb.amax * hb.amax;
+  const float sa = g.a_kc ? ha.rn2sq : ha.cn2sq, sb = g.b_kc ? hb.rn2sq : hb.cn2sq;
+  const float na = (sa > 0.f && sa < ka) ? sa : ka, nb = (sb > 0.f && sb < kb) ? sb : kb;
+  float bound = (sqrtf(na) * sqrtf(nb) * fabsf(g.alpha) * 1.0001f + mb) * mc;
+  if (g.act == OFB_ACT_DGELU || g.act == OFB_ACT_MULAUX) bound *= g.aux_bound > 0.f ? g.aux_bound : 1.13f;
+  return bound * mr;
+}
+__device__ __forceinline__ void gemm_h_bound_publish(const ofb_gemm_h_args& g, float bound) {
   if (g.Cp) {
     ofb_hhdr* h = reinterpret_cast<ofb_hhdr*>(g.Cp);
     h->e = ofb_h_exp(bound); h->amax = bound; h->rn2sq = 0.f; h->cn2sq = 0.f;
   }
   if (g.cbound_out) g.cbound_out[0] = bound;
+}
+__global__ __launch_bounds__(256) void gemm_h_bound_kernel(const ofb_gemm_h_args g) {
+  __shared__ float red[3 * 4];
+  const float bound = gemm_h_bound_block<4>(g, red);
+  if (threadIdx.x == 0) gemm_h_bound_publish(g, bound);
 }
 
 #ifdef OFB_H_STAMPS
@@ -500,6 +513,17 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
   const float alpha = TAIL ? 1.f : g.alpha * ofb_h_pow2(-(ofb_h_hdr(g.A)->e + ofb_h_hdr(g.B)->e));
   const char* Apl = ofb_h_planes(g.A);
   const char* Bpl = ofb_h_planes(g.B);
+  // Output bound folded into the product (plan.stagger bit 1; launches with full rounds whose side vectors are short): every workgroup
+  // derives the same number before its first stage is requested (the loads are OLDER than every LDS-DMA piece, so the hand-counted
+  // vmcnt waits of the K loop still cover what they must), workgroup 0 publishes it for the consumers and the tail's fix-up
+  int fold_e = 0;
+  if (!TAIL && (p.stagger & 2)) {
+    float* red = reinterpret_cast<float*>(lds);
+    const float bound = gemm_h_bound_block<NW>(g, red);
+    if (blockIdx.x == 0 && t == 0) gemm_h_bound_publish(g, bound);
+    fold_e = __builtin_amdgcn_readfirstlane(ofb_h_exp(bound));
+    __syncthreads();                                      // red[] is read before the first stage lands on it
+  }
   while (true) {
     const int nk16 = cur.it1 - cur.it0, nst = (nk16 + KH - 1) / KH;
     const bool last_full = nk16 == nst * KH;              // KH == 2: an odd number of K16 steps ends in a half stage
@@ -634,7 +658,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
       const float* __restrict__ resid = g.resid;
       const float* __restrict__ rowscale = g.rowscale;
       char* __restrict__ Cpl = g.Cp ? (char*)g.Cp + OFB_HHDR : nullptr;
-      const float so = (!TAIL && has_p) ? ofb_h_pow2(reinterpret_cast<const ofb_hhdr*>(g.Cp)->e) : 1.f;   // written by the bound kernel
+      const float so = (!TAIL && has_p) ? ofb_h_pow2((p.stagger & 2) ? fold_e : reinterpret_cast<const ofb_hhdr*>(g.Cp)->e) : 1.f;   // (else: written by the bound kernel)
       const int rp_out = (g.M + 15) & ~15;
       // WIDE also serves tiles that stick out of the matrix on the COLUMN side (N = 264, 480, ... on 192-wide tiles: half of all
       // tiles of the pruned / finetune shapes): N is a multiple of 4 there, so a column quad lies wholly inside or wholly outside
@@ -966,7 +990,12 @@ Plan plan_h(const ofb_gemm_h_args& g) {
   if (narrow < 0) { const char* e = getenv("OFB_GEMM_H_NARROW"); narrow = e ? atoi(e) : 0; }
   const bool wide_ok = !narrow && (g.N & 3) == 0 && al(g.C, g.ldc) && al(g.aux, g.ldaux) && al(g.resid, g.ldr) && al(g.bias, 0) && al(g.colscale, 0) &&
                        (g.Cp == nullptr || (g.c_ncb * 16 >= g.N));
-  p.stagger = wide_ok ? 1 : 0;
+  // bit 1: the output bound is computed by the product kernel itself (gemm_h_kernel) instead of a one-block launch ahead of it
+  static int fold = -1;
+  if (fold < 0) { const char* e = getenv("OFB_GEMM_H_BOUND_FOLD"); fold = e ? atoi(e) : 1; }
+  const long long side = (g.out_bound ? 0 : (long long)(g.bias ? g.N : 0) + (g.colscale ? g.N : 0) + (g.rowscale ? (g.M + g.rs_div - 1) / g.rs_div : 0));
+  const bool fold_ok = fold && (g.Cp || g.cbound_out) && p.full_rounds > 0 && side <= 8192;
+  p.stagger = (wide_ok ? 1 : 0) | (fold_ok ? 2 : 0);
   return p;
 }
 
@@ -977,7 +1006,7 @@ void launch_full(const ofb_gemm_h_args& g, const Plan& p, hipStream_t s) {
 
 template <class CF, bool A_KC, bool B_KC>
 int launch_h(const ofb_gemm_h_args& g, const Plan& p, hipStream_t s) {
-  if (g.Cp || g.cbound_out) hipLaunchKernelGGL(gemm_h_bound_kernel, dim3(1), dim3(256), 0, s, g);
+  if ((g.Cp || g.cbound_out) && !(p.stagger & 2)) hipLaunchKernelGGL(gemm_h_bound_kernel, dim3(1), dim3(256), 0, s, g);
   if (p.full_rounds > 0) {
     const int f = (g.C ? E_C : 0) | (g.Cp ? E_P : 0) | (g.act == OFB_ACT_GELU ? E_GELU : 0) | (g.act == OFB_ACT_DGELU ? E_DGELU : 0) |
                   (g.act == OFB_ACT_GELU_GRAD ? E_GELUG : 0) | (g.act == OFB_ACT_MULAUX ? E_MULAUX : 0) |
@@ -1051,7 +1080,7 @@ extern "C" int ofb_patchify_hformat(const float* img, int32_t B, int32_t Cin, in
   hipStream_t s = (hipStream_t)stream;
   const int ncb = (int)((Cc + 15) / 16), rgs = (int)(((R + 15) / 16) * 4);
   if (hipMemsetAsync(P, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
-  hipLaunchKernelGGL(hstat_flat_kernel, dim3(512), dim3(256), 0, s, img, (size_t)B * Cin * H * W, (ofb_hhdr*)P);
+  hipLaunchKernelGGL(hstat_flat_kernel, dim3(2048), dim3(256), 0, s, img, (size_t)B * Cin * H * W, (ofb_hhdr*)P);
   hipLaunchKernelGGL(patchify_hformat_kernel, dim3((ncb * 16 + 255) / 256, rgs), dim3(256), 0, s, img, B, Cin, H, W, patch, (char*)P, ncb);
   return ofb_launch_status();
 }
