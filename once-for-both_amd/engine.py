@@ -84,6 +84,9 @@ class GraphedStep:
         # branches on hardware queues depends on which streams exist in the process (queues x priorities x RCCL: scripts/lab/
         # queue_matrix.sh) - the same bs-128 capture replays in 25.9 or 37.3 ms - and the sizes graphs are for (launch-bound: few
         # tokens) do not use the side stream anyway (ops._side_ok).  One stream: 25.7 ms at bs 128, always.
+        # (A process-wide switch on purpose: ops._side_ok / dp._launch run inside autograd's per-device worker thread, which does not
+        # inherit Python thread-locals of the thread that calls backward().  Capture is a set-up phase: do not run another model's
+        # backward in a second thread while it is in progress.)
         side_was = hip.SIDE_STREAM
         hip.SIDE_STREAM = side_was and self.side_stream
         try:

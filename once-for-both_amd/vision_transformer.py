@@ -471,13 +471,24 @@ class MIMVisionTransformer(MAEBaseModel):
         is live it is a function of alpha_patch (the reference keeps the graph it built inside compress())."""
         if getattr(self, 'weighted_mask', None) is None:
             return None
+        # switch_cell_patch / patch_search_mask are host-side state that changes in compress() only: the live-cell indices and their
+        # patch counts go to the device ONCE per compress (no boolean-mask indexing on device tensors = no host sync per step, legal
+        # inside a GraphedStep capture).  Deliberate deviation: the reference freezes weighted_mask at compress time (:811-813);
+        # here the term follows alpha_patch while more than one cell is live (DESIGN section 1).
         dev = self.alpha_patch.device
-        sw = self.switch_cell_patch.reshape(-1).to(dev)
-        counts = self.patch_search_mask.sum((1, 2, 3)).to(dev)
-        if int(self.switch_cell_patch.sum()) == 1:
-            return counts[sw].sum()
-        pr = torch.softmax(self.alpha_patch.reshape(-1)[sw], 0)
-        return (pr * counts[sw]).sum()
+        key = (id(self.switch_cell_patch), str(dev))
+        cache = getattr(self, '_active_patch_cache', None)
+        if cache is None or cache[0] != key:
+            sw = self.switch_cell_patch.reshape(-1).to('cpu', torch.bool)
+            idx = torch.nonzero(sw).reshape(-1)
+            counts = self.patch_search_mask.sum((1, 2, 3)).reshape(-1).to('cpu', torch.float32)[idx]
+            cache = (key, int(idx.numel()), idx.to(dev), counts.to(dev), self.switch_cell_patch)   # (keeps the keyed object alive)
+            self._active_patch_cache = cache
+        _, n_live, idx, counts, _ = cache
+        if n_live == 1:
+            return counts.sum()
+        pr = torch.softmax(self.alpha_patch.reshape(-1).index_select(0, idx), 0)
+        return (pr * counts).sum()
 
     def get_flops(self):
         _, out3 = self._flops_eval(0.0)
