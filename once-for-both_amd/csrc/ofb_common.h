@@ -24,7 +24,7 @@ typedef float ofb_f32x2 __attribute__((ext_vector_type(2)));
 // 1.2e-6 at |x| ~ 8), phi(x) = exp(-x^2/2) / sqrt(2 pi).  ~16 VALU + v_exp + v_rcp instead of libm erff's ~45.
 __device__ __forceinline__ void ofb_gelu_parts(float x, float& Phi, float& phi) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = __frcp_rn(1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);       // v_rcp_f32 (1 ulp); __frcp_rn is a 12-instruction IEEE division
   const float e = __expf(-0.5f * x * x);
   const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
   const float half_erfc = 0.5f * poly * e;
