@@ -484,7 +484,8 @@ def main():
                     f'module): bs {args.batch}/GPU, fwd + OFBSearchLOSS + bwd + 3x AdamW')
         step_tflops = 0.0                                        # no FLOP model for the cut shapes: only the GEMM's own work counter is quoted
     elif args.mode == 'search':
-        metric = 'images/sec OFB-search step, DeiT-S bs=128/GPU @1/2/4/8 MI355X'
+        metric = ('images/sec OFB-search step, DeiT-S bs=128/GPU @1/2/4/8 MI355X' if (args.model, args.batch) == ('deit_small', 128) else
+                  f'images/sec OFB-search step, {args.model} bs={args.batch}/GPU ({cfg_tag}; NOT the BASELINE metric)')
         workload = (f'{args.model} OFB search step + PMIM branch ({cfg_tag}): bs {args.batch}/GPU, 224x224 synthetic images, fwd + '
                     'OFBSearchLOSS + bwd + 3x AdamW, drop_path 0.1, w_p 0.99, keep ratio 0.95')
     else:
