@@ -177,6 +177,43 @@ def test_gemm_h_deit_small_layer_shapes():
     _close(dw, dy.double().t() @ x.double(), 'dW 1536x384x25216', tol=2e-5)
 
 
+@pytest.mark.parametrize('M,N,K', [(25216, 384, 384), (25216, 384, 1536), (19200, 384, 1152), (32896, 192, 400), (16500, 576, 392),
+                                   (27800, 384, 384)])
+def test_gemm_h_between_one_and_two_rounds(M, N, K):
+    """between one and two tiles per CU slot pair (394 tiles at DeiT-S bs 128 and N = 384; 300; 257; 387 with a ragged last row tile and
+    an odd number of K16 steps; 436): the shapes of five of the eight activation products of a block.  All epilogue forms these products
+    take in the model + an H-format output; strided row sample against fp64; deterministic.  (Written for the round-4 lab form that ran
+    the remainder tiles as streamed K ranges on the second workgroup of every CU, scripts/lab/gemm_h_ab_launch_inkernel_fixup.patch.txt;
+    kept because nothing else covered these tile counts at full width.)"""
+    from ofb_amd import hip
+    x, w, b = _mk((M, K), 21), _mk((N, K), 22, 0.05), _mk((N,), 23)
+    res, rs = _mk((M, N), 24), _mk(((M + 196) // 197,), 25)
+    rows = torch.arange(0, M, 61)
+    xd, wd = x.cuda(), w.cuda()
+    xp, wp, wpr = hip.to_hformat(xd), hip.to_hformat(wd), hip.to_hformat(wd.t().contiguous())
+    ref = x[rows].double() @ w.double().t()
+    out = torch.full((M, N), float('nan'), device='cuda')
+    hip.gemm_h(xp, wp, 1, 1, M, N, K, C_out=out, ldc=N, bias=b.cuda(), rowscale=rs.cuda(), rs_div=197, resid=res.cuda(), ldr=N)
+    exp = (ref + b.double()) * rs.double()[rows // 197].unsqueeze(1) + res[rows].double()
+    _close(out[rows.cuda()], exp, 'kc,kc bias + rowscale + residual')
+    assert not torch.isnan(out).any()
+    out2 = torch.empty_like(out)
+    hip.gemm_h(xp, wp, 1, 1, M, N, K, C_out=out2, ldc=N, bias=b.cuda(), rowscale=rs.cuda(), rs_div=197, resid=res.cuda(), ldr=N)
+    assert torch.equal(out, out2), 'deterministic'
+    # input-gradient form (kc,kr) with the fused residual-gradient add, and the bound scalar the attention kernels take
+    cb = torch.zeros(1, device='cuda')
+    hip.gemm_h(xp, wpr, 1, 0, M, N, K, C_out=out, ldc=N, resid=res.cuda(), ldr=N)
+    _close(out[rows.cuda()], ref + res[rows].double(), 'kc,kr + residual')
+    hip.gemm_h(xp, wpr, 1, 0, M, N, K, C_out=out, ldc=N, cbound_out=cb)
+    _close(out[rows.cuda()], ref, 'kc,kr plain')
+    assert out.abs().max().item() <= float(cb)
+    # H-format output (bound folded into the product, published by workgroup 0; the fix-up kernel reads it for the remainder tiles)
+    outp = hip.HMat(M, N, 'cuda')
+    hip.gemm_h(xp, wp, 1, 1, M, N, K, C_out=out, ldc=N, Cp=outp, bias=b.cuda())
+    _close(out[rows.cuda()], ref + b.double(), 'kc,kc bias, f32 + planes')
+    assert (outp.to_f32() - out).abs().max().item() <= 2.0 ** -23 * outp.header()[1]
+
+
 def test_gemm_h_rejects_bad_arguments():
     from ofb_amd import hip
     a = hip.to_hformat(torch.zeros(32, 32, device='cuda'))
