@@ -116,12 +116,33 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // operand of that branch's gradient GEMMs, DropPath factor applied), and part gets a third [D] section per block: the column sums
 // of those scaled rows (that branch's last bias gradient).  The planes' exponent comes from dxP's header.amax, which
 // ln_bwd_stat_kernel left there just before.
+// The bound pass (ln_bwd_stat_kernel) leaves one (amax, rn2sq) pair per block in `stat` - no atomics, no memset node: thousands of
+// blocks folding their maxima into two words serialise in one L2 channel (that was 30 of the pass's 43 us) - and EVERY block of the
+// main kernel reduces the <= 1024 pairs itself (8 KB out of the L2); block 0 publishes the header.
+__device__ __forceinline__ float ln_stat_gather(const float* __restrict__ stat, int nb, float* red8, ofb_hhdr* hdr) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  float am = 0.f, rn = 0.f;
+  for (int i = threadIdx.x; i < nb; i += 256) {
+    const float2 v = reinterpret_cast<const float2*>(stat)[i];
+    am = fmaxf(am, v.x); rn = fmaxf(rn, v.y);
+  }
+  am = ofb_wave_max_pos(am); rn = ofb_wave_max_pos(rn);
+  if (lane == 0) { red8[w] = am; red8[4 + w] = rn; }
+  __syncthreads();
+  am = fmaxf(fmaxf(red8[0], red8[1]), fmaxf(red8[2], red8[3]));
+  rn = fmaxf(fmaxf(red8[4], red8[5]), fmaxf(red8[6], red8[7]));
+  __syncthreads();                                          // red8 is the kernels' reduction scratch again from here on
+  if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->e = ofb_h_exp(am); hdr->amax = am; hdr->rn2sq = rn; hdr->cn2sq = 0.f; }
+  return am;
+}
+
 template <int V, bool PF>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ part, int rows, int D,
-                                                     char* __restrict__ dxP, const float* __restrict__ rowscale, int rs_div) {
+                                                     char* __restrict__ dxP, const float* __restrict__ rowscale, int rs_div,
+                                                     const float* __restrict__ stat, int stat_nb) {
   __shared__ float red[4 * 2 * 1024];
   constexpr int NS = PF ? 3 : 2;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -134,12 +155,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   for (int k = 0; k < (PF ? 4 : 1); ++k) cacc[k] = 0.f;
   const int Dp = (D + 15) & ~15;
   float hs = 1.f;
-  if (PF) {
-    ofb_hhdr* h = reinterpret_cast<ofb_hhdr*>(dxP);
-    const int e = ofb_h_exp(h->amax);
-    hs = ofb_h_pow2(e);
-    if (blockIdx.x == 0 && threadIdx.x == 0) h->e = e;
-  }
+  if (PF) hs = ofb_h_pow2(ofb_h_exp(ln_stat_gather(stat, stat_nb, red, reinterpret_cast<ofb_hhdr*>(dxP))));
   for (int row0 = blockIdx.x * 4; row0 < rows; row0 += gridDim.x * 4) {
     const int row = row0 + w;
     float v[LN_MAXE];
@@ -308,17 +324,15 @@ __global__ __launch_bounds__(256) void ln_bwd_p_kernel(const float* __restrict__
                                                        const float* __restrict__ gamma, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, const float* __restrict__ dres,
                                                        float* __restrict__ dx, float* __restrict__ part, int rows, int D,
-                                                       char* __restrict__ dxP, const float* __restrict__ rowscale, int rs_div) {
+                                                       char* __restrict__ dxP, const float* __restrict__ rowscale, int rs_div,
+                                                       const float* __restrict__ stat, int stat_nb) {
   constexpr int NE = 2 * NJ;
   __shared__ float red[4 * 3 * 128 * NJ];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int Dp = (D + 15) & ~15;
   float g[NE], ag[NE], ab[NE], ac[NE];
   ln_p_load<NJ>(g, gamma, D, lane);
-  ofb_hhdr* hdr = reinterpret_cast<ofb_hhdr*>(dxP);       // amax (a bound) was left there by ln_bwd_stat_kernel
-  const int he = ofb_h_exp(hdr->amax);
-  if (blockIdx.x == 0 && threadIdx.x == 0) hdr->e = he;
-  const float hs = ofb_h_pow2(he);
+  const float hs = ofb_h_pow2(ofb_h_exp(ln_stat_gather(stat, stat_nb, red, reinterpret_cast<ofb_hhdr*>(dxP))));
 #pragma unroll
   for (int i = 0; i < NE; ++i) ag[i] = ab[i] = ac[i] = 0.f;
   for (int rg = blockIdx.x * 4 + w; 4 * rg < rows; rg += gridDim.x * 4) {
@@ -398,7 +412,7 @@ template <int NJ>
 __global__ __launch_bounds__(256) void ln_bwd_stat_kernel(const float* __restrict__ dy, const float* __restrict__ gamma,
                                                           const float* __restrict__ rstd, const float* __restrict__ dres,
                                                           const float* __restrict__ rowscale, int rs_div, int rows, int D,
-                                                          ofb_hhdr* __restrict__ hdr) {
+                                                          float* __restrict__ stat) {
   __shared__ float red[2][4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float am = 0.f, rn = 0.f;
@@ -458,8 +472,8 @@ __global__ __launch_bounds__(256) void ln_bwd_stat_kernel(const float* __restric
   if (lane == 0) { red[0][w] = am; red[1][w] = rn; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    ofb_atomic_max_pos(&hdr->amax, 1.0002f * fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3])));
-    ofb_atomic_max_pos(&hdr->rn2sq, 1.0004f * fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3])));
+    stat[2 * blockIdx.x] = 1.0002f * fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    stat[2 * blockIdx.x + 1] = 1.0004f * fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
   }
 }
 
@@ -643,31 +657,33 @@ int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const flo
                   float* partials, int rows, int D, char* dxP, const float* rowscale, int rs_div, hipStream_t s) {
   const dim3 grid(ofb_layernorm_bwd_blocks(rows));
   ofb_prof_pre(3, s, (dxP ? 24.0 : 16.0) * rows * (double)D);
+  // per-block maxima of the bound pass: the last 8 KB of the plane buffer (its slack past the matrix: never read as values)
+  float* stat = dxP ? reinterpret_cast<float*>(dxP + ofb_hformat_bytes(rows, D) - 8192) : nullptr;
+  int nb = 0;
   if (dxP) {
-    if (hipMemsetAsync(dxP, 0, 16, s) != hipSuccess) return (int)hipGetLastError();
     const int nj = ofb_cdiv(D, 128);
     if (D % 2 == 0) {
-      const int nb = ofb_cdiv(rows, 16) < 1024 ? ofb_cdiv(rows, 16) : 1024;   // (measured on [25216][384]: 2048 / 1024 / 512 / 256 blocks = 17 / 13 / 17 / 21 us)
-      if (nj <= 2) hipLaunchKernelGGL(ln_bwd_stat_kernel<2>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
-      else if (nj <= 3) hipLaunchKernelGGL(ln_bwd_stat_kernel<3>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
-      else if (nj <= 6) hipLaunchKernelGGL(ln_bwd_stat_kernel<6>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
-      else hipLaunchKernelGGL(ln_bwd_stat_kernel<8>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
+      nb = ofb_cdiv(rows, 16) < 1024 ? ofb_cdiv(rows, 16) : 1024;   // (measured on [25216][384]: 2048 / 1024 / 512 / 256 blocks = 17 / 13 / 17 / 21 us)
+      if (nj <= 2) hipLaunchKernelGGL(ln_bwd_stat_kernel<2>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, stat);
+      else if (nj <= 3) hipLaunchKernelGGL(ln_bwd_stat_kernel<3>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, stat);
+      else if (nj <= 6) hipLaunchKernelGGL(ln_bwd_stat_kernel<6>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, stat);
+      else hipLaunchKernelGGL(ln_bwd_stat_kernel<8>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, stat);
     } else {
-      const int nb = ofb_cdiv(rows, 4) < 1024 ? ofb_cdiv(rows, 4) : 1024;
-      hipLaunchKernelGGL(ln_bwd_stat_kernel<0>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, (ofb_hhdr*)dxP);
+      nb = ofb_cdiv(rows, 4) < 1024 ? ofb_cdiv(rows, 4) : 1024;
+      hipLaunchKernelGGL(ln_bwd_stat_kernel<0>, dim3(nb), dim3(256), 0, s, dy, gamma, rstd, dres, rowscale, rs_div, rows, D, stat);
     }
   }
   if (dxP && D % 2 == 0) {
     const int nj = ofb_cdiv(D, 128);
-    if (nj <= 2) hipLaunchKernelGGL(ln_bwd_p_kernel<2>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
-    else if (nj <= 3) hipLaunchKernelGGL(ln_bwd_p_kernel<3>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
-    else if (nj <= 6) hipLaunchKernelGGL(ln_bwd_p_kernel<6>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
-    else hipLaunchKernelGGL(ln_bwd_p_kernel<8>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
+    if (nj <= 2) hipLaunchKernelGGL(ln_bwd_p_kernel<2>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
+    else if (nj <= 3) hipLaunchKernelGGL(ln_bwd_p_kernel<3>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
+    else if (nj <= 6) hipLaunchKernelGGL(ln_bwd_p_kernel<6>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
+    else hipLaunchKernelGGL(ln_bwd_p_kernel<8>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
   } else if (dxP) {
-    hipLaunchKernelGGL((ln_bwd_kernel<1, true>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
+    hipLaunchKernelGGL((ln_bwd_kernel<1, true>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
   } else {
-    if (D % 2 == 0) hipLaunchKernelGGL((ln_bwd_kernel<2, false>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
-    else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div);
+    if (D % 2 == 0) hipLaunchKernelGGL((ln_bwd_kernel<2, false>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
+    else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
   }
   ofb_prof_post(3, s);
   return ofb_launch_status();
