@@ -144,7 +144,9 @@ int ofb_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
 /* Same, and dx * rowscale[row / rs_div] (rowscale optional: the DropPath factor of the branch this gradient flows into) also as
  * H-format planes dx_h[rows][D]; partials is then [ofb_layernorm_bwd_blocks(rows)][3][D]: dgamma | dbeta | column sums of the
  * scaled dx rows (that branch's output-bias gradient).  The planes' exponent comes from a bound formed by a pass over dy before
- * the main kernel: |dx_row|_2 <= rstd |gamma * dy_row|_2 (LayerNorm's Jacobian is rstd times an orthogonal projection). */
+ * the main kernel: |dx_row|_2 <= rstd |gamma * dy_row|_2 (LayerNorm's Jacobian is rstd times an orthogonal projection); the pass
+ * parks its per-block maxima in the LAST 8 KB of dx_h (ofb_hformat_bytes(rows, D) bytes: slack past the matrix that no consumer reads
+ * as values), so dx_h must be a buffer of exactly that size. */
 int ofb_layernorm_bwd_h(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                         const float* dres, float* dx, float* partials, void* dx_h, const float* rowscale, int32_t rs_div,
                         int32_t rows, int32_t D, void* stream);

@@ -5,6 +5,8 @@
 // of |dout| (the dO GEMM's), constants for the probabilities (<= 1) and row-norm bounds for dS (backward, below).
 // Forward: one workgroup of 13 waves per (batch, head): the sequence (N <= 208 tokens = 13 tiles of 16; DeiT: N = 197) is cut into
 // 16-token tiles and wave w owns query tile w.  Backward: one workgroup of 8 waves per (batch, head), keys on the lanes.
+// Longer sequences (N <= 4096: 384-px inputs, patch 8) run the same kernels chunked: the forward spreads the query tiles over
+// ceil(N / 208) workgroups per (batch, head) (blockIdx.y), the backward is launched once per 224 keys (attn_bwd_kernel<true>).
 // Probabilities never touch HBM.  Reference math: models/layers.py:510-514 (search branch) and its autograd.
 //
 // 16x16x32 operand conventions: lane l gives A[i = l&15][k = 8*(l>>4) + j] and B[k = 8*(l>>4) + j][col = l&15] (j = 0..7, one 16-byte
