@@ -280,15 +280,15 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
       // forms P = exp((S - lse) - residue) = exp(S - m) / l without the half-ulp of |lse| a single float would put on the whole row
       const float ll = logf(l), ls = m_run + ll;
       const size_t li = ((size_t)b * H + head) * N + q;
-      lse[li] = ls;
-      lse[(size_t)B * H * N + li] = (m_run - ls) + ll;
+      OFB_NT_STORE(ls, lse + li);                                                  // (lse and the f32 rows are read by the backward only)
+      OFB_NT_STORE((m_run - ls) + ll, lse + (size_t)B * H * N + li);
     }
     // O[dt][r] = O^T[channel 16 dt + 4g + r][query c]: four consecutive channels of this lane's query
     float* op = out + ((size_t)b * N + q) * ldo + head * dh;
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
       const int ch = 16 * dt + 4 * g;
-      if (ch < dh) *reinterpret_cast<f32x4*>(op + ch) = O[dt];
+      if (ch < dh) OFB_NT_STORE(O[dt], reinterpret_cast<f32x4*>(op + ch));
     }
   }
   if (PF) {
@@ -434,7 +434,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
       const int ld = i == 0 ? ldq : ldo;
       const int pos = qb * AB_QB + (t >> 4), d4 = (t & 15) << 2;
       sreg[i] = zero4();
-      if (valid(pos) && d4 < dh) sreg[i] = *reinterpret_cast<const f32x4*>(base + (unsigned)(pos * ld + d4));
+      if (valid(pos) && d4 < dh) sreg[i] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(base + (unsigned)(pos * ld + d4)));   // every row is read once
     }
   };
   auto stage_store = [&](int qb) {
@@ -478,7 +478,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
   for (int i = 0; i < NIT; ++i) {
     const int idx = t + AB_THREADS * i, pos = idx >> 4, c4 = idx & 15;
     kv[i] = zero4();
-    if (valid(key0 + pos) && 4 * c4 < dh) kv[i] = *reinterpret_cast<const f32x4*>(kbase + (unsigned)((key0 + pos) * ldq + 4 * c4));
+    if (valid(key0 + pos) && 4 * c4 < dh) kv[i] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(kbase + (unsigned)((key0 + pos) * ldq + 4 * c4)));
   }
   if (!LONG && t < AB_NPOS && valid(t)) {
     const size_t li = ((size_t)b * H + head) * N + t;
@@ -496,7 +496,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
       for (int u = 0; u < 2; ++u) {
         const int d0 = 32 * ks + 8 * g + 4 * u;
         vraw[kt][ks][u] = zero4();
-        if (kv_ok && d0 < dh) vraw[kt][ks][u] = *reinterpret_cast<const f32x4*>(vbase + (unsigned)(pos * ldq + d0));
+        if (kv_ok && d0 < dh) vraw[kt][ks][u] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(vbase + (unsigned)(pos * ldq + d0)));
       }
   }
   AB_STAMP(58);

@@ -239,7 +239,7 @@ __global__ __launch_bounds__(256) void to_hformat_colsum_kernel(const float* __r
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int r = 4 * rg + t;
-        float x = (r < R && c < C) ? X[(size_t)r * ld + c] : 0.f;
+        float x = (r < R && c < C) ? OFB_NT_LOAD(X + (size_t)r * ld + c) : 0.f;       // (the f32 gradient is not read again)
         if (rowscale && r < R) x *= rowscale[rs_div == 1 ? r : r / rs_div];
         v[t] = x;
       }
@@ -711,7 +711,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
             for (int tt = 0; tt < 4; ++tt) {
               const int row = row0 + tt;
               rsv[tt] = has_rs ? rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
-              if (dg || mula) sa[tt] = *reinterpret_cast<const f32x4*>(auxr + (size_t)row * g.ldaux + col);
+              if (dg || mula) sa[tt] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(auxr + (size_t)row * g.ldaux + col));   // last use of the saved derivative
               if (has_res) sr[tt] = *reinterpret_cast<const f32x4*>(resid + (size_t)row * g.ldr + col);
             }
             f32x4 o[4], ax[4];
@@ -747,7 +747,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
             if (live) {
               if ((gelu && auxw) || gelug) {
 #pragma unroll
-                for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(auxw + (size_t)(row0 + tt) * g.ldaux + col) = ax[tt];
+                for (int tt = 0; tt < 4; ++tt) OFB_NT_STORE(ax[tt], reinterpret_cast<f32x4*>(auxw + (size_t)(row0 + tt) * g.ldaux + col));   // read by the backward only
               }
               if (has_c) {
 #pragma unroll

@@ -343,12 +343,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(const ofb_adamw_tensor* __re
   if (hyper) { lr = hyper[0]; bc1 = hyper[1]; rsqrt_bc2 = hyper[2]; }
   const float step = lr / bc1, decay = 1.0f - lr * wd;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < tt.n; i += (int64_t)gridDim.x * 256) {
-    const float g = tt.g[i];
+    // gradient and moments stream past the caches (next use: a whole step away); the parameter stays (the next forward converts it)
+    const float g = OFB_NT_LOAD(tt.g + i);
     const float p = tt.p[i] * decay;
-    const float m = tt.m[i] * beta1 + g * (1.0f - beta1);
-    const float v = tt.v[i] * beta2 + g * g * (1.0f - beta2);
-    tt.m[i] = m;
-    tt.v[i] = v;
+    const float m = OFB_NT_LOAD(tt.m + i) * beta1 + g * (1.0f - beta1);
+    const float v = OFB_NT_LOAD(tt.v + i) * beta2 + g * g * (1.0f - beta2);
+    OFB_NT_STORE(m, tt.m + i);
+    OFB_NT_STORE(v, tt.v + i);
     tt.p[i] = p - step * m / (sqrtf(v) * rsqrt_bc2 + eps);
   }
 }

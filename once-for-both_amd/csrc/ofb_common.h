@@ -19,6 +19,17 @@ void ofb_prof_post(int tag, hipStream_t s);
 
 typedef float ofb_f32x2 __attribute__((ext_vector_type(2)));
 
+// Streaming hints: data that is read for the last time in a pass, or written for a reader that is a whole pass away (what the
+// forward saves for the backward), goes past the caches as "non-temporal" so that it does not evict what the next kernels re-read
+// (measured on the fc1 product: GELU' written non-temporal 167 -> 153 us).  -DOFB_LAB_NO_NT builds the plain forms for an A/B.
+#ifdef OFB_LAB_NO_NT
+#define OFB_NT_LOAD(p) (*(p))
+#define OFB_NT_STORE(v, p) (*(p) = (v))
+#else
+#define OFB_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define OFB_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 // GELU(erf) pieces from ONE exponential: Phi(x) = 0.5 (1 + erf(x / sqrt2)) via the Abramowitz-Stegun 7.1.26 erfc form
 // (|error| <= 1.5e-7 on erf; measured 4e-7 max abs error on gelu / gelu' in fp32, below torch's own fp32 gelu error of
 // 1.2e-6 at |x| ~ 8), phi(x) = exp(-x^2/2) / sqrt(2 pi).  ~16 VALU + v_exp + v_rcp instead of libm erff's ~45.

@@ -264,6 +264,17 @@ __device__ __forceinline__ void ln_p_load(float (&v)[2 * NJ], const float* __res
     v[2 * j] = t.x; v[2 * j + 1] = t.y;
   }
 }
+// the same for rows that are not read again in this pass (saved activations and incoming gradients in the backward)
+template <int NJ>
+__device__ __forceinline__ void ln_p_load_nt(float (&v)[2 * NJ], const float* __restrict__ p, int D, int lane) {
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int c = (j * 64 + lane) * 2;
+    float2 t = make_float2(0.f, 0.f);
+    if (c < D) { const ofb_f32x2 q = OFB_NT_LOAD(reinterpret_cast<const ofb_f32x2*>(p + c)); t = make_float2(q[0], q[1]); }
+    v[2 * j] = t.x; v[2 * j + 1] = t.y;
+  }
+}
 
 template <int NJ>
 __global__ __launch_bounds__(256) void ln_fwd_p_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
@@ -346,8 +357,8 @@ __global__ __launch_bounds__(256) void ln_bwd_p_kernel(const float* __restrict__
         continue;
       }
       float v[NE], d[NE];
-      ln_p_load<NJ>(v, x + (size_t)row * D, D, lane);
-      ln_p_load<NJ>(d, dy + (size_t)row * D, D, lane);
+      ln_p_load_nt<NJ>(v, x + (size_t)row * D, D, lane);
+      ln_p_load_nt<NJ>(d, dy + (size_t)row * D, D, lane);
       const float mu = mean[row], rs = rstd[row];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
