@@ -762,10 +762,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
                   ofb_hsplit_pair(o[2][e] * so, o[3][e] * so, h1[e][1], h2[e][1]);
                 }
                 char* slot = Cpl + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8;
-                *reinterpret_cast<uint4*>(slot) = make_uint4(h1[0][0], h1[0][1], h1[1][0], h1[1][1]);
-                *reinterpret_cast<uint4*>(slot + 16) = make_uint4(h1[2][0], h1[2][1], h1[3][0], h1[3][1]);
-                *reinterpret_cast<uint4*>(slot + 128) = make_uint4(h2[0][0], h2[0][1], h2[1][0], h2[1][1]);
-                *reinterpret_cast<uint4*>(slot + 144) = make_uint4(h2[2][0], h2[2][1], h2[3][0], h2[3][1]);
+                // (H-format outputs are 155-MB streams at the DeiT-S sizes: written past the caches, -0.07 ms per step in a same-box A/B)
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                OFB_NT_STORE(((u32x4){h1[0][0], h1[0][1], h1[1][0], h1[1][1]}), reinterpret_cast<u32x4*>(slot));
+                OFB_NT_STORE(((u32x4){h1[2][0], h1[2][1], h1[3][0], h1[3][1]}), reinterpret_cast<u32x4*>(slot + 16));
+                OFB_NT_STORE(((u32x4){h2[0][0], h2[0][1], h2[1][0], h2[1][1]}), reinterpret_cast<u32x4*>(slot + 128));
+                OFB_NT_STORE(((u32x4){h2[2][0], h2[2][1], h2[3][0], h2[3][1]}), reinterpret_cast<u32x4*>(slot + 144));
               }
             }
             if (g.colpart && initem) {
