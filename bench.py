@@ -289,6 +289,8 @@ def main():
     ap.add_argument('--force-dp', action='store_true', help='exercise the DP bucket path even with one rank (debug)')
     ap.add_argument('--pruned', action='store_true', help='search mode: time the search step of a model that compress() has already cut '
                     '(ragged shapes, what most of a real search runs on; reference engine.py:201-205) - NOT the BASELINE line')
+    ap.add_argument('--search-epoch', type=float, default=0.0, help='search mode: the epoch whose warm-up state (w_p, patch keep ratio) is timed; '
+                    '0 = the state the BASELINE metric is quoted on, 10 = SURVEY 8(d) second point (w_p 0.545, keep ratio 0.85)')
     args = ap.parse_args()
 
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:     # bare `python bench.py --gpus N`: become the launcher
@@ -345,7 +347,11 @@ def main():
                                          attn_search=True, mlp_search=True, embed_search=True, patch_search=False, mae=True,
                                          mask_ratio=1.0)
             model.correct_require_grad(0.5, 0.5, 0, 0.5)
-        model.adjust_masking_ratio(0.0, 20, 100)             # epoch-0 state: keep ratio 0.95, w_p 0.99
+        # epoch-0 state by default: keep ratio 0.95, w_p 0.99; --search-epoch 10 = SURVEY 8(d)'s second point (0.85 / 0.545): more
+        # masked patches for the decoder / PMIM branch, gates further from the sigmoid scores
+        model.adjust_masking_ratio(args.search_epoch, 20, 100)
+        for m in model.searchable_modules:
+            m.update_w(args.search_epoch, 20)
         model.to(dev).train()
         lr = 2.5e-4 * eff_bs / 256
         opt_p, opt_a, opt_d = engine.build_optimizers(model, lr)
@@ -484,10 +490,11 @@ def main():
                     f'module): bs {args.batch}/GPU, fwd + OFBSearchLOSS + bwd + 3x AdamW')
         step_tflops = 0.0                                        # no FLOP model for the cut shapes: only the GEMM's own work counter is quoted
     elif args.mode == 'search':
-        metric = ('images/sec OFB-search step, DeiT-S bs=128/GPU @1/2/4/8 MI355X' if (args.model, args.batch) == ('deit_small', 128) else
+        metric = ('images/sec OFB-search step, DeiT-S bs=128/GPU @1/2/4/8 MI355X' if (args.model, args.batch, args.search_epoch) == ('deit_small', 128, 0.0) else
                   f'images/sec OFB-search step, {args.model} bs={args.batch}/GPU ({cfg_tag}; NOT the BASELINE metric)')
         workload = (f'{args.model} OFB search step + PMIM branch ({cfg_tag}): bs {args.batch}/GPU, 224x224 synthetic images, fwd + '
-                    'OFBSearchLOSS + bwd + 3x AdamW, drop_path 0.1, w_p 0.99, keep ratio 0.95')
+                    f'OFBSearchLOSS + bwd + 3x AdamW, drop_path 0.1, w_p {0.99 - 0.89 * min(args.search_epoch, 20) / 20:.3f}, '
+                    f'keep ratio {0.95 - 0.2 * min(args.search_epoch, 20) / 20:.3f}')
     else:
         metric = 'images/sec finetune step, pruned OFB-DeiT-C-like subnet (configs[4]; NOT the BASELINE metric)'
         workload = (f'configs[4]: finetune micro-step of a synthesised ~1.7 GMAC subnet (search model cut by compress()), bs {args.batch}/GPU, '
