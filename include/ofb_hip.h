@@ -108,6 +108,14 @@ int32_t ofb_colsum_h_slabs(int32_t R);
 int ofb_colsum_h(const void* P, int32_t R, int32_t C, float* partial, void* stream);
 int64_t ofb_gemm_h_workspace_bytes(const ofb_gemm_h_args* args);
 int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream);
+/* Run-time switches of the GEMM (same-process A/B of kernel variants; results are identical to rounding, only speed differs).
+ * Unset keys take the environment variable named below, read once, else the default.  Not thread-safe against running calls. */
+#define OFB_TUNE_GEMM_MFMA 0   /* OFB_GEMM_H_MFMA: 16 (default) = v_mfma_f32_16x16x32_f16, 32 = v_mfma_f32_32x32x16_f16 on the 128 x 192 tile */
+#define OFB_TUNE_GEMM_SCHED 1  /* OFB_GEMM_H_SCHED: reserved (tile scheduling of whole rounds) */
+#define OFB_TUNE_GEMM_TILE 2   /* reserved */
+#define OFB_TUNE_RESERVED3 3
+#define OFB_TUNE_COUNT 4
+int ofb_tune(int32_t key, int32_t value);
 
 /* out[i] = sum_s workspace[s*count + i] (+ out[i] if accumulate): sums per-chunk partial buffers (embed assembly) */
 int ofb_splitk_reduce(const float* workspace, int32_t splits, int64_t count, float* out, int32_t accumulate,

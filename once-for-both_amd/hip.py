@@ -21,7 +21,7 @@ ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs',
+    'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs', 'ofb_tune',
     'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_fwd_h', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_h', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_amax', 'ofb_attention_fwd', 'ofb_attention_fwd_h', 'ofb_attention_bwd',
@@ -161,6 +161,14 @@ class HMat:
         h = self.buf[:16].cpu()
         f = h.view(torch.float32)
         return int(h.view(torch.int32)[0]), float(f[1]), float(f[2]), float(f[3])
+
+
+TUNE_GEMM_MFMA, TUNE_GEMM_SCHED, TUNE_GEMM_TILE = 0, 1, 2
+
+
+def tune(key, value):
+    """run-time switch of a kernel variant (include/ofb_hip.h: OFB_TUNE_*): same results to rounding, for same-process A/B timing"""
+    check(lib().ofb_tune(int(key), int(value)), 'ofb_tune')
 
 
 def amax(x, out=None):

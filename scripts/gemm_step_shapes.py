@@ -5,18 +5,33 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ofb_amd import hip
 M, D, H3, HID = 128 * 197, 384, 1152, 1536
+# --ab KEY=V1,V2[,V3]: every product is timed under each value of the run-time switch hip.TUNE_<KEY> (interleaved rounds in this one
+# process, MI355X guide rule 24); the table then carries one column per value
+AB = None
+for a in sys.argv[1:]:
+    if a.startswith('--ab='):
+        k, vs = a[5:].split('=')
+        AB = (getattr(hip, 'TUNE_' + k.upper()), [int(v) for v in vs.split(',')])
+TOT = {}
 def run(tag, fn, flops, count, iters=10):
-    for _ in range(2): fn()
+    variants = AB[1] if AB else [None]
+    best = {v: 1e9 for v in variants}
+    for v in variants:
+        if AB: hip.tune(AB[0], v)
+        for _ in range(2): fn()
     torch.cuda.synchronize()
-    best = 1e9
     for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(iters): fn()
-        e1.record(); torch.cuda.synchronize()
-        best = min(best, e0.elapsed_time(e1) / iters)
-    print(f'{tag:46s} {best*1e3:8.1f} us {flops/best/1e9:7.1f} TF   x{count:2d}/step = {best*count:6.2f} ms')
-    return best * count
+        for v in variants:
+            if AB: hip.tune(AB[0], v)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters): fn()
+            e1.record(); torch.cuda.synchronize()
+            best[v] = min(best[v], e0.elapsed_time(e1) / iters)
+    cols = '  |  '.join(f'{best[v]*1e3:8.1f} us {flops/best[v]/1e9:7.1f} TF' for v in variants)
+    print(f'{tag:46s} {cols}   x{count:2d}/step = ' + ' / '.join(f'{best[v]*count:6.2f}' for v in variants) + ' ms')
+    for v in variants: TOT[v] = TOT.get(v, 0.) + best[v] * count
+    return best[variants[0]] * count
 r = lambda *s: torch.randn(*s, device='cuda')
 P, G = hip.to_hformat, hip.gemm_h
 x, rs = r(M, D), torch.rand(128, device="cuda").repeat_interleave(197)
@@ -45,7 +60,7 @@ dw3 = torch.empty(HID, D, device='cuda')
 tot += run('bwd dW fc1  KR,KR', lambda: G(dhP, xp, 0, 0, HID, D, M, C_out=dw3, ldc=D), 2.*M*HID*D, 12)
 dw4 = torch.empty(D, HID, device='cuda')
 tot += run('bwd dW fc2  KR,KR', lambda: G(xp, hP, 0, 0, D, HID, M, C_out=dw4, ldc=HID), 2.*M*D*HID, 12)
-print(f'sum over 12 blocks: {tot:.2f} ms')
+print('sum over 12 blocks: ' + ' / '.join(f'{TOT[v]:.2f} ms' + (f' ({v})' if v is not None else '') for v in TOT)); TOT.clear()
 tot2 = 0
 tot2 += run('convert x [M][384] -> planes (stat + split)', lambda: P(x), 0, 1)
 hh = r(M, HID)
