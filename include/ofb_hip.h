@@ -111,7 +111,7 @@ int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream);
 /* Run-time switches of the GEMM (same-process A/B of kernel variants; results are identical to rounding, only speed differs).
  * Unset keys take the environment variable named below, read once, else the default.  Not thread-safe against running calls. */
 #define OFB_TUNE_GEMM_MFMA 0   /* OFB_GEMM_H_MFMA: 16 (default) = v_mfma_f32_16x16x32_f16, 32 = v_mfma_f32_32x32x16_f16 on the 128 x 192 tile */
-#define OFB_TUNE_GEMM_SCHED 1  /* OFB_GEMM_H_SCHED: reserved (tile scheduling of whole rounds) */
+#define OFB_TUNE_GEMM_SCHED 1  /* reserved */
 #define OFB_TUNE_GEMM_TILE 2   /* reserved */
 #define OFB_TUNE_RESERVED3 3
 #define OFB_TUNE_COUNT 4
