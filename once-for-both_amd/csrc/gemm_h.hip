@@ -27,6 +27,12 @@ typedef short hs16x4 __attribute__((ext_vector_type(4)));
 typedef short hs16x8 __attribute__((ext_vector_type(8)));
 #define OFB_LDSP(p) ((__attribute__((address_space(3))) void*)(p))
 
+// lab only (scripts/lab/ablate_gemm_h.sh): -DOFB_LAB_ABLATE=n removes ONE ingredient of the 16x16x32 kernel (results are wrong) to see
+// what its time is made of: 1 = no B pieces after the prologue, 2 = no LDS-DMA at all after the prologue, 3 = no MFMAs (fragment reads
+// kept alive), 4 = no fragment reads after the prologue, 5 = no global stores in the wide epilogue
+#ifndef OFB_LAB_ABLATE
+#define OFB_LAB_ABLATE 0
+#endif
 #ifndef OFB_H_NTERM
 #define OFB_H_NTERM 3               /* 4: also h2 h2 (lab: accuracy comparison) */
 #endif
@@ -46,7 +52,7 @@ struct Cfg {
   static constexpr int HR = (NST * STAGE >= (128 + 32) * (BN + 4) * 4) ? 128 : 64;    // rows of the tile parked in LDS per epilogue pass (+ a column-sum row per 4)
   static constexpr int TROW = HR + 4;
   static_assert(A_PIECES % NW == 0 && MI % 2 == 0 && BM % HR == 0 && (32 * MI) <= HR && HR % (32 * MI) == 0, "piece / epilogue schedule");
-  static_assert(BN * TROW * 4 <= NST * STAGE && QA >= 1 && QA <= 8 && QB <= 8 && NST >= 2 && NST <= 3 && KH >= 1 && KH <= 2, "LDS budget / schedule");
+  static_assert(BN * TROW * 4 <= NST * STAGE && QA >= 1 && QA <= 8 && QB <= 8 && NST >= 2 && NST <= 4 && KH >= 1 && KH <= 2, "LDS budget / schedule");
   static_assert(NST * STAGE * WGS <= 163840, "LDS per CU");
 };
 using C128 = Cfg<2, 2, 2, 3, 2, 2, 2>;
@@ -59,7 +65,7 @@ using C96 = Cfg<4, 1, 2, 3, 3, 1, 2>;     // K16 stages: two K32 stages of a 256
 // (lab, round 4: Cfg<4, 2, 2, 3, 2, 2, 1> = 256 x 192 with EIGHT waves, one workgroup per CU, runs correctly and is 0-12 % slower than two
 //  independent 4-wave workgroups on every step shape: profiles/r04_gemm_8wave_tile_and_turnstiles.txt)
 #ifdef OFB_GEMM_H_LAB
-using C128K1 = Cfg<2, 2, 2, 3, 3, 1, 2>;          // lab: K16 stages, three of them
+using C128K1 = Cfg<2, 2, 2, 3, 4, 1, 2>;          // lab: K16 stages, FOUR of them (three stages of lead for the LDS-DMA)
 #endif
 constexpr int GRAN = OFB_HGRAN;
 constexpr int CS_SLAB_RG = 64;                      // row groups (256 rows) per column-sum slab
@@ -476,7 +482,8 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
   auto dma = [&](unsigned ldsaddr, unsigned voff, const char* base) __attribute__((always_inline)) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(ldsaddr), "v"(voff), "s"(base) : "memory");
   };
-  auto issue = [&](int buf, const char* a_src, const char* b_src) __attribute__((always_inline)) {
+  auto issue = [&](int buf, const char* a_src, const char* b_src, int steady = 0) __attribute__((always_inline)) {
+    if (OFB_LAB_ABLATE == 2 && steady) return;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0" : "=s"(keep) :: "memory");
     if constexpr (SPLIT) {
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
 #pragma unroll
       for (int q = 0; q < QA; ++q) dma(la + q * 1024, a_ln, a_src + a_pc[q]);
 #pragma unroll
-      for (int q = 0; q < QB; ++q) dma(lb + q * 1024, b_ln, b_src + b_pc[q]);
+      for (int q = 0; q < QB; ++q) if (OFB_LAB_ABLATE != 1 || steady == 0) dma(lb + q * 1024, b_ln, b_src + b_pc[q]);
     } else {
       const unsigned l0 = lds0 + (unsigned)buf * (unsigned)STAGE;
 #pragma unroll
@@ -596,9 +603,15 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
 #define OFB_MMA_HALF(AF, BF, BLK0)                                                                                                   \
   _Pragma("unroll") for (int q = T0; q < 4; ++q) _Pragma("unroll") for (int i = 0; i < HA; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
       acc[BLK0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i][TA[q]], BF[j][TB[q]], acc[BLK0 + i][j], 0, 0, 0);
+#if OFB_LAB_ABLATE == 3
+#define OFB_MMA_QUARTER(AF, BF, I0, J0)                                                                                              \
+  _Pragma("unroll") for (int i = 0; i < HM; ++i) _Pragma("unroll") for (int j = 0; j < HN; ++j)                                       \
+      asm volatile("" :: "v"(AF[i][0]), "v"(AF[i][1]), "v"(BF[j][0]), "v"(BF[j][1]));
+#else
 #define OFB_MMA_QUARTER(AF, BF, I0, J0)                                                                                              \
   _Pragma("unroll") for (int q = T0; q < 4; ++q) _Pragma("unroll") for (int i = 0; i < HM; ++i) _Pragma("unroll") for (int j = 0; j < HN; ++j) \
       acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[i][TA[q]], BF[j][TB[q]], acc[I0 + i][J0 + j], 0, 0, 0);
+#endif
 #define OFB_INTERLEAVE(NM, ND)                                                               \
   _Pragma("unroll") for (int z_ = 0; z_ < (NM); ++z_) {                                      \
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                       \
@@ -657,6 +670,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
     issue(0, a_base, b_base);
     if (nst > 1) issue(1, a_base + a_step, b_base + b_step);
     if (NST > 2 && nst > 2) issue(2, a_base + 2 * a_step, b_base + 2 * b_step);
+    if (NST > 3 && nst > 3) issue(3, a_base + 3 * a_step, b_base + 3 * b_step);
     vm_wait(((nst < NST ? nst : NST) - 1) * n_w);        // stage 0 landed; the other prologue stages may be in flight
     __builtin_amdgcn_s_barrier();
     OFB_HSTAMP(1);
@@ -667,6 +681,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
       if (q_buf) flip16();                                    // every unit starts in buffer 0
       rdA16(fa_lo, 0);
       rdB16(fb_l, 0);
+      if (OFB_LAB_ABLATE == 4) { rdA16(fa_hi, HM); rdB16(fb_r, HN); }
     }
     // the hand-over inside the LAST sub-step of stage i: this wave is done reading buf(i), its pieces of stage i+1 have landed
     // (later stages may fly), everybody agrees (barrier), stage i + NST goes into buf(i)
@@ -676,7 +691,7 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
       young = young < 0 ? 0 : (young > NST - 2 ? NST - 2 : young);
       vm_wait(young * n_w);
       __builtin_amdgcn_s_barrier();
-      if (i + NST < nst) issue(buf, a_base + (size_t)(i + NST) * a_step, b_base + (size_t)(i + NST) * b_step);
+      if (i + NST < nst) issue(buf, a_base + (size_t)(i + NST) * a_step, b_base + (size_t)(i + NST) * b_step, 1);
     };
     auto stage = [&](int i, int buf, bool full) __attribute__((always_inline)) {
       const int nbuf = buf + 1 == NST ? 0 : buf + 1;
@@ -685,12 +700,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
         // fragment reads of the halves that come next ride in the MFMA gaps: upper A, right B of this stage, then left B and lower A
         // of the next one (after the last stage they fetch a stale buffer that nothing consumes)
         __builtin_amdgcn_sched_barrier(0);
-        rdA16(fa_hi, HM);
+        if (OFB_LAB_ABLATE != 4) rdA16(fa_hi, HM);
         if (!full) { clear_hi(fa_lo); clear_hi(fb_l); }
         OFB_MMA_QUARTER(fa_lo, fb_l, 0, 0)
         OFB_SPREAD(NMQ, RQA)
         __builtin_amdgcn_sched_barrier(0);
-        rdB16(fb_r, HN);
+        if (OFB_LAB_ABLATE != 4) rdB16(fb_r, HN);
         if (!full) clear_hi(fa_hi);
         OFB_MMA_QUARTER(fa_hi, fb_l, HM, 0)
         OFB_SPREAD(NMQ, RQB)
@@ -698,12 +713,12 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
         if (full) handover(i, buf);
         flip16();
         __builtin_amdgcn_sched_barrier(0);
-        rdB16(fb_l, 0);
+        if (OFB_LAB_ABLATE != 4) rdB16(fb_l, 0);
         if (!full) clear_hi(fb_r);
         OFB_MMA_QUARTER(fa_lo, fb_r, 0, HN)
         OFB_SPREAD(NMQ, RQB)
         __builtin_amdgcn_sched_barrier(0);
-        rdA16(fa_lo, 0);
+        if (OFB_LAB_ABLATE != 4) rdA16(fa_lo, 0);
         OFB_MMA_QUARTER(fa_hi, fb_r, HM, HN)
         OFB_SPREAD(NMQ, RQA)
         __builtin_amdgcn_sched_barrier(0);
@@ -911,7 +926,8 @@ __global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args
               *reinterpret_cast<uint4*>(slot) = z; *reinterpret_cast<uint4*>(slot + 16) = z;
               *reinterpret_cast<uint4*>(slot + 128) = z; *reinterpret_cast<uint4*>(slot + 144) = z;
             }
-            if (live) {
+            if (OFB_LAB_ABLATE == 5) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); if (gelu || gelug) asm volatile("" :: "v"(ax[0]), "v"(ax[1]), "v"(ax[2]), "v"(ax[3])); }
+            if (live && OFB_LAB_ABLATE != 5) {
               if ((gelu && auxw) || gelug) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) OFB_NT_STORE(ax[tt], reinterpret_cast<f32x4*>(auxw + (size_t)(row0 + tt) * g.ldaux + col));   // read by the backward only
@@ -1110,6 +1126,7 @@ int h_tile_choice(const ofb_gemm_h_args& g) {
   if (forced < 0) { const char* e = getenv("OFB_GEMM_H_TILE"); forced = e ? atoi(e) : 0; }
   if (forced == 128) return 128;
 #ifdef OFB_GEMM_H_LAB
+  if (h_tune[OFB_TUNE_GEMM_TILE] == 1281) return 1281;
   if (forced == 1281) return 1281;
 #endif
   if (g.a_kc && !g.colpart && g.M >= 4 * C96::BM) {
