@@ -65,6 +65,9 @@ using C96 = Cfg<4, 1, 2, 3, 3, 1, 2>;     // K16 stages: two K32 stages of a 256
 // (lab, round 4: Cfg<4, 2, 2, 3, 2, 2, 1> = 256 x 192 with EIGHT waves, one workgroup per CU, runs correctly and is 0-12 % slower than two
 //  independent 4-wave workgroups on every step shape: profiles/r04_gemm_8wave_tile_and_turnstiles.txt)
 #ifdef OFB_GEMM_H_LAB
+// lab: 128 x 128 tile, wave tile 64 x 64, three K16 stages, THREE workgroups per CU (48 KB LDS, <= 168 registers): a third workgroup to
+// hide the latency of the LDS-DMA, against 20 % more staged bytes and fragment reads per MFMA
+using C128S = Cfg<2, 2, 2, 2, 3, 1, 3>;
 using C128K1 = Cfg<2, 2, 2, 3, 4, 1, 2>;          // lab: K16 stages, FOUR of them (three stages of lead for the LDS-DMA)
 #endif
 constexpr int GRAN = OFB_HGRAN;
@@ -388,7 +391,7 @@ __device__ __forceinline__ void vm_wait(int n) {           // n is wave-uniform
 enum : int { E_C = 1, E_P = 2, E_GELU = 4, E_DGELU = 8, E_RS = 16, E_RES = 32, E_ANY = 64, E_GELUG = 128, E_MULAUX = 256 };
 
 template <class CF, bool A_KC, bool B_KC, bool TAIL, int EPI>
-__global__ __launch_bounds__(CF::NT, 2) void gemm_h_kernel(const ofb_gemm_h_args g, const Plan p) {
+__global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_h_args g, const Plan p) {
   constexpr int BM = CF::BM, BN = CF::BN, WN = CF::WN, MI = CF::MI, NI = CF::NI, HA = CF::HA, NST = CF::NST, NW = CF::NW, KH = CF::KH;
   constexpr int STAGE = CF::STAGE, A_BYTES = CF::A_BYTES, QA = CF::QA, QB = CF::QB, HR = CF::HR, TROW = CF::TROW;
   constexpr int NBA = BM / 32, NBB = BN / 32;                 // 32-row blocks of each operand's tile
@@ -1126,8 +1129,8 @@ int h_tile_choice(const ofb_gemm_h_args& g) {
   if (forced < 0) { const char* e = getenv("OFB_GEMM_H_TILE"); forced = e ? atoi(e) : 0; }
   if (forced == 128) return 128;
 #ifdef OFB_GEMM_H_LAB
-  if (h_tune[OFB_TUNE_GEMM_TILE] == 1281) return 1281;
-  if (forced == 1281) return 1281;
+  if (h_tune[OFB_TUNE_GEMM_TILE] == 1281 || h_tune[OFB_TUNE_GEMM_TILE] == 1283) return h_tune[OFB_TUNE_GEMM_TILE];
+  if (forced == 1281 || forced == 1283) return forced;
 #endif
   if (g.a_kc && !g.colpart && g.M >= 4 * C96::BM) {
     const int c192 = ofb_cdiv(g.N, 192) * 192, c96 = ofb_cdiv(g.N, 96) * 96;
@@ -1351,7 +1354,7 @@ extern "C" int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream) {
   const int tile = h_tile_choice(g);
   const int mf = h_switch(OFB_TUNE_GEMM_MFMA, "OFB_GEMM_H_MFMA", 16);
 #ifdef OFB_GEMM_H_LAB
-  const int rc = tile == 1281 ? run_h<C128K1>(g, s) : (tile == 96 ? run_h<C96>(g, s) : (mf == 16 ? run_h<C128F>(g, s) : run_h<C128>(g, s)));
+  const int rc = tile == 1283 ? run_h<C128S>(g, s) : tile == 1281 ? run_h<C128K1>(g, s) : (tile == 96 ? run_h<C96>(g, s) : (mf == 16 ? run_h<C128F>(g, s) : run_h<C128>(g, s)));
 #else
   const int rc = tile == 96 ? run_h<C96>(g, s) : (mf == 16 ? run_h<C128F>(g, s) : run_h<C128>(g, s));
 #endif
