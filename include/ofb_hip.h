@@ -65,7 +65,8 @@ extern "C" {
  * H-format operand of fc2 plus the f32 gelu'(pre-activation) in aux.  An H-format output needs its exponent first: a one-block
  * pre-kernel bounds |output| from the operand headers and the epilogue inputs (bias, colscale, rowscale are scanned; aux_bound
  * bounds |aux| of the multiplying activations, default 1.13 = max gelu'); out_bound (device scalar) overrides that bound and is
- * required with resid.  cbound_out (optional device scalar) receives the bound of an f32 output for the consumer that will split
+ * required with resid (for an H-format output AND for cbound_out: the analytic bound does not see the residual).  cbound_out (optional
+ * device scalar) receives the bound of an f32 output for the consumer that will split
  * it (attention).  colpart: optional [ofb_gemm_h_colpart_rows(args)][N] partial column sums of the OUTPUT (one row per 128-row
  * tile row; 32 rows per tile row that runs in the streamed tail), each summed in a fixed order: the bias gradient of an
  * H-format-only result, e.g. d(pre-activation) of fc1; add the rows with ofb_colsum.

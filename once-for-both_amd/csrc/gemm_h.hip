@@ -1346,7 +1346,7 @@ extern "C" int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream) {
   if ((g.act == OFB_ACT_DGELU || g.act == OFB_ACT_GELU_GRAD || g.act == OFB_ACT_MULAUX) && !g.aux) return OFB_EINVAL;
   if (g.C && g.ldc < g.N) return OFB_EINVAL;
   if (g.Cp && g.c_ncb < (g.N + 15) / 16) return OFB_EINVAL;
-  if (g.Cp && g.resid && !g.out_bound) return OFB_ELIMIT;      // no bound for a residual sum without scanning it: the caller supplies one
+  if ((g.Cp || g.cbound_out) && g.resid && !g.out_bound) return OFB_ELIMIT;   // no bound for a residual sum without scanning it: the caller supplies one
   if (g.a_ncb < ((g.a_kc ? g.K : g.M) + 15) / 16 || g.b_ncb < ((g.b_kc ? g.K : g.N) + 15) / 16) return OFB_EINVAL;
   if (!ofb_aligned16(g.A) || !ofb_aligned16(g.B) || (g.Cp && !ofb_aligned16(g.Cp))) return OFB_EINVAL;
   hipStream_t s = (hipStream_t)stream;

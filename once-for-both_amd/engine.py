@@ -148,9 +148,10 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
     if device is not None and torch.device(device).type == 'cuda':
         from . import hip
         hip.reset_nonfinite(device)                      # the device-side NaN gate is scoped to this epoch loop, not to the process
-    # epoch statistics stay on the device (MetricLogger.global_avg of the reference, engine.py:87-90,186-199): running sums of
-    # the four losses plus a count of non-finite totals; the host reads them at print points only
-    sums = None
+    # epoch statistics stay on the device (MetricLogger of the reference, engine.py:87-90,186-199: one meter per key, global_avg = sum
+    # of the values a meter received / how many it received): running sums of the four losses and of the three learning rates, a
+    # count of non-finite totals and the number of updates of the three meter families; the host reads them at print points only
+    sums, stats, hsum = None, {}, [0.0] * 6
     for it, (samples, targets) in enumerate(data_loader):
         samples = samples.to(device, non_blocking=True)
         targets = targets.to(device, non_blocking=True)
@@ -164,43 +165,55 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
                 if not m.finish_search:
                     m.update_w(t, args.warmup_epochs)
         boundary = (it + 1) % accum_iter == 0
-        opts = (optimizer_param, optimizer_arch if not finish_search else None, optimizer_decoder)
+        has_arch = optimizer_arch is not None and not finish_search
+        opts = (optimizer_param, optimizer_arch if has_arch else None, optimizer_decoder)
         base, arch, dec, total = search_step(net, criterion, samples, targets, target_flops, opts, finish_search, accum_iter,
                                              do_step=boundary, reducer=reducer)
-        with torch.no_grad():
-            tf = total.detach().float()
-            zero = torch.zeros_like(tf)
-            vals = torch.stack([tf, base.detach().float(), arch.detach().float() if arch is not None else zero,
-                                dec.detach().float() if not isinstance(dec, float) else zero])
-            row = torch.cat([torch.nan_to_num(vals, nan=0.0, posinf=0.0, neginf=0.0), (~torch.isfinite(tf)).float().reshape(1)])
-            sums = row if sums is None else sums + row
         if boundary:
             gstep = epoch * n_iter + it
             lr_scheduler_param.step_update(gstep)
-            if optimizer_arch is not None and not finish_search:
+            if has_arch:
                 lr_scheduler_arch.step_update(gstep)
             if optimizer_decoder is not None:
                 lr_scheduler_decoder.step_update(gstep)
         if model_ema is not None:
             model_ema.update(model)
+        has_dec = optimizer_decoder is not None and not isinstance(dec, float)
+        with torch.no_grad():
+            tf = total.detach().float()
+            zero = torch.zeros_like(tf)
+            vals = torch.stack([tf, base.detach().float(), arch.detach().float() if (arch is not None and has_arch) else zero,
+                                dec.detach().float() if has_dec else zero])
+            # device part [loss_total, loss_param, loss_arch, loss_decoder, non-finite]; host part [lr_param, lr_arch, lr_decoder, n, n_arch,
+            # n_decoder] (known without a sync: joined to the device part at the print points only)
+            row = torch.cat([torch.nan_to_num(vals, nan=0.0, posinf=0.0, neginf=0.0).double(), (~torch.isfinite(tf)).double().reshape(1)])
+            sums = row if sums is None else sums + row
+        for i, v in enumerate((optimizer_param.param_groups[0]['lr'], optimizer_arch.param_groups[0]['lr'] if has_arch else 0.0,
+                               optimizer_decoder.param_groups[0]['lr'] if has_dec else 0.0, 1.0, float(has_arch), float(has_dec))):
+            hsum[i] += v
         if it % print_freq == 0 or it == n_iter - 1:          # the only host syncs of the loop
+            last = it == n_iter - 1
+            # every rank must take the same decision (a rank that left alone would leave the others in the next collective): the
+            # sums - the non-finite count among them - are reduced over the ranks at every look; at the epoch's end the reduced
+            # vector is the epoch's statistics over ALL ranks (engine.py:216, utils.py:41-52), the iteration counts included
+            from .dp import sum_across_ranks
+            tot, _ = sum_across_ranks(torch.cat([sums, torch.tensor(hsum, dtype=torch.float64, device=sums.device)]),
+                                      reducer.group if reducer is not None else None)
+            host = tot.tolist()
             lv = float(total.detach())
-            host = sums.tolist()
-            # any micro-step since the last look (reference: every micro-step, engine.py:146-148).  No parameter, moment or EMA
-            # update was applied after the first non-finite loss: the device-side watch (search_step) froze the AdamW / EMA kernels
-            if not math.isfinite(lv) or host[4] > 0:
-                print('Loss is {}, stopping training'.format(lv if not math.isfinite(lv) else 'non-finite in an earlier micro-step'))
+            # no parameter, moment or EMA update was applied after the first non-finite loss: the device-side watch (search_step)
+            # froze the AdamW / EMA kernels (reference: a host check every micro-step, engine.py:146-148)
+            if host[4] > 0:
+                print('Loss is {}, stopping training'.format(lv if not math.isfinite(lv) else 'non-finite on a rank / in an earlier micro-step'))
                 sys.exit(1)
-            n_seen = it + 1
-            if it == n_iter - 1:
-                # epoch end: the averages of ALL ranks (engine.py:216, utils.py:41-52): one fused all-reduce of the device vector
-                from .dp import sum_across_ranks
-                tot, w = sum_across_ranks(sums, reducer.group if reducer is not None else None)
-                host, n_seen = tot.tolist(), n_seen * w
-            stats = dict(loss_total=host[0] / n_seen, loss_param=host[1] / n_seen, loss_arch=host[2] / n_seen,
-                         loss_decoder=host[3] / n_seen, lr_param=optimizer_param.param_groups[0]['lr'])       # epoch global averages
-            print(f'Epoch: [{epoch}] [{it}/{n_iter}] loss_total: {lv:.5f} ' + ' '.join(f'{k}(avg): {v:.5f}' for k, v in stats.items())
-                  + f' time: {(time.time() - t0) / (it + 1):.4f}')
+            n, n_arch, n_dec = host[8], host[9], host[10]
+            stats = dict(loss_param=host[1] / n, loss_total=host[0] / n, lr_param=host[5] / n)
+            if n_arch > 0:
+                stats.update(loss_arch=host[2] / n_arch, lr_arch=host[6] / n_arch)
+            if n_dec > 0:
+                stats.update(loss_decoder=host[3] / n_dec, lr_decoder=host[7] / n_dec)
+            print(f'Epoch: [{epoch}] [{it}/{n_iter}] loss_total: {lv:.5f} ' + ' '.join(f'{k}(avg): {v:.6f}' for k, v in stats.items())
+                  + f' time: {(time.time() - t0) / (it + 1):.4f}' + (' (all ranks)' if last else ''))
         every = max(1, n_iter // 3 // accum_iter)
         if not finish_search and boundary and ((it + 1) // accum_iter) % every == 0 and hasattr(net, 'compress'):
             finish_search, execute_prune, optimizer_param, optimizer_decoder, optimizer_arch = net.compress(
@@ -227,7 +240,7 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
     if device is not None and torch.device(device).type == 'cuda':
         from . import hip
         hip.reset_nonfinite(device)
-    sums = None                                          # device-side [sum of losses, count of non-finite losses]
+    sums, hsum = None, [0.0, 0.0]                        # device: [sum of losses, non-finite losses]; host: [sum of lr, iterations]
     for it, (samples, targets) in enumerate(data_loader):
         samples, targets = samples.to(device, non_blocking=True), targets.to(device, non_blocking=True)
         if mixup_fn is not None:
@@ -249,21 +262,22 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
         if model_ema is not None:
             model_ema.update(model)
         with torch.no_grad():
-            lf = loss.detach().float()
-            row = torch.stack([torch.nan_to_num(lf, nan=0.0, posinf=0.0, neginf=0.0), (~torch.isfinite(lf)).float()])
+            lf = loss.detach().double()
+            row = torch.stack([torch.nan_to_num(lf, nan=0.0, posinf=0.0, neginf=0.0), (~torch.isfinite(lf)).double()])
             sums = row if sums is None else sums + row
+        hsum[0] += optimizer.param_groups[0]['lr']       # engine.py:66 (after the window's scheduler update)
+        hsum[1] += 1.0
         if it % print_freq == 0 or it == n_iter - 1:
+            # the ranks decide together (see search_one_epoch); at the epoch's end the reduced sums are the statistics of ALL ranks
+            from .dp import sum_across_ranks
+            tot, _ = sum_across_ranks(torch.cat([sums, torch.tensor(hsum, dtype=torch.float64, device=sums.device)]),
+                                      reducer.group if reducer is not None else None)
+            host = tot.tolist()
             lv = float(loss.detach())
-            host = sums.tolist()
-            if not math.isfinite(lv) or host[1] > 0:
-                print('Loss is {}, stopping training'.format(lv if not math.isfinite(lv) else 'non-finite in an earlier micro-step'))
+            if host[1] > 0:
+                print('Loss is {}, stopping training'.format(lv if not math.isfinite(lv) else 'non-finite on a rank / in an earlier micro-step'))
                 sys.exit(1)
-            n_seen = it + 1
-            if it == n_iter - 1:                         # epoch end: all ranks' average (engine.py:70, utils.py:41-52)
-                from .dp import sum_across_ranks
-                tot, w = sum_across_ranks(sums, reducer.group if reducer is not None else None)
-                host, n_seen = tot.tolist(), n_seen * w
-            stats = dict(loss=host[0] / n_seen, lr=optimizer.param_groups[0]['lr'])                    # epoch global average
+            stats = dict(loss=host[0] / host[3], lr=host[2] / host[3])                     # MetricLogger.global_avg (engine.py:72)
     return stats
 
 

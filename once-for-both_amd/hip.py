@@ -837,8 +837,12 @@ def watch_nonfinite(values):
 
 
 def reset_nonfinite(device=None):
+    if device is not None:
+        device = torch.device(device)
+        if device.type == 'cuda' and device.index is None:              # the registry's keys carry an index (nonfinite_flag)
+            device = torch.device('cuda', torch.cuda.current_device())
     for d, t in _nonfinite.items():
-        if device is None or d == torch.device(device):
+        if device is None or d == device:
             t.zero_()
 
 

@@ -531,7 +531,9 @@ class PatchEmbedTokens(torch.autograd.Function):
         Kp = w2d.shape[1]
         db = _new(dconv, D)
         dw = p_linear_bwd_weight(hip.to_hformat(dconv, B * L, D, D, colsum_out=db), _pm(patches, B * L, Kp), B * L, D, Kp, out=grad_slot(w2d))
-        dcls = dpos[0].reshape(cshape)
+        # (a copy, not a view of dpos: autograd may adopt a returned gradient as the leaf's .grad; two leaves whose .grad share
+        #  storage would both accumulate into it from the second micro-step of a gradient-accumulation window on)
+        dcls = dpos[0].reshape(cshape).clone()
         return (None, dw.view(wshape), db, None if gshape is None else dgm[0].view(gshape), dpos.view(pshape), dcls,
                 None if mshape is None else dgm[1].view(mshape), None, None)
 

@@ -251,7 +251,7 @@ class MIMVisionTransformer(MAEBaseModel):
         self._side_stream = None
 
     # ---- checkpoints: whole-object pickles (search.py:671-740) and deepcopy (ModelEma) --------------
-    _TRANSIENT = ('_gate_out', '_side_stream', '_flops_maps', '_forced', '_masked_ids', '_dp_keep')
+    _TRANSIENT = ('_gate_out', '_side_stream', '_flops_maps', '_forced', '_masked_ids', '_dp_keep', '_active_patch_cache')
 
     def __getstate__(self):
         d = self.__dict__.copy()
@@ -476,13 +476,14 @@ class MIMVisionTransformer(MAEBaseModel):
         # inside a GraphedStep capture).  Deliberate deviation: the reference freezes weighted_mask at compress time (:811-813);
         # here the term follows alpha_patch while more than one cell is live.
         dev = self.alpha_patch.device
-        key = (id(self.switch_cell_patch), str(dev))
+        # (object identity AND version counters: an in-place edit of the switch or a rebuilt / edited patch_search_mask refreshes the cache)
+        key = (id(self.switch_cell_patch), self.switch_cell_patch._version, id(self.patch_search_mask), self.patch_search_mask._version, str(dev))
         cache = getattr(self, '_active_patch_cache', None)
         if cache is None or cache[0] != key:
             sw = self.switch_cell_patch.reshape(-1).to('cpu', torch.bool)
             idx = torch.nonzero(sw).reshape(-1)
             counts = self.patch_search_mask.sum((1, 2, 3)).reshape(-1).to('cpu', torch.float32)[idx]
-            cache = (key, int(idx.numel()), idx.to(dev), counts.to(dev), self.switch_cell_patch)   # (keeps the keyed object alive)
+            cache = (key, int(idx.numel()), idx.to(dev), counts.to(dev), (self.switch_cell_patch, self.patch_search_mask))   # (keeps the keyed objects alive)
             self._active_patch_cache = cache
         _, n_live, idx, counts, _ = cache
         if n_live == 1:

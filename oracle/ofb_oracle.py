@@ -508,15 +508,20 @@ class OptimState:
         return next(g for g, names in self.groups.items() if name in names)
 
     def step(self, p, grads, lr):
-        """one AdamW step on every listed parameter that received a gradient (optim.py:71-73 skips grad None)."""
+        """one AdamW step on every listed parameter that received a gradient (optim.py:71-73 skips grad None).
+        lr: one float for the three optimizers, or {'p': .., 'd': .., 'a': ..} - an optimizer that is absent from the dict does not
+        step (engine.py:207-209: optimizer_arch is None once the search has finished)."""
         for g, names in self.groups.items():
             b1, wd = self.HYPER[g]
+            if isinstance(lr, dict) and g[0] not in lr:
+                continue
+            glr = lr[g[0]] if isinstance(lr, dict) else lr
             for k in names:
                 if grads.get(k) is None:
                     continue
                 st = self.state.setdefault(k, dict(step=0, m=torch.zeros_like(p[k]), v=torch.zeros_like(p[k])))
                 st['step'] += 1
-                p[k], st['m'], st['v'] = adamw_step(p[k], grads[k], st['m'], st['v'], st['step'], lr, b1, 0.999, 1e-8, wd)
+                p[k], st['m'], st['v'] = adamw_step(p[k], grads[k], st['m'], st['v'], st['step'], glr, b1, 0.999, 1e-8, wd)
 
     # optim.py:122-182 -------------------------------------------------------------------
     def take(self, name, index, dim):
@@ -707,6 +712,65 @@ def compress_model(cfg: Config, p, st: SearchState, opt: OptimState = None, thre
         finish &= st.finished.get(name, False)
         execute |= st.execute.get(name, False)
     return finish, execute
+
+
+def search_epoch(cfg: Config, p, st: SearchState, opt: OptimState, n_iter, batch_of, noise_of, *, epoch, accum_iter, warmup_epochs,
+                 lr, lr_sched, hook=None, target_flops=1.0, w=(0.5, 0.5, 0.0, 0.5, 5.0), thresh=0.2, progressive=True,
+                 max_ratio=0.95, min_ratio=0.75, finish_search=False):
+    """engine.search_one_epoch (engine.py:75-219) on the functional oracle: per accumulation window the masking-ratio and w_p
+    schedules at t = it / len + epoch (:101-115; vision_transformer.py:521-523, layers.py:169-171), per micro-step the search loss
+    / accum_iter accumulated into the gradients (:152,169), at the window's end the three AdamW steps and the lr schedulers'
+    step_update(epoch * len + it) (:170-184), the meters of MetricLogger (:186-196; global_avg = mean over the updates a meter
+    received, utils.py:62-64) and, while the search is live, compress() every len // 3 // accum windows (:201-209).
+    batch_of(it) -> (imgs, labels); noise_of(it) -> patch-mask noise; lr: {'p','a','d'} initial rates; lr_sched(which, gstep) -> rate;
+    hook(it) runs before batch `it` is drawn (the data loader's side effects).
+    Returns (stats, finish_search, execute_pruned, per-iteration dict)."""
+    lr = dict(lr)
+    has_arch = not finish_search
+    acc, meters, per_it = {}, {}, {k: [] for k in ('base', 'arch', 'dec', 'keep_ratio', 'w_p', 'finish')}
+    execute_pruned = False
+
+    def meter(k, v):
+        meters.setdefault(k, []).append(float(v))
+
+    for it in range(n_iter):
+        if hook is not None:
+            hook(it)
+        imgs, labels = batch_of(it)
+        if it % accum_iter == 0:
+            t = it / n_iter + epoch
+            if progressive and t <= warmup_epochs:
+                st.keep_ratio = max_ratio - (max_ratio - min_ratio) * t / warmup_epochs
+            if t <= warmup_epochs:
+                st.w_p = (0.1 - 0.99) / warmup_epochs * t + 0.99             # every module that has not finished its search
+        leaves = {k: v.detach().clone().requires_grad_(k not in st.frozen) for k, v in p.items()}
+        out = search_step_loss(cfg, leaves, st, imgs, labels, noise_of(it), None, target_flops, w, finish_search)
+        (out['loss_total'] / accum_iter).backward()
+        for k, v in leaves.items():
+            if v.grad is not None:
+                acc[k] = v.grad if k not in acc else acc[k] + v.grad
+        per_it['base'].append(float(out['base'].detach())); per_it['arch'].append(float(out['arch'].detach()))
+        per_it['dec'].append(float(out['decoder_loss'].detach())); per_it['keep_ratio'].append(st.keep_ratio)
+        per_it['w_p'].append(st.w_p); per_it['finish'].append(float(finish_search))
+        boundary = (it + 1) % accum_iter == 0
+        if boundary:
+            opt.step(p, acc, {k: v for k, v in lr.items() if k != 'a' or has_arch})
+            acc = {}
+            gstep = epoch * n_iter + it
+            for which in ('p', 'a', 'd'):
+                if which != 'a' or has_arch:
+                    lr[which] = lr_sched(which, gstep)
+        meter('loss_param', out['base'].detach()); meter('loss_total', out['loss_total'].detach()); meter('lr_param', lr['p'])
+        if has_arch:
+            meter('loss_arch', out['arch'].detach()); meter('lr_arch', lr['a'])
+        meter('loss_decoder', out['decoder_loss'].detach()); meter('lr_decoder', lr['d'])
+        if not finish_search and boundary and ((it + 1) // accum_iter) % (n_iter // 3 // accum_iter) == 0:
+            fin, ex = compress_model(cfg, p, st, opt, thresh)
+            execute_pruned |= bool(ex)
+            if fin:
+                finish_search, has_arch = True, False
+    stats = {k: sum(v) / len(v) for k, v in meters.items()}
+    return stats, finish_search, execute_pruned, per_it
 
 
 def fuse_params(cfg: Config, p, st: SearchState):

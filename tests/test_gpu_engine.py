@@ -192,3 +192,138 @@ def test_graphed_step_reproduces_eager_steps():
         assert r_eg[k_eg] <= max(1e-5, 2 * r_ee[k_ee])
     finally:
         torch.cuda.set_stream(prev)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the epoch protocol against the REFERENCE's own run of engine.search_one_epoch / train_one_epoch (tests/golden/mini_epoch.npz,
+# micro_train_epoch.npz, made by tests/golden/make_golden_epoch.py; the oracle is pinned to the same fixtures in
+# tests/test_oracle_epoch.py): schedules, gradient accumulation, the compress trigger, the three optimizers with per-step learning
+# rates and the returned statistics (every key of the reference's MetricLogger)
+# ------------------------------------------------------------------------------------------------------------------
+def test_search_one_epoch_matches_reference_run():
+    import numpy as np
+    from oracle import ofb_oracle as O
+    from ofb_amd import engine
+    from ofb_amd.losses import OFBSearchLOSS, DistillationLoss, LabelSmoothingCrossEntropy
+    from tests import epoch_util as E
+    from tests.golden_util import sample
+    from tests.test_gpu_model import build_product
+    z = E.load()
+    cfg = O.Config(**E.MINI, drop_path_rate=0.0)
+    dev = torch.device('cuda')
+    inputs = dict(patch_noise=E.noise_of(0, cfg.num_patches), droppath_u=torch.zeros(2 * cfg.depth, E.BATCH))
+    m = build_product(cfg, O.SearchState(), inputs)
+    by_name = dict(zip(O.module_names(cfg), m.searchable_modules))
+    opt_p, opt_a, opt_d = engine.build_optimizers(m, lr=E.LR0['p'], lr_arch=E.LR0['a'], lr_decoder=E.LR0['d'], weight_decay=1e-3)
+
+    class Sched:
+        def __init__(self, opt, which):
+            self.opt, self.which, self.calls = opt, which, []
+
+        def step_update(self, gstep):
+            self.calls.append(gstep)
+            for g in self.opt.param_groups:
+                g['lr'] = E.lr_at(self.which, gstep)
+
+    sch = {'p': Sched(opt_p, 'p'), 'a': Sched(opt_a, 'a'), 'd': Sched(opt_d, 'd')}
+    per_it = dict(base=[], arch=[], keep_ratio=[], w_p=[])
+    crit0 = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, attn_w=0.5, mlp_w=0.5,
+                          patch_w=0.0, embedding_w=0.5, flops_w=5.0)
+
+    def crit(samples, outputs, targets, mdl, phase, target_flops, finish):
+        loss = crit0(samples, outputs, targets, mdl, phase, target_flops, finish)
+        base, arch = loss if isinstance(loss, tuple) else (loss, None)
+        per_it['base'].append(base.detach())
+        per_it['arch'].append(arch.detach() if arch is not None else torch.zeros((), device=dev))
+        per_it['keep_ratio'].append(float(m.patch_ratio_list[0]))
+        live = [x.w_p for x in m.searchable_modules if not x.finish_search]
+        per_it['w_p'].append(float(live[0]) if live else -1.0)
+        return loss
+
+    class Loader:                                            # the loader of the fixture: crafts the alphas, selects the noise
+        def __len__(self):
+            return E.N_ITER
+
+        def __iter__(self):
+            for i in range(E.N_ITER):
+                stage = E.CRAFT_AT.get(i)
+                if stage:
+                    for name, a in E.crafted(z, stage).items():
+                        assert tuple(by_name[name].alpha.shape) == tuple(a.shape), name
+                        by_name[name].alpha.data.copy_(a)
+                m._forced = dict(patch_noise=E.noise_of(i, cfg.num_patches).to(dev), droppath_u=torch.zeros(2 * cfg.depth, E.BATCH, device=dev))
+                yield E.batch_of(i, cfg.num_classes)
+
+    args = types.SimpleNamespace(accum_iter=E.ACCUM, warmup_epochs=E.WARMUP_EPOCHS, epochs=E.EPOCHS)
+    stats, fin, pruned, o_p, o_d, o_a = engine.search_one_epoch(m, crit, 1.0, Loader(), opt_p, opt_d, opt_a, sch['p'], sch['a'], sch['d'], dev,
+                                                                epoch=0, args=args, print_freq=2)
+    torch.cuda.synchronize()
+    assert [int(fin), int(pruned)] == z['flags'].tolist() and o_a is None
+    for w in 'pad':
+        assert sch[w].calls == z[f'sched_calls.{w}'].tolist(), (w, sch[w].calls)
+    got = {k: np.array([float(v) for v in per_it[k]]) for k in per_it}
+    for k in ('base', 'arch', 'keep_ratio', 'w_p'):
+        exp = z[f'it.{k}']
+        ok = exp >= 0 if k == 'w_p' else np.ones_like(exp, bool)
+        assert np.allclose(got[k][ok], exp[ok], rtol=1e-3, atol=1e-7), (k, got[k], exp)
+    E.check_stats(z, stats, 1e-3)                           # north_star tolerance; the same keys as the reference's dict
+    assert abs(o_p.param_groups[0]['lr'] - z['lr_final'][0]) < 1e-12 and abs(o_d.param_groups[0]['lr'] - z['lr_final'][1]) < 1e-12
+    name_of = {id(p): k for k, p in m.named_parameters()}
+    for tag, o in (('p', o_p), ('d', o_d)):
+        for gi, grp in enumerate(o.param_groups):
+            assert [name_of[id(p)] for p in grp['params']] == list(z[f'optnames.{tag}.{gi}']), (tag, gi)
+    for name, mod in by_name.items():
+        assert np.array_equal(mod.switch_cell.cpu().numpy().astype(bool), z[f'switch.{name}']), name
+        fl = z[f'flags.{name}'].tolist()
+        assert [int(mod.finish_search), int(mod.execute_prune)] == fl[:2], name
+    for k, p in m.named_parameters():
+        v = p.detach().cpu()
+        assert list(v.shape) == z[f'shape.{k}'].tolist() and bool(p.requires_grad) == bool(z[f'rg.{k}']), k
+        if 'alpha' in k or 'score' in k:
+            assert float((v - torch.from_numpy(z[f'val.{k}'])).abs().max()) < 1e-3 * max(1.0, float(np.abs(z[f'val.{k}']).max())), k
+        elif not k.endswith('qkv.bias'):                    # (zero-gradient third: Adam moves it by +-lr on rounding noise)
+            assert float((sample(v).double() - torch.from_numpy(z[f'vsamp.{k}']).double()).abs().max()) < 2e-4, k
+
+
+def test_train_one_epoch_matches_reference_run():
+    import numpy as np
+    import ofb_amd
+    from ofb_amd import engine
+    from ofb_amd.optim import AdamW
+    from ofb_amd.losses import DistillationLoss, LabelSmoothingCrossEntropy
+    from oracle import fill
+    from oracle import ofb_oracle as O
+    from tests import epoch_util as E
+    from tests.golden_util import sample
+    z = E.load('micro_train_epoch')
+    batch, n_iter = int(z['meta'][0]), int(z['meta'][1])
+    dev = torch.device('cuda')
+    m = ofb_amd.VisionTransformer(embed_dim=E.FT['embed_dim'], depth=E.FT['depth'], num_heads=E.FT['num_heads'],
+                                  num_classes=E.FT['num_classes'], drop_path_rate=0.0)
+    m.load_state_dict({k: torch.from_numpy(fill.param_value(k, tuple(v.shape))) for k, v in m.state_dict().items()})
+    m.to(dev)
+    names, params = {0: [], 1: []}, {0: [], 1: []}
+    for k, p in m.named_parameters():
+        gi = 0 if O.optimizer_group(k, tuple(p.shape)) == 'nodecay' else 1
+        names[gi].append(k)
+        params[gi].append(p)
+    opt = AdamW([{'params': params[0], 'weight_decay': 0.}, {'params': params[1], 'weight_decay': 1e-3}], names, lr=1e-3)
+
+    class Sched:
+        calls = []
+
+        def step_update(self, gstep):
+            self.calls.append(gstep)
+            for g in opt.param_groups:
+                g['lr'] = E.ft_lr_at(gstep)
+
+    data = [E.batch_of(i, E.FT['num_classes'], batch) for i in range(n_iter)]
+    crit = DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0)
+    sched = Sched()
+    stats = engine.train_one_epoch(m, crit, data, opt, sched, dev, epoch=1, args=types.SimpleNamespace(accum_iter=1), print_freq=1)
+    torch.cuda.synchronize()
+    assert sched.calls == z['sched_calls'].tolist()
+    E.check_stats(z, stats, 1e-3)
+    for k, p in m.named_parameters():
+        if not k.endswith('qkv.bias'):
+            assert float((sample(p.detach().cpu()).double() - torch.from_numpy(z[f'vsamp.{k}']).double()).abs().max()) < 2e-4, k

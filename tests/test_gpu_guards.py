@@ -210,3 +210,32 @@ def test_layernorm_module_used_twice_and_hooked_parameters_get_whole_gradients()
     hip._deferred.append((x1, 1, 1, 1, x1))
     hip.begin_forward()
     assert not ops._cb_queued[0] and not hip._deferred
+
+
+def test_gradient_accumulation_equals_the_sum_of_the_micro_steps():
+    """two micro-steps accumulated into .grad (engine.py:152-169 with accum_iter 2) against the same two backward passes run
+    separately and added: every leaf, bit for bit where the addition order is the same.  Regression (round 5): the cls_token
+    gradient was returned as a VIEW of the pos_embed gradient; autograd adopted both as the leaves' .grad, which then shared
+    storage, and from the second micro-step on each of them accumulated into the other (found by the reference-pinned epoch test,
+    tests/test_gpu_engine.py::test_search_one_epoch_matches_reference_run)."""
+    z, cfg, st, inputs, lr = load_case('micro_a')
+    m = build_product(cfg, st, inputs)
+    singles = []
+    for rep in range(2):
+        for p in m.parameters():
+            p.grad = None
+        run_step(m, inputs)
+        singles.append({k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    for p in m.parameters():
+        p.grad = None
+    run_step(m, inputs)
+    run_step(m, inputs)                                                           # accumulates on top of the first pass
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        exp = singles[0][k] + singles[1][k]
+        err = float((p.grad - exp).abs().max()) / (float(exp.abs().max()) + 1e-30)
+        assert err < 1e-5, (k, err)
+    spans = sorted((p.grad.data_ptr(), p.grad.data_ptr() + p.grad.numel() * 4, k) for k, p in m.named_parameters() if p.grad is not None)
+    for (a0, a1, ka), (b0, b1, kb) in zip(spans, spans[1:]):                      # no two leaves' gradients overlap in memory
+        assert a1 <= b0, (ka, kb)
