@@ -93,7 +93,15 @@ typedef struct ofb_gemm_h_args {
   float aux_bound;
   const float* out_bound;
   float* cbound_out;
+  /* optional (all three or none): rn_out[ofb_gemm_h_rn_tiles(args)] receives, per output tile, the maximum over the tile's rows m of
+   * rn_rowfac[m] * | rn_gamma[n] * C[m][n], n in the tile |_2 - with rn_gamma / rn_rowfac = the weight and the saved 1 / std of the
+   * LayerNorm whose backward consumes this output (an input gradient), the bound of that backward's result is
+   * sqrt(column tiles) * max(rn_out): ofb_layernorm_bwd_h_rn takes it instead of running its own pass over the gradient */
+  const float* rn_gamma;
+  const float* rn_rowfac;
+  float* rn_out;
 } ofb_gemm_h_args;
+int32_t ofb_gemm_h_rn_tiles(const ofb_gemm_h_args* args, int32_t* col_tiles);   /* entries of rn_out; *col_tiles = tiles along N */
 int32_t ofb_gemm_h_colpart_rows(const ofb_gemm_h_args* args);
 int64_t ofb_hformat_bytes(int32_t R, int32_t C);
 /* bound (optional device scalar >= max |X * rowscale|): skips the statistics pass that otherwise measures amax / row norms first */
@@ -159,6 +167,11 @@ int ofb_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
 int ofb_layernorm_bwd_h(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
                         const float* dres, float* dx, float* partials, void* dx_h, const float* rowscale, int32_t rs_div,
                         int32_t rows, int32_t D, void* stream);
+/* The same with the bound of the result taken from rn[n_rn] - the rn_out of the ofb_gemm_h call that produced dy, rn_fac = sqrt(its
+ * column tiles) - instead of a bound pass over dy; dy must be the only gradient of the LayerNorm's output (no dres). */
+int ofb_layernorm_bwd_h_rn(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, float* dx,
+                           float* partials, void* dx_p, const float* rowscale, int32_t rs_div, int32_t rows, int32_t D, const float* rn,
+                           int32_t n_rn, float rn_fac, void* stream);
 
 /* out[N] = column sums of x[M][ld] (optionally rows scaled by rowscale[m / rs_div]): bias gradients of every
  * Linear on the path.  scratch: ofb_colsum_slabs(M, N) * N floats. */

@@ -388,7 +388,7 @@ __device__ __forceinline__ void vm_wait(int n) {           // n is wave-uniform
 
 // Epilogue forms are compile-time (EPI = set of E_* bits): with run-time flags hipcc has to assume that a side-input load may
 // follow an aliasing store and puts s_waitcnt vmcnt(0) between the stores of every element.
-enum : int { E_C = 1, E_P = 2, E_GELU = 4, E_DGELU = 8, E_RS = 16, E_RES = 32, E_ANY = 64, E_GELUG = 128, E_MULAUX = 256 };
+enum : int { E_C = 1, E_P = 2, E_GELU = 4, E_DGELU = 8, E_RS = 16, E_RES = 32, E_ANY = 64, E_GELUG = 128, E_MULAUX = 256, E_RN = 512 };
 
 template <class CF, bool A_KC, bool B_KC, bool TAIL, int EPI>
 __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_h_args g, const Plan p) {
@@ -821,12 +821,24 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
       // NARROW form: one (4-row group, column) item per thread, dword accesses, per-element guards.
       constexpr int TLD = BN + 4;
       static_assert((HR + HR / 4) * TLD * 4 <= NST * STAGE, "epilogue patch + column-sum rows");
+      // (the row-norm hand-over needs room for its parts behind them and four threads per parked row: the 128 x 192 tiles; the host
+      //  keeps launches that ask for it off the other tiles)
+      constexpr bool RN_OK = ((HR + HR / 4) * TLD + HR * (BN / 4) + 4) * 4 <= NST * STAGE && CF::NT >= 4 * HR && (BN / 4) % 16 == 0;
       constexpr bool ANY = (EPI & E_ANY) != 0;
       const bool has_c = ANY ? g.C != nullptr : (EPI & E_C) != 0, has_p = ANY ? g.Cp != nullptr : (EPI & E_P) != 0;
       const bool gelu = ANY ? g.act == OFB_ACT_GELU : (EPI & E_GELU) != 0, dg = ANY ? g.act == OFB_ACT_DGELU : (EPI & E_DGELU) != 0;
       const bool gelug = ANY ? g.act == OFB_ACT_GELU_GRAD : (EPI & E_GELUG) != 0, mula = ANY ? g.act == OFB_ACT_MULAUX : (EPI & E_MULAUX) != 0;
       const bool has_rs = ANY ? g.rowscale != nullptr : (EPI & E_RS) != 0, has_res = ANY ? g.resid != nullptr : (EPI & E_RES) != 0;
+      // E_RN (rn_out): per tile, max over its rows of rn_rowfac[row] * |rn_gamma (.) output row, this tile's columns|_2 - what the
+      // LayerNorm backward that consumes this gradient needs for the exponent of ITS output planes (rowops.hip: the bound pass it
+      // otherwise runs over the whole gradient).  Every item parks its rows' sums of squares in Rp[row][column quad] (plain stores: the
+      // 48 items of a row group adding into one word by LDS atomics serialised the CU's atomic unit, +19 us per launch), four threads
+      // per row add them up after the pass; the tile's maximum gathers in Rmx[0]
+      const bool rn = RN_OK && !TAIL && (ANY ? g.rn_out != nullptr : (EPI & E_RN) != 0);
       float* T = reinterpret_cast<float*>(lds);
+      float* Rp = reinterpret_cast<float*>(lds) + (HR + HR / 4) * TLD;         // [HR][BN / 4]
+      float* Rmx = Rp + HR * (BN / 4);
+      if (rn && t == 0) Rmx[0] = 0.f;                                  // (visible behind the barriers below; read back at the tile's end)
       float* __restrict__ Cout = g.C;
       float* __restrict__ auxw = g.aux;
       const float* __restrict__ auxr = g.aux;
@@ -923,6 +935,16 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
                 o[tt][e] = val;
               }
             }
+            if (rn && initem) {
+              const f32x4 gm = *reinterpret_cast<const f32x4*>(g.rn_gamma + col);
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt) {
+                float ss = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float q = gm[e] * o[tt][e]; ss += q * q; }
+                Rp[(4 * rgl + tt) * NQ + cq] = live ? ss : 0.f;
+              }
+            }
             if (zpad) {
               char* slot = Cpl + ((size_t)(row0 >> 2) * g.c_ncb + (col0 >> 4)) * GRAN + (col0 & 15) * 8;
               const uint4 z = make_uint4(0u, 0u, 0u, 0u);
@@ -963,6 +985,22 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
               *reinterpret_cast<f32x4*>(S + rgl * TLD + lcol) = cs4;
             }
           }
+          if (rn) {
+            __syncthreads();                                          // every item's row parts are in
+            if (RN_OK && t < 4 * HR) {
+              const int rr = t >> 2, part = t & 3, row = cur.m0 + HR * half + rr;
+              float ss = 0.f;
+#pragma unroll
+              for (int q4 = 0; q4 < NQ / 16; ++q4) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(Rp + rr * NQ + (NQ / 4) * part + 4 * q4);
+                ss += (v[0] + v[1]) + (v[2] + v[3]);
+              }
+              ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
+              const float v = row < g.M ? g.rn_rowfac[row] * sqrtf(ss) : 0.f;
+              const float m = ofb_wave_max_pos(v);
+              if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(Rmx), __float_as_uint(m));
+            }
+          }
           if (!TAIL && g.colpart) {
             // column sums of this pass: one thread per column adds the row groups' sums in order; the passes of a tile in order too
             __syncthreads();
@@ -984,6 +1022,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
 #pragma unroll 1
           for (int k = 0; k < NRG; ++k) {
             const int rgl = w + NW * k, row0 = cur.m0 + HR * half + 4 * rgl;
+            float rss[4] = {0.f, 0.f, 0.f, 0.f};                        // E_RN: this lane's share of the four rows' sums of squares
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
               const int lcol = lane + 64 * c, col = cur.n0 + lcol;
@@ -1017,9 +1056,23 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
                 pv[tt] = ok ? val : 0.f;
               }
               cacc[c] += (pv[0] + pv[1]) + (pv[2] + pv[3]);
+              if (rn) {
+                const float gmv = colok ? g.rn_gamma[colc] : 0.f;
+#pragma unroll
+                for (int tt = 0; tt < 4; ++tt) { const float q = gmv * pv[tt]; rss[tt] += q * q; }
+              }
               if (has_p && row0 < rp_out && col < g.c_ncb * 16)
                 store_h4(Cpl + ((size_t)(row0 >> 2) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8, pv[0] * so, pv[1] * so, pv[2] * so,
                          pv[3] * so);
+            }
+            if (rn) {                                                   // a wave holds whole tile rows here: their sums by shuffles
+              float m = 0.f;
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt) {
+                const float ss = ofb_wave_sum(rss[tt]);
+                if (row0 + tt < g.M) m = fmaxf(m, g.rn_rowfac[row0 + tt] * sqrtf(ss));
+              }
+              if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(Rmx), __float_as_uint(m));
             }
           }
           if (g.colpart) {
@@ -1038,6 +1091,10 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
           }
         }
         if (half + 1 < BM / HR) __syncthreads();                    // T is rewritten by the next pass (the next unit starts with a barrier)
+      }
+      if (rn) {
+        __syncthreads();
+        if (t == 0) g.rn_out[(cur.m0 / BM) * p.nt + cur.n0 / BN] = Rmx[0];
       }
     }
     OFB_HSTAMP(3);
@@ -1132,7 +1189,7 @@ int h_tile_choice(const ofb_gemm_h_args& g) {
   if (h_tune[OFB_TUNE_GEMM_TILE] == 1281 || h_tune[OFB_TUNE_GEMM_TILE] == 1283) return h_tune[OFB_TUNE_GEMM_TILE];
   if (forced == 1281 || forced == 1283) return forced;
 #endif
-  if (g.a_kc && !g.colpart && g.M >= 4 * C96::BM) {
+  if (g.a_kc && !g.colpart && !g.rn_out && g.M >= 4 * C96::BM) {
     const int c192 = ofb_cdiv(g.N, 192) * 192, c96 = ofb_cdiv(g.N, 96) * 96;
     if (forced == 96) return 96;
     if (c96 < c192) {
@@ -1157,6 +1214,7 @@ Plan plan_h(const ofb_gemm_h_args& g) {
   const long long iters = (long long)tiles * ofb_cdiv(g.K, 16);
   if (iters < W) W = (int)iters;
   Plan p = make_plan(g.M, g.N, g.K, W, CF::BM, CF::BN, 16);
+  if (p.R > 0 && g.rn_out) { p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0; }   // (the fix-up kernel has no row-norm form)
   if (p.R > 0 && g.colpart && p.R % p.nt != 0) {                     // column sums of tail tiles come from the fix-up kernel, which
     p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;         // addresses them per whole tile row
   }
@@ -1206,10 +1264,12 @@ int launch_h(const ofb_gemm_h_args& g, const Plan& p, hipStream_t s) {
   if (p.full_rounds > 0) {
     const int f = (g.C ? E_C : 0) | (g.Cp ? E_P : 0) | (g.act == OFB_ACT_GELU ? E_GELU : 0) | (g.act == OFB_ACT_DGELU ? E_DGELU : 0) |
                   (g.act == OFB_ACT_GELU_GRAD ? E_GELUG : 0) | (g.act == OFB_ACT_MULAUX ? E_MULAUX : 0) |
-                  (g.rowscale ? E_RS : 0) | (g.resid ? E_RES : 0);
+                  (g.rowscale ? E_RS : 0) | (g.resid ? E_RES : 0) | (g.rn_out ? E_RN : 0);
     switch (f) {     // the forms the model issues; anything else takes the generic (run-time flags) instantiation
       case E_C: launch_full<CF, A_KC, B_KC, E_C>(g, p, s); break;
       case E_C | E_RES: launch_full<CF, A_KC, B_KC, E_C | E_RES>(g, p, s); break;
+      case E_C | E_RES | E_RN: launch_full<CF, A_KC, B_KC, E_C | E_RES | E_RN>(g, p, s); break;
+      case E_C | E_RN: launch_full<CF, A_KC, B_KC, E_C | E_RN>(g, p, s); break;
       case E_C | E_RS | E_RES: launch_full<CF, A_KC, B_KC, E_C | E_RS | E_RES>(g, p, s); break;
       case E_P | E_GELUG: launch_full<CF, A_KC, B_KC, E_P | E_GELUG>(g, p, s); break;
       case E_P | E_MULAUX: launch_full<CF, A_KC, B_KC, E_P | E_MULAUX>(g, p, s); break;
@@ -1335,6 +1395,15 @@ extern "C" int32_t ofb_gemm_h_colpart_rows(const ofb_gemm_h_args* args) {
   return p.R ? (p.mt - p.R / p.nt) + (p.R / p.nt) * (C128::BM / 4) : p.mt;
 }
 
+extern "C" int32_t ofb_gemm_h_rn_tiles(const ofb_gemm_h_args* args, int32_t* col_tiles) {
+  if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
+  const bool c96 = h_tile_choice(*args) == 96;
+  const int bm = c96 ? C96::BM : C128::BM, bn = c96 ? C96::BN : C128::BN;
+  const int nt = ofb_cdiv(args->N, bn);
+  if (col_tiles) *col_tiles = nt;
+  return ofb_cdiv(args->M, bm) * nt;
+}
+
 extern "C" int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream) {
   if (!args) return OFB_EINVAL;
   const ofb_gemm_h_args& g = *args;
@@ -1346,6 +1415,7 @@ extern "C" int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream) {
   if ((g.act == OFB_ACT_DGELU || g.act == OFB_ACT_GELU_GRAD || g.act == OFB_ACT_MULAUX) && !g.aux) return OFB_EINVAL;
   if (g.C && g.ldc < g.N) return OFB_EINVAL;
   if (g.Cp && g.c_ncb < (g.N + 15) / 16) return OFB_EINVAL;
+  if (g.rn_out && (!g.rn_gamma || !g.rn_rowfac || !ofb_aligned16(g.rn_gamma))) return OFB_EINVAL;
   if ((g.Cp || g.cbound_out) && g.resid && !g.out_bound) return OFB_ELIMIT;   // no bound for a residual sum without scanning it: the caller supplies one
   if (g.a_ncb < ((g.a_kc ? g.K : g.M) + 15) / 16 || g.b_ncb < ((g.b_kc ? g.K : g.N) + 15) / 16) return OFB_EINVAL;
   if (!ofb_aligned16(g.A) || !ofb_aligned16(g.B) || (g.Cp && !ofb_aligned16(g.Cp))) return OFB_EINVAL;

@@ -119,12 +119,22 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const float* __restrict__ x
 // The bound pass (ln_bwd_stat_kernel) leaves one (amax, rn2sq) pair per block in `stat` - no atomics, no memset node: thousands of
 // blocks folding their maxima into two words serialise in one L2 channel (that was 30 of the pass's 43 us) - and EVERY block of the
 // main kernel reduces the <= 1024 pairs itself (8 KB out of the L2); block 0 publishes the header.
-__device__ __forceinline__ float ln_stat_gather(const float* __restrict__ stat, int nb, float* red8, ofb_hhdr* hdr) {
+// nb < 0: `stat` holds -nb single values handed over by the GEMM that produced dy (gemm_h.hip, E_RN): per output tile the maximum
+// over its rows of rstd |gamma (.) dy, the tile's columns|_2.  A row's norm over ALL columns is at most sqrt(column tiles) times its
+// largest tile part: rn_fac carries that factor, max |rowscale| (scanned here: one value per image) the DropPath factor - the bound
+// pass over dy is not run at all.  (dres is not covered: the caller uses this form only without a separate residual gradient.)
+__device__ __forceinline__ float ln_stat_gather(const float* __restrict__ stat, int nb, float* red8, ofb_hhdr* hdr,
+                                                const float* __restrict__ rowscale, int n_rs, float rn_fac) {
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float am = 0.f, rn = 0.f;
-  for (int i = threadIdx.x; i < nb; i += 256) {
-    const float2 v = reinterpret_cast<const float2*>(stat)[i];
-    am = fmaxf(am, v.x); rn = fmaxf(rn, v.y);
+  if (nb >= 0) {
+    for (int i = threadIdx.x; i < nb; i += 256) {
+      const float2 v = reinterpret_cast<const float2*>(stat)[i];
+      am = fmaxf(am, v.x); rn = fmaxf(rn, v.y);
+    }
+  } else {
+    for (int i = threadIdx.x; i < -nb; i += 256) am = fmaxf(am, stat[i]);
+    if (rowscale) for (int i = threadIdx.x; i < n_rs; i += 256) rn = fmaxf(rn, fabsf(rowscale[i]));     // (rn: scratch for max |rowscale|)
   }
   am = ofb_wave_max_pos(am); rn = ofb_wave_max_pos(rn);
   if (lane == 0) { red8[w] = am; red8[4 + w] = rn; }
@@ -132,6 +142,10 @@ __device__ __forceinline__ float ln_stat_gather(const float* __restrict__ stat, 
   am = fmaxf(fmaxf(red8[0], red8[1]), fmaxf(red8[2], red8[3]));
   rn = fmaxf(fmaxf(red8[4], red8[5]), fmaxf(red8[6], red8[7]));
   __syncthreads();                                          // red8 is the kernels' reduction scratch again from here on
+  if (nb < 0) {
+    am = 1.0004f * rn_fac * (rowscale ? rn : 1.f) * am;
+    rn = 1.0004f * am * am;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0) { hdr->e = ofb_h_exp(am); hdr->amax = am; hdr->rn2sq = rn; hdr->cn2sq = 0.f; }
   return am;
 }
@@ -142,7 +156,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
                                                      const float* __restrict__ rstd, const float* __restrict__ dres,
                                                      float* __restrict__ dx, float* __restrict__ part, int rows, int D,
                                                      char* __restrict__ dxP, const float* __restrict__ rowscale, int rs_div,
-                                                     const float* __restrict__ stat, int stat_nb) {
+                                                     const float* __restrict__ stat, int stat_nb, float rn_fac) {
   __shared__ float red[4 * 2 * 1024];
   constexpr int NS = PF ? 3 : 2;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -155,7 +169,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ d
   for (int k = 0; k < (PF ? 4 : 1); ++k) cacc[k] = 0.f;
   const int Dp = (D + 15) & ~15;
   float hs = 1.f;
-  if (PF) hs = ofb_h_pow2(ofb_h_exp(ln_stat_gather(stat, stat_nb, red, reinterpret_cast<ofb_hhdr*>(dxP))));
+  if (PF) hs = ofb_h_pow2(ofb_h_exp(ln_stat_gather(stat, stat_nb, red, reinterpret_cast<ofb_hhdr*>(dxP), rowscale, (rows + rs_div - 1) / rs_div, rn_fac)));
   for (int row0 = blockIdx.x * 4; row0 < rows; row0 += gridDim.x * 4) {
     const int row = row0 + w;
     float v[LN_MAXE];
@@ -336,14 +350,14 @@ __global__ __launch_bounds__(256) void ln_bwd_p_kernel(const float* __restrict__
                                                        const float* __restrict__ rstd, const float* __restrict__ dres,
                                                        float* __restrict__ dx, float* __restrict__ part, int rows, int D,
                                                        char* __restrict__ dxP, const float* __restrict__ rowscale, int rs_div,
-                                                       const float* __restrict__ stat, int stat_nb) {
+                                                       const float* __restrict__ stat, int stat_nb, float rn_fac) {
   constexpr int NE = 2 * NJ;
   __shared__ float red[4 * 3 * 128 * NJ];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int Dp = (D + 15) & ~15;
   float g[NE], ag[NE], ab[NE], ac[NE];
   ln_p_load<NJ>(g, gamma, D, lane);
-  const float hs = ofb_h_pow2(ofb_h_exp(ln_stat_gather(stat, stat_nb, red, reinterpret_cast<ofb_hhdr*>(dxP))));
+  const float hs = ofb_h_pow2(ofb_h_exp(ln_stat_gather(stat, stat_nb, red, reinterpret_cast<ofb_hhdr*>(dxP), rowscale, (rows + rs_div - 1) / rs_div, rn_fac)));
 #pragma unroll
   for (int i = 0; i < NE; ++i) ag[i] = ab[i] = ac[i] = 0.f;
   for (int rg = blockIdx.x * 4 + w; 4 * rg < rows; rg += gridDim.x * 4) {
@@ -665,13 +679,18 @@ extern "C" int32_t ofb_layernorm_bwd_blocks(int32_t rows) { return rows >= 4096 
 
 namespace {
 int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd, const float* dres, float* dx,
-                  float* partials, int rows, int D, char* dxP, const float* rowscale, int rs_div, hipStream_t s) {
+                  float* partials, int rows, int D, char* dxP, const float* rowscale, int rs_div, hipStream_t s,
+                  const float* rn = nullptr, int n_rn = 0, float rn_fac = 1.f) {
   const dim3 grid(ofb_layernorm_bwd_blocks(rows));
   ofb_prof_pre(3, s, (dxP ? 24.0 : 16.0) * rows * (double)D);
   // per-block maxima of the bound pass: the last 8 KB of the plane buffer (its slack past the matrix: never read as values)
-  float* stat = dxP ? reinterpret_cast<float*>(dxP + ofb_hformat_bytes(rows, D) - 8192) : nullptr;
+  const float* stat = dxP ? reinterpret_cast<float*>(dxP + ofb_hformat_bytes(rows, D) - 8192) : nullptr;
   int nb = 0;
-  if (dxP) {
+  if (dxP && rn) {                                          // the producing GEMM left the bound's ingredients: no pass over dy
+    stat = rn;
+    nb = -n_rn;
+  } else if (dxP) {
+    float* stat = reinterpret_cast<float*>(dxP + ofb_hformat_bytes(rows, D) - 8192);
     const int nj = ofb_cdiv(D, 128);
     if (D % 2 == 0) {
       nb = ofb_cdiv(rows, 16) < 1024 ? ofb_cdiv(rows, 16) : 1024;   // (measured on [25216][384]: 2048 / 1024 / 512 / 256 blocks = 17 / 13 / 17 / 21 us)
@@ -686,15 +705,15 @@ int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const flo
   }
   if (dxP && D % 2 == 0) {
     const int nj = ofb_cdiv(D, 128);
-    if (nj <= 2) hipLaunchKernelGGL(ln_bwd_p_kernel<2>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
-    else if (nj <= 3) hipLaunchKernelGGL(ln_bwd_p_kernel<3>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
-    else if (nj <= 6) hipLaunchKernelGGL(ln_bwd_p_kernel<6>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
-    else hipLaunchKernelGGL(ln_bwd_p_kernel<8>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
+    if (nj <= 2) hipLaunchKernelGGL(ln_bwd_p_kernel<2>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb, rn_fac);
+    else if (nj <= 3) hipLaunchKernelGGL(ln_bwd_p_kernel<3>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb, rn_fac);
+    else if (nj <= 6) hipLaunchKernelGGL(ln_bwd_p_kernel<6>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb, rn_fac);
+    else hipLaunchKernelGGL(ln_bwd_p_kernel<8>, grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb, rn_fac);
   } else if (dxP) {
-    hipLaunchKernelGGL((ln_bwd_kernel<1, true>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
+    hipLaunchKernelGGL((ln_bwd_kernel<1, true>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb, rn_fac);
   } else {
-    if (D % 2 == 0) hipLaunchKernelGGL((ln_bwd_kernel<2, false>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
-    else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb);
+    if (D % 2 == 0) hipLaunchKernelGGL((ln_bwd_kernel<2, false>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb, rn_fac);
+    else hipLaunchKernelGGL((ln_bwd_kernel<1, false>), grid, dim3(256), 0, s, dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, dxP, rowscale, rs_div, stat, nb, rn_fac);
   }
   ofb_prof_post(3, s);
   return ofb_launch_status();
@@ -717,6 +736,19 @@ extern "C" int ofb_layernorm_bwd_h(const float* dy, const float* x, const float*
   if (rowscale && rs_div <= 0) return OFB_EINVAL;
   if (D > 64 * LN_MAXE) return OFB_ELIMIT;
   return ln_bwd_launch(dy, x, gamma, mean, rstd, dres, dx, partials, rows, D, (char*)dx_p, rowscale, rs_div, (hipStream_t)stream);
+}
+
+// The same with the bound of the result taken from rn[n_rn] (ofb_gemm_h's rn_out of the GEMM that produced dy; rn_fac = sqrt of its
+// column tiles) instead of a pass over dy.  dy must be the ONLY gradient of the LayerNorm's output (no dres).
+extern "C" int ofb_layernorm_bwd_h_rn(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                                      float* dx, float* partials, void* dx_p, const float* rowscale, int32_t rs_div, int32_t rows,
+                                      int32_t D, const float* rn, int32_t n_rn, float rn_fac, void* stream) {
+  if (!dy || !x || !gamma || !mean || !rstd || !dx || !partials || !dx_p || !rn || n_rn <= 0 || !(rn_fac >= 1.f) || rows <= 0 || D <= 0)
+    return OFB_EINVAL;
+  if (rowscale && rs_div <= 0) return OFB_EINVAL;
+  if (D > 64 * LN_MAXE) return OFB_ELIMIT;
+  return ln_bwd_launch(dy, x, gamma, mean, rstd, nullptr, dx, partials, rows, D, (char*)dx_p, rowscale, rs_div, (hipStream_t)stream, rn,
+                       n_rn, rn_fac);
 }
 
 extern "C" int32_t ofb_colsum_slabs(int32_t M, int32_t N) {

@@ -21,9 +21,9 @@ ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs', 'ofb_tune',
+    'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs', 'ofb_tune', 'ofb_gemm_h_rn_tiles',
     'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
-    'ofb_layernorm_fwd', 'ofb_layernorm_fwd_h', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_h', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
+    'ofb_layernorm_fwd', 'ofb_layernorm_fwd_h', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_h', 'ofb_layernorm_bwd_h_rn', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_amax', 'ofb_attention_fwd', 'ofb_attention_fwd_h', 'ofb_attention_bwd',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
@@ -128,6 +128,7 @@ class GemmHArgs(C.Structure):
         ('resid', C.c_void_p), ('ldr', C.c_int32), ('aux', C.c_void_p), ('ldaux', C.c_int32), ('act', C.c_int32),
         ('workspace', C.c_void_p), ('workspace_bytes', C.c_int64), ('colpart', C.c_void_p),
         ('aux_bound', C.c_float), ('out_bound', C.c_void_p), ('cbound_out', C.c_void_p),
+        ('rn_gamma', C.c_void_p), ('rn_rowfac', C.c_void_p), ('rn_out', C.c_void_p),
     ]
 
 
@@ -494,8 +495,9 @@ def gated_weight_h(W, gvec, N, K):
 
 def gemm_h(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bias=None, colscale=None, rowscale=None, rs_div=1,
            resid=None, ldr=0, aux=None, ldaux=0, act=ACT_NONE, colsum_out=None, want_colpart=False, aux_bound=0.0, out_bound=None,
-           cbound_out=None):
+           cbound_out=None, rn=None):
     """C[M][N] (f32 and / or H-format) = A * B on H-format operands (HMat); a_kc / b_kc: reduction along the operand's columns.
+    rn = (gamma [N], rowfac [M]): returns (per-tile row-norm maxima, sqrt(column tiles)) for ofb_layernorm_bwd_h_rn (include/ofb_hip.h).
     colsum_out [N]: also receives the column sums of the output (fused per-tile partial sums + one small reduction).
     want_colpart: return the per-tile partial column sums [rows][N] themselves (the consumer adds them up).
     aux_bound: bound of |aux| for the multiplying activations (default 1.13 = max gelu'); out_bound: device scalar that IS the
@@ -517,6 +519,12 @@ def gemm_h(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bia
         rows = int(lib().ofb_gemm_h_colpart_rows(C.byref(g)))
         part = torch.empty(rows, N, device=A.buf.device, dtype=torch.float32)
         g.colpart = ptr(part)
+    rn_out = None
+    if rn is not None:
+        nt = C.c_int32(0)
+        n_rn = int(lib().ofb_gemm_h_rn_tiles(C.byref(g), C.byref(nt)))
+        rn_out = (torch.empty(n_rn, device=A.buf.device, dtype=torch.float32), float(nt.value) ** 0.5)
+        g.rn_gamma, g.rn_rowfac, g.rn_out = ptr(rn[0]), ptr(rn[1]), ptr(rn_out[0])
     lib().ofb_gemm_h_workspace_bytes.restype = C.c_int64
     need = lib().ofb_gemm_h_workspace_bytes(C.byref(g))
     if need > 0:
@@ -527,6 +535,7 @@ def gemm_h(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bia
         return part
     if part is not None:
         colsum(part, N, part.shape[0], N, colsum_out)
+    return rn_out
 
 
 def splitk_reduce(ws, splits, count, out, accumulate=False):
@@ -569,6 +578,13 @@ def layernorm_bwd_h(dy, x, gamma, mean, rstd, dres, dx, partials, dxP, rowscale,
     """LayerNorm backward that also writes dx * rowscale[row // rs_div] as planes `dxP`; partials: [blocks][3][D]."""
     check(lib().ofb_layernorm_bwd_h(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dres), ptr(dx), ptr(partials),
                                     ptr(dxP.buf), ptr(rowscale), _i(rs_div), _i(rows), _i(D), stream()), 'ofb_layernorm_bwd_h')
+
+
+def layernorm_bwd_h_rn(dy, x, gamma, mean, rstd, dx, partials, dxP, rowscale, rs_div, rows, D, rn, rn_fac):
+    """layernorm_bwd_h without its bound pass over dy: `rn` / `rn_fac` come from the GEMM that produced dy (gemm_h(rn=...))."""
+    check(lib().ofb_layernorm_bwd_h_rn(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(partials), ptr(dxP.buf),
+                                       ptr(rowscale), _i(rs_div), _i(rows), _i(D), ptr(rn), _i(rn.numel()), _f(rn_fac), stream()),
+          'ofb_layernorm_bwd_h_rn')
 
 
 def layernorm_bwd_blocks(rows):

@@ -51,13 +51,18 @@ def p_linear_fwd(xP, M, K, WP, b, colscale=None, act=hip.ACT_NONE, aux=None, row
 
 
 def p_linear_bwd_input(dyP, M, N, WP, K, resid=None, act=hip.ACT_NONE, aux=None, want_f32=True, want_p=False, colsum_out=None,
-                       want_colpart=False, cbound_out=None):
+                       want_colpart=False, cbound_out=None, ln=None):
     """dX[M,K] = dY[M,N] @ W[N,K]: dY reduced along its columns (KC), W along its rows (KR): the SAME H-format copy of W as forward.
-    want_colpart: third return value = the per-tile partial column sums of dX [rows][K]"""
+    want_colpart: third return value = the per-tile partial column sums of dX [rows][K]
+    ln = (gamma, rstd) of the LayerNorm whose output x was: the epilogue also leaves what that LayerNorm's backward needs to bound its
+    result (parked under dX's identity for it: _put_rn)"""
     dx = torch.empty(M, K, device=dyP.buf.device, dtype=torch.float32) if want_f32 else None
     dxP = hip.HMat(M, K, dyP.buf.device) if want_p else None
+    use_rn = ln is not None and want_f32 and not want_colpart and colsum_out is None and _RN_HANDOVER
     part = hip.gemm_h(dyP, WP, 1, 0, M, K, N, C_out=dx, ldc=K, Cp=dxP, resid=resid, ldr=K, act=act, aux=aux, ldaux=K, colsum_out=colsum_out,
-                      want_colpart=want_colpart, cbound_out=cbound_out)
+                      want_colpart=want_colpart, cbound_out=cbound_out, rn=ln if use_rn else None)
+    if use_rn and part is not None:
+        _put_rn(dx, part)
     return (dx, dxP, part) if want_colpart else (dx, dxP)
 
 
@@ -126,7 +131,7 @@ class _nullctx:
     def __exit__(self, *a): return False
 
 
-def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None, fold=1):
+def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None, fold=1, ln=None):
     """H-format backward of y = g[n] * (x W^T + b)[n] (or plain Linear when gvec is None): dx (+resid fused), dW, db, dg.
     WP: the forward's H-format copy of W; dy_colsum: callable giving colsum(dY) (the raw bias gradient) as a vector [N] or as
     (partials [rows][N], rows) straight from the producing kernel - the gate-fold kernel adds partial rows up itself."""
@@ -135,13 +140,13 @@ def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None, fold=
     W = W.view(N, K)
     slot = grad_slot(W)
     if gvec is None:
-        dx, _ = p_linear_bwd_input(dyP, M, N, WP, K, resid=resid)
+        dx, _ = p_linear_bwd_input(dyP, M, N, WP, K, resid=resid, ln=ln)
         dW = slot if slot is not None else _new(W, N, K)
         with (hip.side_work(W.device, keep=[dyP.buf, xP.buf]) if side else _nullctx()):
             p_linear_bwd_weight(dyP, xP, M, N, K, out=dW)
         return dx, dW, (_reduced(dy_colsum(), N) if b is not None else None), None
     WeffP = hip.gated_weight_h(W, gvec, N, K)                            # g[n] * W[n][:] as planes (all gated layers in one launch)
-    dx, _ = p_linear_bwd_input(dyP, M, N, WeffP, K, resid=resid)
+    dx, _ = p_linear_bwd_input(dyP, M, N, WeffP, K, resid=resid, ln=ln)
     dbraw, rows = None, 1
     if b is not None:
         dbraw = dy_colsum()
@@ -207,8 +212,28 @@ class Linear(torch.autograd.Function):
 #    DropPath row scales (`_ofb_up`, see attn_branch / mlp_branch); LN's backward kernel then also writes dx * rowscale as planes
 #    and its column sums (the branch's output-bias gradient), parked in _grad_p under the gradient tensor's identity, where the
 #    branch's backward picks them up (_take_grad_p) instead of running ofb_to_hformat_colsum over the gradient.
+#  * backward, the other way round: the branch that consumes LN's output y computes LN's dy (its input gradient, residual add
+#    included) in a GEMM; LN's wrapper tags y with (gamma, rstd) (`_ofb_ln`), the branch hands them to that GEMM, whose epilogue
+#    leaves per-tile row-norm maxima (hip.gemm_h(rn=...)), parked in _rn under the gradient's identity: LN's backward kernel takes
+#    its output exponent from them instead of running a bound pass over dy (0.34 ms per DeiT-S step).  OFB_RN_HANDOVER=0: off.
 _ln_pending = [None]
 _grad_p = {}
+_rn = {}
+_RN_HANDOVER = os.environ.get('OFB_RN_HANDOVER', '1') != '0'
+
+
+def _put_rn(dx, rn):
+    if len(_rn) >= 4:
+        _rn.clear()
+    _rn[dx.data_ptr()] = (dx, dx._version, rn)
+
+
+def _take_rn(dy, rows, D):
+    e = _rn.pop(dy.data_ptr(), None)
+    if e is None:
+        return None
+    dx, ver, rn = e
+    return rn if (dx._version == ver and dx.numel() == rows * D and dy.is_contiguous()) else None
 
 
 def _put_grad_p(dx, dxP, colsum, rowscale):
@@ -241,7 +266,7 @@ class LayerNorm(torch.autograd.Function):
         y, mean, rstd = torch.empty_like(x), _new(x, rows), _new(x, rows)
         yP = hip.HMat.for_rows_written_by_kernel(rows, D, x.device)
         hip.layernorm_fwd_h(x, gamma, beta, y, yP, mean, rstd, rows, D, eps)
-        _ln_pending[0] = yP
+        _ln_pending[0] = (yP, (gamma, rstd) if up is not None else None)
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.fork = fork
         ctx.up = up
@@ -265,8 +290,12 @@ class LayerNorm(torch.autograd.Function):
             rowscale = ctx.up[0]
             part = _new(x, nb, 3 * D)
             dxP = hip.HMat.for_rows_written_by_kernel(rows, D, x.device)
-            hip.layernorm_bwd_h(_c(dy), x, gamma, mean, rstd, _c(dres) if dres is not None else None, dx, part, dxP, rowscale,
-                                _rs_div(rowscale, rows), rows, D)
+            rn = _take_rn(dy, rows, D) if dres is None else None
+            if rn is not None:                             # the GEMM that produced dy left the bound's ingredients (see _rn above)
+                hip.layernorm_bwd_h_rn(dy, x, gamma, mean, rstd, dx, part, dxP, rowscale, _rs_div(rowscale, rows), rows, D, rn[0], rn[1])
+            else:
+                hip.layernorm_bwd_h(_c(dy), x, gamma, mean, rstd, _c(dres) if dres is not None else None, dx, part, dxP, rowscale,
+                                    _rs_div(rowscale, rows), rows, D)
             dgb = _new(x, 3 * D)
             _ln_colsum(part, 3 * D, nb, dgb, ctx)
             _put_grad_p(dx, dxP, dgb[2 * D:], rowscale)
@@ -302,9 +331,12 @@ def _ln_colsum(part, width, nb, dgb, ctx):
 def _ln_apply(x, gamma, beta, eps, fork):
     _ln_pending[0] = None
     out = LayerNorm.apply(x, gamma, beta, eps, fork, getattr(x, '_ofb_up', None))
-    yP, _ln_pending[0] = _ln_pending[0], None
-    if yP is not None:
-        (out[0] if fork else out)._ofb_p = yP
+    pend, _ln_pending[0] = _ln_pending[0], None
+    if pend is not None:
+        y = out[0] if fork else out
+        y._ofb_p = pend[0]
+        if pend[1] is not None:
+            y._ofb_ln = pend[1]
     return out
 
 
@@ -356,6 +388,7 @@ class AttnBranch(torch.autograd.Function):
         r2d = x2d if resid is None else _c(resid).view(M, D)
         xP, wqP, wpP = _P(x, M, D), hip.weight_h(wqkv), hip.weight_h(wproj)
         ctx.wp = (wqP, wpP)
+        ctx.ln = getattr(x, '_ofb_ln', None) if resid is None else None     # (x is the LayerNorm's only consumer then: see _rn)
         qb = _new(x, 1)                                # device-side bound of |qkv| (Cauchy-Schwarz, from the qkv GEMM): the attention
         qkv, _ = p_linear_fwd(xP, M, D, wqP, bqkv, colscale=g3, cbound_out=qb)    # kernels split q, k, v with its exponent
         if g3 is not None:
@@ -400,7 +433,8 @@ class AttnBranch(torch.autograd.Function):
         hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale, qb, dob, dq_amax)
         dqkvP = hip.to_hformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw, bound=dq_amax)
         # fold = 3: the gate-fold kernel adds the q | k | v contributions to the gate gradient itself
-        dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None, fold=3)
+        dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None, fold=3,
+                                                ln=ctx.ln)
         dg = None
         if dg3 is not None:
             dg = dg3.view(heads, dh)
@@ -434,6 +468,7 @@ class MlpBranch(torch.autograd.Function):
         r2d = x2d if resid is None else _c(resid).view(M, D)
         xP, w1P, w2P = _P(x, M, D), hip.weight_h(w1), hip.weight_h(w2)
         ctx.wp = (w1P, w2P)
+        ctx.ln = getattr(x, '_ofb_ln', None) if resid is None else None
         # gelu(g * fc1(x)) leaves the kernel as the H-format operand of fc2 (and of the fc2 weight gradient); beside it only
         # GELU'(pre-activation) is kept in f32 (`hpre` holds the derivative here): the epilogue has Phi and phi in hand, and the
         # backward epilogue becomes a single multiply
@@ -472,7 +507,7 @@ class MlpBranch(torch.autograd.Function):
         dw2 = dw2 if dw2 is not None else _new(d2, D, hid)
         with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2, tokens=M) else _nullctx()):
             p_linear_bwd_weight(d2sP, hP, M, D, hid, out=dw2)
-        dx, dw1, db1, dg = _p_gated_linear_bwd(dhP, lambda: db1_raw, xP, M, w1, w1P, b1, gv, resid=d2 if self_resid else None)
+        dx, dw1, db1, dg = _p_gated_linear_bwd(dhP, lambda: db1_raw, xP, M, w1, w1P, b1, gv, resid=d2 if self_resid else None, ln=ctx.ln)
         dres = None if self_resid else dout
         return dx.view(B, N, D), dres, dw1, db1, dw2, db2, (None if dg is None else dg.view(1, -1)), None
 

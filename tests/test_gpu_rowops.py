@@ -134,3 +134,57 @@ def test_gate_fold(N, K):
         _close(dW3, dWraw.double() * g3.double().unsqueeze(1), 1e-6, 'fold dW (tiled gate)')
         _close(db3, dbraw.double() * g3.double(), 1e-6, 'fold db (tiled gate)')
         _close(dg3, full.view(3, N // 3).sum(0), 1e-5, 'fold dg summed over q | k | v')
+
+
+@pytest.mark.parametrize('M,N,K,with_resid', [(1970, 384, 200, True), (788, 264, 72, False), (2100, 768, 96, True), (300, 100, 40, True)])
+def test_gemm_row_norm_handover_to_layernorm_backward(M, N, K, with_resid):
+    """the input-gradient GEMM's epilogue leaves, per output tile, max_rows rstd |gamma (.) dy, the tile's columns|_2 (ofb_gemm_h
+    rn_out); ofb_layernorm_bwd_h_rn bounds its result with sqrt(column tiles) x their maximum instead of a pass over dy: the values
+    against torch, the resulting bound >= the exact one and within sqrt(column tiles) x 1.01 of it, the planes and dx as the plain path's"""
+    from ofb_amd import hip
+    g = torch.Generator().manual_seed(3)
+    dyq = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(K, N, generator=g) * 0.1).cuda()
+    resid = torch.randn(M, N, generator=g).cuda() if with_resid else None
+    gamma = (1.0 + 0.3 * torch.randn(N, generator=g)).cuda()
+    x = torch.randn(M, N, generator=g).cuda()
+    mean, var = x.mean(1), x.var(1, unbiased=False)
+    rstd = (var + 1e-6).rsqrt()
+    dyP, wP = hip.to_hformat(dyq), hip.to_hformat(w)
+    dy = torch.empty(M, N, device='cuda')
+    rn = hip.gemm_h(dyP, wP, 1, 0, M, N, K, C_out=dy, ldc=N, resid=resid, ldr=N, rn=(gamma, rstd))
+    vals, fac = rn
+    ref = dyq.double() @ w.double() + (resid.double() if with_resid else 0)
+    assert float((dy.double() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
+    # per-tile reference: the tile geometry follows the value count (128 x 192 or 256 x 96 tiles)
+    nt = int(round(fac * fac))
+    bn = 192 if nt == (N + 191) // 192 else 96
+    bm = 128 if bn == 192 else 256
+    assert vals.numel() == ((M + bm - 1) // bm) * nt
+    t = (gamma.double() * ref) ** 2
+    exp = torch.zeros(vals.numel(), dtype=torch.float64)
+    for mi in range((M + bm - 1) // bm):
+        for ni in range(nt):
+            part = t[mi * bm:(mi + 1) * bm, ni * bn:(ni + 1) * bn].sum(1).sqrt() * rstd.double()[mi * bm:(mi + 1) * bm]
+            exp[mi * nt + ni] = float(part.max())
+    assert float((vals.double().cpu() - exp).abs().max()) < 1e-5 * float(exp.max()), (vals[:4], exp[:4])
+    # LayerNorm backward with the hand-over against the plain plane-writing backward
+    rowscale = (torch.rand(10, generator=g) + 0.5).cuda()
+    rs_div = (M + 9) // 10
+    nb = hip.layernorm_bwd_blocks(M)
+    outs = []
+    for use_rn in (False, True):
+        dx, part, dxP = torch.empty(M, N, device='cuda'), torch.empty(nb, 3 * N, device='cuda'), hip.HMat.for_rows_written_by_kernel(M, N, 'cuda')
+        if use_rn:
+            hip.layernorm_bwd_h_rn(dy, x, gamma, mean, rstd, dx, part, dxP, rowscale, rs_div, M, N, vals, fac)
+        else:
+            hip.layernorm_bwd_h(dy, x, gamma, mean, rstd, None, dx, part, dxP, rowscale, rs_div, M, N)
+        outs.append((dx, part, dxP))
+    (dx0, part0, p0), (dx1, part1, p1) = outs
+    assert torch.equal(dx0, dx1) and torch.allclose(part0, part1, rtol=1e-6, atol=1e-6)
+    b0, b1 = p0.header()[1], p1.header()[1]
+    scaled = dx0 * rowscale[torch.arange(M, device='cuda') // rs_div].unsqueeze(1)
+    true_max = float(scaled.abs().max())
+    assert b1 >= true_max and b1 >= 0.99 * b0 and b1 <= fac * 1.01 * float(rowscale.abs().max()) / float(rowscale.abs().min()) * b0 + 1e-30, (b0, b1, true_max)
+    err = (p1.to_f32() - scaled).abs()
+    assert bool((err <= 2.0 ** -23 * scaled.abs() + 2.0 ** -39 * b1).all())
