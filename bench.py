@@ -223,15 +223,18 @@ def report_exchange(reducer, rank, world, dev, seconds, steps):
     if reducer is None or not dist.is_initialized():
         return
     n = max(reducer.finalized, 1)
-    mine = torch.tensor([rank, len(reducer.buckets), reducer.collectives / n, reducer.wait_seconds / n * 1e3, seconds / max(steps, 1) * 1e3],
-                        dtype=torch.float64, device=dev if dev is not None else 'cpu')
+    serial = reducer.measure_collectives()                   # (after the timed region: every bucket's all-reduce alone, back to back)
+    mine = torch.tensor([rank, len(reducer.buckets), reducer.collectives / n, reducer.wait_seconds / n * 1e3, seconds / max(steps, 1) * 1e3,
+                         serial], dtype=torch.float64, device=dev if dev is not None else 'cpu')
     rows = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(rows, mine)
     if rank == 0:
+        print(f'[exchange] buckets in launch order (MB): {reducer.bucket_sizes_mb()}', file=sys.stderr, flush=True)
         for r in rows:
             r = r.tolist()
+            hid = f', {100.0 * (1.0 - r[3] / r[5]):.0f} % of it hidden under backward' if r[5] > 0 else ''
             print(f'[exchange] rank {int(r[0])}: {int(r[1])} buckets, {r[2]:.1f} collectives/step, exposed wait {r[3]:.3f} ms/step of '
-                  f'{r[4]:.3f} ms/step', file=sys.stderr, flush=True)
+                  f'{r[4]:.3f} ms/step; the collectives alone, serial: {r[5]:.3f} ms/step{hid}', file=sys.stderr, flush=True)
 
 
 def rehearsal(args, rank, world, real_stdout):

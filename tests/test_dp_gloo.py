@@ -1,5 +1,7 @@
 """world_size-2 gloo test of the data-parallel gradient exchange (runs on CPU; on MI355X the same code uses RCCL)."""
 import os
+
+import pytest
 import socket
 
 import torch
@@ -191,24 +193,26 @@ def test_epoch_statistics_are_averaged_over_ranks_world2():
         assert dict(out) == {0: 1, 1: 1}
 
 
-def test_bench_self_launch_four_ranks():
-    """the self-launch path with FOUR ranks (gloo rehearsal): rendezvous, broadcast, bucketed exchange, the fused statistics
-    collective and the per-rank exchange report"""
+@pytest.mark.parametrize('n', [4, 8])
+def test_bench_self_launch_four_and_eight_ranks(n):
+    """the self-launch path with FOUR and with EIGHT ranks (gloo rehearsal of the driver's N = 4 / 8 launches): rendezvous, broadcast,
+    bucketed exchange, the fused statistics collective and the per-rank exchange report (bucket sizes, exposed wait, serial cost)"""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
     env['OFB_BENCH_REHEARSAL'] = 'gloo'
-    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1'], env=env,
-                       capture_output=True, text=True, timeout=300)
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', str(n), '--steps', '2', '--warmup', '1'], env=env,
+                       capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, r.stdout
     res = json.loads(lines[0])
-    assert res['n_gpus'] == 4 and res['config']['collective']['ranks'] == 4 and res['config']['exchange_ok'] is True
+    assert res['n_gpus'] == n and res['config']['collective']['ranks'] == n and res['config']['exchange_ok'] is True
     rep = [l for l in r.stderr.splitlines() if l.startswith('[exchange] rank')]
-    assert len(rep) == 4 and all('exposed wait' in l for l in rep), r.stderr[-1500:]
+    assert len(rep) == n and all('exposed wait' in l and 'serial' in l for l in rep), r.stderr[-1500:]
+    assert any(l.startswith('[exchange] buckets in launch order') for l in r.stderr.splitlines())
 
 
 def test_bench_self_launch_two_ranks():

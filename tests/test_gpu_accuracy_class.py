@@ -237,3 +237,37 @@ def test_attention_backward_is_fp32_class(kind):
         print(f'attention bwd {kind} {name}: rms error kernel {rk:.2e}  fp32 cpu {rf:.2e}  16-bit operands {r16:.2e}')
         assert r16 > 16 * rf, 'the criterion must be able to see a reduced-precision engine'
         assert rk <= 4 * rf, f'attention backward {name} RMS error is not fp32-class'
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# ONE exponent per tensor: what a ROW far below the tensor's maximum keeps.  Row r of A is scaled by 2^-s_r,
+# s_r = 0 .. 34: its elements sit s_r binades under the bound, so they keep min(23, 39 - s_r - headroom) significant bits (hformat.h)
+# and the row of the product - which an f32 engine delivers at 2^-24 whatever its scale - carries a RELATIVE error of about
+# 2^(s_r - 39) / (typical / max ratio).  The test measures the per-row relative error against fp64 and asserts the envelope that
+# DESIGN section 3 states: fp32-class up to a spread of 2^12, inside north_star's 1e-3 up to 2^26, for the three storage forms.
+# ------------------------------------------------------------------------------------------------------------------
+ROW_SPREADS = list(range(0, 36, 2))
+
+
+@pytest.mark.parametrize('form', FORMS)
+def test_row_spread_envelope_of_the_per_tensor_exponent(form):
+    M, N, K = 16 * len(ROW_SPREADS), 192, 384
+    g = torch.Generator().manual_seed(7)
+    a = torch.randn(M, K, generator=g)
+    s = torch.tensor(ROW_SPREADS).repeat_interleave(16).float()
+    a = a * torch.pow(torch.tensor(2.0), -s).unsqueeze(1)
+    b_t = torch.randn(N, K, generator=g)
+    exact = a.double() @ b_t.double().t()
+    got = _run(form, a, b_t).double()
+    rel = (got - exact).norm(dim=1) / exact.norm(dim=1)
+    chain = (fma_chain_reference(a, b_t).double() - exact).norm(dim=1) / exact.norm(dim=1)
+    curve = {sp: float(rel[s == sp].max()) for sp in ROW_SPREADS}
+    print(f'{form}: per-row relative error by spread (log2): ' + ' '.join(f'{sp}:{torch.log2(torch.tensor(curve[sp])).item():.1f}' for sp in ROW_SPREADS))
+    print(f'     k-ordered f32 chain, worst row: 2^{torch.log2(chain.max()).item():.1f}')
+    for sp in ROW_SPREADS:
+        if sp <= 12:
+            assert curve[sp] <= 2.0 * float(chain.max()), (form, sp, curve[sp])              # fp32-class: as good as an f32 chain
+        if sp <= 26:
+            assert curve[sp] <= 1e-3, (form, sp, curve[sp])                                 # north_star's tolerance
+        # the format's model: absolute 2^-39 of the bound per element (+ the f32 floor); a K-term row sum of independent errors
+        assert curve[sp] <= 2.0 ** (sp - 39 + 4) + 3.0 * float(chain.max()), (form, sp, curve[sp])
