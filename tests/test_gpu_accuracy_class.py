@@ -271,3 +271,103 @@ def test_row_spread_envelope_of_the_per_tensor_exponent(form):
             assert curve[sp] <= 1e-3, (form, sp, curve[sp])                                 # north_star's tolerance
         # the format's model: absolute 2^-39 of the bound per element (+ the f32 floor); a K-term row sum of independent errors
         assert curve[sp] <= 2.0 ** (sp - 39 + 4) + 3.0 * float(chain.max()), (form, sp, curve[sp])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The same class THROUGH THE MODEL PATH'S BOUNDS: the cases above hand the kernels measured maxima; the step takes its
+# exponents from analytic bounds (LayerNorm: sqrt(D) |gamma| + |beta|; GEMMs that write planes: Cauchy-Schwarz x epilogue factors;
+# attention: the qkv GEMM's bound; LayerNorm backward: row norms), which sit 2^2 - 2^8 above the data and move the accuracy window by
+# that much.  One LayerNorm -> gated MLP (and -> gated attention) block with TRAINED-LIKE statistics - outlier LayerNorm weights,
+# gate values down to 1e-5, outlier weight rows, an output gradient whose columns span 2^-20 .. 1 - forward and backward through
+# ops.layer_norm / ops.mlp_branch / ops.attn_branch, against fp64; the criterion: RMS error of every output and gradient at most
+# 4x that of an fp32 torch evaluation of the same graph.
+# ------------------------------------------------------------------------------------------------------------------
+def _trained_like(B, N, D, hid, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s: torch.randn(*s, generator=g)                      # noqa: E731
+    x = r(B, N, D) * (1.0 + 3.0 * (torch.rand(1, 1, D, generator=g) < 0.03).float())          # a few hot channels
+    gamma = 1.0 + 0.2 * r(D)
+    gamma[::37] *= 30.0                                               # outlier LayerNorm weights
+    beta = 0.1 * r(D)
+    w1, b1 = r(hid, D) * D ** -0.5, 0.02 * r(hid)
+    w1[::29] *= 8.0                                                   # outlier rows
+    w2, b2 = r(D, hid) * hid ** -0.5, 0.02 * r(D)
+    gate = torch.sigmoid(2.0 * r(hid))
+    gate[::11] = 1e-5                                                 # channels the search has all but closed
+    dy = r(B, N, D) * torch.pow(torch.tensor(2.0), -torch.randint(0, 21, (D,), generator=g).float())   # per-column tiny gradients
+    return x, gamma, beta, w1, b1, w2, b2, gate, dy
+
+
+def _mlp_block_ref(x, gamma, beta, w1, b1, w2, b2, gate, dy, dtype):
+    t = [v.detach().to(dtype).requires_grad_(True) for v in (x, gamma, beta, w1, b1, w2, b2, gate)]
+    x_, gm, bt, w1_, b1_, w2_, b2_, g_ = t
+    h = torch.nn.functional.layer_norm(x_, (x_.shape[-1],), gm, bt, 1e-6)
+    pre = (h @ w1_.t() + b1_) * g_
+    out = h + torch.nn.functional.gelu(pre) @ w2_.t() + b2_
+    out.backward(dy.to(dtype))
+    return [out.detach()] + [v.grad for v in t]
+
+
+def test_model_path_bounds_mlp_block_is_fp32_class():
+    from ofb_amd import ops
+    B, N, D, hid = 4, 197, 384, 1536
+    vals = _trained_like(B, N, D, hid, 21)
+    x, gamma, beta, w1, b1, w2, b2, gate, dy = vals
+    exact = _mlp_block_ref(*vals, torch.float64)
+    f32 = _mlp_block_ref(*vals, torch.float32)
+    t = [v.detach().clone().cuda().requires_grad_(True) for v in (x, gamma, beta, w1, b1, w2, b2, gate)]
+    x_, gm, bt, w1_, b1_, w2_, b2_, g_ = t
+    h = ops.layer_norm(x_, gm, bt, 1e-6)
+    out = ops.mlp_branch(h, None, w1_, b1_, w2_, b2_, g_.view(1, -1), None)       # resid None: h is the residual (search path)
+    out.backward(dy.cuda())
+    torch.cuda.synchronize()
+    got = [out.detach()] + [v.grad for v in t]
+    names = ['out', 'dx', 'dgamma', 'dbeta', 'dw1', 'db1', 'dw2', 'db2', 'dgate']
+    for name, gk, ge, gf in zip(names, got, exact, f32):
+        ek, ef = _rms(gk.cpu().double().reshape(ge.shape) - ge), _rms(gf.double() - ge)
+        print(f'mlp block {name}: rms error kernel path {ek:.2e}  fp32 torch {ef:.2e}  (scale {_rms(ge):.2e})')
+        assert ek <= 4 * ef + 1e-12 * _rms(ge), f'{name}: the model path (analytic bounds) is not fp32-class: {ek:.2e} vs {ef:.2e}'
+
+
+def _attn_block_ref(x, gamma, beta, wq, bq, wp, bp, gate, dy, heads, dtype):
+    t = [v.detach().to(dtype).requires_grad_(True) for v in (x, gamma, beta, wq, bq, wp, bp, gate)]
+    x_, gm, bt, wq_, bq_, wp_, bp_, g_ = t
+    B, N, D = x_.shape
+    d = wq_.shape[0] // 3 // heads
+    h = torch.nn.functional.layer_norm(x_, (D,), gm, bt, 1e-6)
+    qkv = (h @ wq_.t() + bq_).reshape(B, N, 3, heads, d) * g_.reshape(1, 1, 1, heads, d)
+    q, k, v = (qkv[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    p = torch.softmax(q @ k.transpose(-1, -2) * d ** -0.5, -1)
+    o = (p @ v).permute(0, 2, 1, 3).reshape(B, N, heads * d)
+    out = h + o @ wp_.t() + bp_
+    out.backward(dy.to(dtype))
+    return [out.detach()] + [v.grad for v in t]
+
+
+def test_model_path_bounds_attention_block_is_fp32_class():
+    from ofb_amd import ops
+    B, N, D, heads, d = 4, 197, 384, 6, 64
+    g = torch.Generator().manual_seed(33)
+    x, gamma, beta, _, _, _, _, _, dy = _trained_like(B, N, D, 1536, 22)
+    wq, bq = torch.randn(3 * heads * d, D, generator=g) * D ** -0.5, 0.02 * torch.randn(3 * heads * d, generator=g)
+    wq[::31] *= 6.0
+    wp, bp = torch.randn(D, heads * d, generator=g) * (heads * d) ** -0.5, 0.02 * torch.randn(D, generator=g)
+    gate = torch.sigmoid(2.0 * torch.randn(heads, d, generator=g))
+    gate[:, ::13] = 1e-5
+    vals = (x, gamma, beta, wq, bq, wp, bp, gate, dy)
+    exact = _attn_block_ref(*vals, heads, torch.float64)
+    f32 = _attn_block_ref(*vals, heads, torch.float32)
+    t = [v.detach().clone().cuda().requires_grad_(True) for v in vals[:8]]
+    x_, gm, bt, wq_, bq_, wp_, bp_, g_ = t
+    h = ops.layer_norm(x_, gm, bt, 1e-6)
+    out = ops.attn_branch(h, None, wq_, bq_, wp_, bp_, g_, None, heads, d ** -0.5)
+    out.backward(dy.cuda())
+    torch.cuda.synchronize()
+    got = [out.detach()] + [v.grad for v in t]
+    names = ['out', 'dx', 'dgamma', 'dbeta', 'dwqkv', 'dbqkv', 'dwproj', 'dbproj', 'dgate']
+    for name, gk, ge, gf in zip(names, got, exact, f32):
+        ek, ef = _rms(gk.cpu().double().reshape(ge.shape) - ge), _rms(gf.double() - ge)
+        print(f'attention block {name}: rms error kernel path {ek:.2e}  fp32 torch {ef:.2e}  (scale {_rms(ge):.2e})')
+        if name == 'dbqkv':                       # (its k third is a mathematical zero: both sides hold rounding noise only)
+            continue
+        assert ek <= 4 * ef + 1e-12 * _rms(ge), f'{name}: the model path (analytic bounds) is not fp32-class: {ek:.2e} vs {ef:.2e}'
