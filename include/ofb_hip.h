@@ -101,7 +101,7 @@ typedef struct ofb_gemm_h_args {
   const float* rn_rowfac;
   float* rn_out;
 } ofb_gemm_h_args;
-int32_t ofb_gemm_h_rn_tiles(const ofb_gemm_h_args* args, int32_t* col_tiles);   /* entries of rn_out; *col_tiles = tiles along N */
+int32_t ofb_gemm_h_rn_tiles(const ofb_gemm_h_args* args, int32_t* col_tiles);   /* entries of rn_out (0: this shape should not ask for it); *col_tiles = tiles along N */
 int32_t ofb_gemm_h_colpart_rows(const ofb_gemm_h_args* args);
 int64_t ofb_hformat_bytes(int32_t R, int32_t C);
 /* bound (optional device scalar >= max |X * rowscale|): skips the statistics pass that otherwise measures amax / row norms first */
@@ -121,7 +121,8 @@ int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream);
  * Unset keys take the environment variable named below, read once, else the default.  Not thread-safe against running calls. */
 #define OFB_TUNE_GEMM_MFMA 0   /* OFB_GEMM_H_MFMA: 16 (default) = v_mfma_f32_16x16x32_f16, 32 = v_mfma_f32_32x32x16_f16 on the 128 x 192 tile */
 #define OFB_TUNE_GEMM_SCHED 1  /* reserved */
-#define OFB_TUNE_GEMM_TILE 2   /* reserved */
+#define OFB_TUNE_GEMM_TILE 2   /* OFB_GEMM_H_TILE: 0 (default) = the 128 x 192 tile everywhere, 96 = the 256 x 96 tile wherever it is legal, 97 = by the
+                                  padded-columns model of rounds 3-4, 128 = forced */
 #define OFB_TUNE_RESERVED3 3
 #define OFB_TUNE_COUNT 4
 int ofb_tune(int32_t key, int32_t value);

@@ -1182,8 +1182,9 @@ int h_switch(int key, const char* env, int dflt) {
 }
 
 int h_tile_choice(const ofb_gemm_h_args& g) {
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("OFB_GEMM_H_TILE"); forced = e ? atoi(e) : 0; }
+  static int env_forced = -1;
+  if (env_forced < 0) { const char* e = getenv("OFB_GEMM_H_TILE"); env_forced = e ? atoi(e) : 0; }
+  const int forced = h_tune[OFB_TUNE_GEMM_TILE] > 0 ? h_tune[OFB_TUNE_GEMM_TILE] : env_forced;      // ofb_tune overrides the environment
   if (forced == 128) return 128;
 #ifdef OFB_GEMM_H_LAB
   if (h_tune[OFB_TUNE_GEMM_TILE] == 1281 || h_tune[OFB_TUNE_GEMM_TILE] == 1283) return h_tune[OFB_TUNE_GEMM_TILE];
@@ -1192,7 +1193,11 @@ int h_tile_choice(const ofb_gemm_h_args& g) {
   if (g.a_kc && !g.colpart && !g.rn_out && g.M >= 4 * C96::BM) {
     const int c192 = ofb_cdiv(g.N, 192) * 192, c96 = ofb_cdiv(g.N, 96) * 96;
     if (forced == 96) return 96;
-    if (c96 < c192) {
+    // Round 5: with the 128 x 192 tile on 16x16x32 (two K32 stages) the 256 x 96 tile (32x32x16, three K16 stages: a 16x16x32 form
+    // does not fit two workgroups' LDS) no longer pays for the widths it was built for - forced onto 128 x 192 the pruned search
+    // step runs 10.1-11.2 k images/s against 9.99 k, the finetune subnet 13.15 k against 13.05 k (same box,
+    // profiles/r05_tile_choice_pruned_finetune.txt).  OFB_GEMM_H_TILE=97 restores the padded-columns model of rounds 3-4.
+    if (forced == 97 && c96 < c192) {
       const double rounds = (double)ofb_cdiv(g.M, C96::BM) * (c96 / 96) / (double)(h_cu_count() * C96::WGS);
       const double frac = rounds - (double)(long long)rounds;
       if (!(frac > 0.0 && frac < 0.3 && g.K < 384)) return 96;
@@ -1397,7 +1402,13 @@ extern "C" int32_t ofb_gemm_h_colpart_rows(const ofb_gemm_h_args* args) {
 
 extern "C" int32_t ofb_gemm_h_rn_tiles(const ofb_gemm_h_args* args, int32_t* col_tiles) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
-  const bool c96 = h_tile_choice(*args) == 96;
+  ofb_gemm_h_args g = *args;
+  // 0 = "do not ask for rn_out here": the product would take the 256 x 96 tile (a width that pads badly on 192 columns), which has no
+  // room for the row-norm parts; forcing it onto 128 x 192 tiles costs more than the LayerNorm bound pass it would save
+  g.rn_out = nullptr;
+  if (h_tile_choice(g) == 96) return 0;
+  g.rn_out = reinterpret_cast<float*>(16);                  // the geometry of the launch that WILL carry rn_out
+  const bool c96 = h_tile_choice(g) == 96;
   const int bm = c96 ? C96::BM : C128::BM, bn = c96 ? C96::BN : C128::BN;
   const int nt = ofb_cdiv(args->N, bn);
   if (col_tiles) *col_tiles = nt;

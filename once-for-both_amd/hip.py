@@ -523,8 +523,9 @@ def gemm_h(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bia
     if rn is not None:
         nt = C.c_int32(0)
         n_rn = int(lib().ofb_gemm_h_rn_tiles(C.byref(g), C.byref(nt)))
-        rn_out = (torch.empty(n_rn, device=A.buf.device, dtype=torch.float32), float(nt.value) ** 0.5)
-        g.rn_gamma, g.rn_rowfac, g.rn_out = ptr(rn[0]), ptr(rn[1]), ptr(rn_out[0])
+        if n_rn > 0:                                         # (0: a shape for the 96-column tile, which has no row-norm form)
+            rn_out = (torch.empty(n_rn, device=A.buf.device, dtype=torch.float32), float(nt.value) ** 0.5)
+            g.rn_gamma, g.rn_rowfac, g.rn_out = ptr(rn[0]), ptr(rn[1]), ptr(rn_out[0])
     lib().ofb_gemm_h_workspace_bytes.restype = C.c_int64
     need = lib().ofb_gemm_h_workspace_bytes(C.byref(g))
     if need > 0:

@@ -82,9 +82,20 @@ SHAPES = [(256, 256, 64), (394, 384, 384), (591, 1152, 384), (130, 70, 36), (128
           (1027, 576, 264), (1500, 960, 264)]
 
 
-@pytest.mark.parametrize('M,N,K', SHAPES)
-def test_gemm_h_modes_and_outputs(M, N, K):
+@pytest.fixture(params=[0, 96], ids=['tile128', 'tile96'])
+def tile_choice(request):
+    """every shape on the default tile and, where it is legal (token-row forms, M >= 1024), on the 256 x 96 tile (32x32x16, K16 stages)"""
     from ofb_amd import hip
+    hip.tune(hip.TUNE_GEMM_TILE, request.param)
+    yield request.param
+    hip.tune(hip.TUNE_GEMM_TILE, 0)
+
+
+@pytest.mark.parametrize('M,N,K', SHAPES)
+def test_gemm_h_modes_and_outputs(M, N, K, tile_choice):
+    from ofb_amd import hip
+    if tile_choice == 96 and M < 1024:
+        pytest.skip('the 256 x 96 tile needs M >= 1024')
     a, b = _mk((M, K), 3), _mk((N, K), 4)                       # logical A[M][K], B[N][K]
     exact = a.double() @ b.double().t()
     ad, bd = a.cuda(), b.cuda()
@@ -111,8 +122,10 @@ def test_gemm_h_modes_and_outputs(M, N, K):
 
 
 @pytest.mark.parametrize('M,N,K', [(394, 384, 384), (300, 1536, 384), (130, 70, 36), (1200, 264, 72), (1400, 480, 264), (2100, 672, 100)])
-def test_gemm_h_epilogues(M, N, K):
+def test_gemm_h_epilogues(M, N, K, tile_choice):
     from ofb_amd import hip
+    if tile_choice == 96 and M < 1024:
+        pytest.skip('the 256 x 96 tile needs M >= 1024')
     x, w, b = _mk((M, K), 5), _mk((N, K), 6, 0.1), _mk((N,), 7)
     cs, res = _mk((N,), 8), _mk((M, N), 9)
     rs = _mk(((M + 196) // 197,), 10)

@@ -136,7 +136,8 @@ def test_gate_fold(N, K):
         _close(dg3, full.view(3, N // 3).sum(0), 1e-5, 'fold dg summed over q | k | v')
 
 
-@pytest.mark.parametrize('M,N,K,with_resid', [(1970, 384, 200, True), (788, 264, 72, False), (2100, 768, 96, True), (300, 100, 40, True)])
+@pytest.mark.parametrize('M,N,K,with_resid', [(1970, 384, 200, True), (788, 264, 72, False), (2100, 768, 96, True), (300, 100, 40, True),
+                                                (2100, 264, 96, True), (1300, 480, 72, False)])   # (widths the 96-column tile would take without rn)
 def test_gemm_row_norm_handover_to_layernorm_backward(M, N, K, with_resid):
     """the input-gradient GEMM's epilogue leaves, per output tile, max_rows rstd |gamma (.) dy, the tile's columns|_2 (ofb_gemm_h
     rn_out); ofb_layernorm_bwd_h_rn bounds its result with sqrt(column tiles) x their maximum instead of a pass over dy: the values
@@ -153,6 +154,9 @@ def test_gemm_row_norm_handover_to_layernorm_backward(M, N, K, with_resid):
     dyP, wP = hip.to_hformat(dyq), hip.to_hformat(w)
     dy = torch.empty(M, N, device='cuda')
     rn = hip.gemm_h(dyP, wP, 1, 0, M, N, K, C_out=dy, ldc=N, resid=resid, ldr=N, rn=(gamma, rstd))
+    if rn is None:                                           # a shape the library runs on its 256 x 96 tile: the hand-over steps aside
+        assert M >= 1024 and (N + 95) // 96 * 96 < (N + 191) // 192 * 192
+        return
     vals, fac = rn
     ref = dyq.double() @ w.double() + (resid.double() if with_resid else 0)
     assert float((dy.double() - ref).abs().max()) < 3e-6 * float(ref.abs().max())
