@@ -510,7 +510,7 @@ def main():
                                            ranks=dist.get_world_size() if dist.is_initialized() else 1,
                                            buckets=len(reducer.buckets) if reducer is not None else 0), init_steps=INIT_STEPS,
                            hip_graph=bool(use_graph),
-                           step_tflops_per_gpu=round(step_tflops, 2), step_frac_of_f32_mfma_peak=round(step_tflops / PEAK_F32_MFMA_TFLOPS, 4),
+                           step_tflops_per_gpu=round(step_tflops, 2), step_frac_of_3term_f16_ceiling=round(step_tflops / (2500.0 / 3.0), 4),
                            gflop_per_image=gflop_img, baseline_gflop_per_image=BASELINE_GFLOP_PER_IMG[args.model]),
                roofline=roof)
     if ft_info:
