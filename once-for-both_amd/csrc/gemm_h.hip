@@ -627,7 +627,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
 
   const int v = ofb_xcd_remap(blockIdx.x, p.W);     // consecutive v share an XCD (and thus operand panels in its L2)
   int sidx = 0;
-  Seg cur = get_seg<TAIL>(p, v, 0);
+  Seg cur = get_seg<TAIL>(p, v, 0, (int)blockIdx.x);
   if (!cur.ok) return;
 #ifdef OFB_H_STAMPS
   if (t == 0 && blockIdx.x < 1024) {
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
       }
     }
     OFB_HSTAMP(3);
-    const Seg nxt = get_seg<TAIL>(p, v, ++sidx);
+    const Seg nxt = get_seg<TAIL>(p, v, ++sidx, (int)blockIdx.x);
     if (!nxt.ok) break;
     cur = nxt;
   }
@@ -1223,6 +1223,13 @@ Plan plan_h(const ofb_gemm_h_args& g) {
   if (p.R > 0 && g.colpart && p.R % p.nt != 0) {                     // column sums of tail tiles come from the fix-up kernel, which
     p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;         // addresses them per whole tile row
   }
+  // A remainder of at most half a round behind >= 2 full rounds runs as one more, partial round on the FIRST-dispatched workgroup of
+  // every CU (get_seg's spread form): those run their units ~1.4x faster than the later-dispatched ones, so full_rounds + 1 of
+  // their units end about when the others' full_rounds do - the remainder costs (almost) no time, no partial tiles, no fix-up launch
+  const bool spread_on = h_switch(OFB_TUNE_GEMM_SCHED, "OFB_GEMM_H_SPREAD", 1) != 0;
+  if (spread_on && p.R > 0 && p.full_rounds >= 2 && 2 * p.R <= W && (g.a_kc || g.b_kc)) {
+    p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;
+  }
   if (p.R > 0) {
     // costs in K16 steps of one workgroup: a streamed tail = its K steps + the partial tiles' round trip through HBM + the extra
     // launches, against one more (partly idle) data-parallel round of I steps
@@ -1254,7 +1261,9 @@ Plan plan_h(const ofb_gemm_h_args& g) {
   if (fold < 0) { const char* e = getenv("OFB_GEMM_H_BOUND_FOLD"); fold = e ? atoi(e) : 1; }
   const long long side = (g.out_bound ? 0 : (long long)(g.bias ? g.N : 0) + (g.colscale ? g.N : 0) + (g.rowscale ? (g.M + g.rs_div - 1) / g.rs_div : 0));
   const bool fold_ok = fold && (g.Cp || g.cbound_out) && p.full_rounds > 0 && side <= 8192;
-  p.stagger = (wide_ok ? 1 : 0) | (fold_ok ? 2 : 0);
+  // bit 3: the partial last round of a multi-round launch is spread over the XCDs by the raw block index (gemm_plan.h: get_seg)
+  const bool spread = spread_on && p.full_rounds >= 2 && p.R == 0 && p.ntiles < p.full_rounds * p.W;
+  p.stagger = (wide_ok ? 1 : 0) | (fold_ok ? 2 : 0) | (spread ? 8 : 0);
   return p;
 }
 

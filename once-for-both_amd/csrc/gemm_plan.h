@@ -41,13 +41,19 @@ __host__ __device__ __forceinline__ void tile_coord(const Plan& p, int tile, int
 // slot >= 0 -> raw partial tile to workspace[slot].
 struct Seg { int m0, n0, it0, it1, slot; bool ok; };
 
+// raw: the workgroup's own blockIdx.x (v is its XCD-contiguous remap).  Full rounds hand tile v + idx W to workgroup v: neighbours on
+// an XCD share operand panels in its L2.  A PARTIAL last round of a multi-round launch (plan.stagger bit 3) goes by the raw index
+// instead: its tiles then fall round-robin over ALL XCDs - the contiguous form piled them on the first XCDs, whose CUs ran one round
+// more on both of their workgroups while the others idled - and on the first-dispatched workgroup of every CU, the one that runs
+// its units ~1.4x faster than its later-dispatched neighbour
 template <bool TAIL>
-__device__ __forceinline__ Seg get_seg(const Plan p, int v, int idx) {
+__device__ __forceinline__ Seg get_seg(const Plan p, int v, int idx, int raw = -1) {
   Seg s;
   s.m0 = s.n0 = s.it0 = s.it1 = 0; s.slot = -1; s.ok = false;
   if (!TAIL) {
     if (idx >= p.full_rounds) return s;
-    const int tile = v + idx * p.W;
+    const bool spread = (p.stagger & 8) != 0 && idx + 1 == p.full_rounds && raw >= 0;
+    const int tile = (spread ? raw : v) + idx * p.W;
     if (tile >= p.ntiles) return s;
     tile_coord(p, tile, s.m0, s.n0); s.it0 = 0; s.it1 = p.I; s.ok = true;
     return s;
