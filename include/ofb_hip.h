@@ -123,7 +123,7 @@ int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream);
 #define OFB_TUNE_GEMM_SCHED 1  /* OFB_GEMM_H_SPREAD: 1 (default) = a partial last round of a multi-round launch is spread over all XCDs, 0 = contiguous */
 #define OFB_TUNE_GEMM_TILE 2   /* OFB_GEMM_H_TILE: 0 (default) = the 128 x 192 tile everywhere, 96 = the 256 x 96 tile wherever it is legal, 97 = by the
                                   padded-columns model of rounds 3-4, 128 = forced */
-#define OFB_TUNE_RESERVED3 3
+#define OFB_TUNE_GEMM_T112 3   /* OFB_GEMM_H_T112: 1 = the 112 x 192 tile for token-row products whose 128-row tiles fill between half a round and one round; 0 (default) = off: measured slower, profiles/r05_gemm_tile_112.txt */
 #define OFB_TUNE_COUNT 4
 int ofb_tune(int32_t key, int32_t value);
 

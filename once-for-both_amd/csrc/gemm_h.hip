@@ -39,19 +39,25 @@ typedef short hs16x8 __attribute__((ext_vector_type(8)));
 
 // Tile configuration: WM x WN waves, wave tile (32 MI) x (32 NI), NST LDS stages of KH K16 sub-steps, WGS workgroups per CU, MF = the
 // MFMA's block size: 32 = v_mfma_f32_32x32x16_f16 (one instruction per K16 sub-step), 16 = v_mfma_f32_16x16x32_f16 (one per K32 stage).
-template <int WM_, int WN_, int MI_, int NI_, int NST_, int KH_, int WGS_, int MF_ = 32>
+// MB16 / NB16 (MF = 16 only, 0 = derived from MI / NI): the wave tile given directly in 16-row / 16-column blocks.  The tile then
+// COMPUTES BMT = 16 MB16 WM rows while it STAGES BM = BMT rounded up to 32 (the LDS image keeps its 32-row pieces); tiles step by BMT.
+template <int WM_, int WN_, int MI_, int NI_, int NST_, int KH_, int WGS_, int MF_ = 32, int MB16_ = 0, int NB16_ = 0>
 struct Cfg {
   static constexpr int WM = WM_, WN = WN_, MI = MI_, NI = NI_, NST = NST_, KH = KH_, WGS = WGS_, NW = WM * WN, MF = MF_;
-  static constexpr int MB = 32 * MI / MF, NB = 32 * NI / MF;                          // MFMA blocks of the wave tile
-  static_assert(MF == 32 || (MF == 16 && KH == 2 && MB % 2 == 0 && NB % 2 == 0), "a 16x16x32 instruction spans one K32 stage; quarter steps");
-  static constexpr int BM = 32 * MI * WM, BN = 32 * NI * WN, NT = 64 * NW;
+  static constexpr int MB = MB16_ ? MB16_ : 32 * MI / MF, NB = NB16_ ? NB16_ : 32 * NI / MF;     // MFMA blocks of the wave tile
+  static_assert(MF == 32 || (MF == 16 && KH == 2), "a 16x16x32 instruction spans one K32 stage");
+  static_assert((MB16_ == 0 && NB16_ == 0) || MF == 16, "block-granular wave tiles are a 16x16x32 form");
+  static constexpr int BMT = MF * MB * WM;                                            // rows a tile computes (= its step along M)
+  static constexpr int BM = (BMT + 31) / 32 * 32, BN = MF * NB * WN, NT = 64 * NW;     // rows / columns staged
   static constexpr int A_BYTES = BM * 64 * KH, B_BYTES = BN * 64 * KH, STAGE = A_BYTES + B_BYTES;
   static constexpr int A_PIECES = A_BYTES / 1024, B_PIECES = B_BYTES / 1024;          // 1-KB LDS-DMA pieces per stage
   static constexpr int QA = A_PIECES / NW, QB = (B_PIECES + NW - 1) / NW;             // pieces per wave (the last B piece only for some waves)
-  static constexpr int HA = MI / 2;                                                   // row blocks per half step
+  static constexpr int HA = MI / 2;                                                   // row blocks per half step (MF = 32)
   static constexpr int HR = (NST * STAGE >= (128 + 32) * (BN + 4) * 4) ? 128 : 64;    // rows of the tile parked in LDS per epilogue pass (+ a column-sum row per 4)
   static constexpr int TROW = HR + 4;
-  static_assert(A_PIECES % NW == 0 && MI % 2 == 0 && BM % HR == 0 && (32 * MI) <= HR && HR % (32 * MI) == 0, "piece / epilogue schedule");
+  static constexpr int NPASS = (BMT + HR - 1) / HR;                                   // epilogue passes (the last one may be short)
+  static_assert(A_PIECES % NW == 0 && BN % 32 == 0 && BMT % 16 == 0, "piece schedule");
+  static_assert(MF == 16 || (MI % 2 == 0 && BM % HR == 0 && (32 * MI) <= HR && HR % (32 * MI) == 0), "epilogue schedule of the 32x32 forms");
   static_assert(BN * TROW * 4 <= NST * STAGE && QA >= 1 && QA <= 8 && QB <= 8 && NST >= 2 && NST <= 4 && KH >= 1 && KH <= 2, "LDS budget / schedule");
   static_assert(NST * STAGE * WGS <= 163840, "LDS per CU");
 };
@@ -59,6 +65,11 @@ using C128 = Cfg<2, 2, 2, 3, 2, 2, 2>;
 //   C128F: the same tile, stages and LDS image on v_mfma_f32_16x16x32_f16 (4 x 6 blocks per wave, quarter steps of 18 MFMAs): the
 //        chip holds a higher clock on this shape at equal cycles per FLOP (MI355X_MICROARCH "DVFS give-back" item 7)
 using C128F = Cfg<2, 2, 2, 3, 2, 2, 2, 16>;
+//   C112F: a 112 x 192 tile on the same stages (128 rows staged, 7 x 16 computed): four waves side by side, wave tile 112 x 48 = 7 x 3
+//        blocks.  For products whose 128-row tiles fill between half a round and one round of the 2 x CUs workgroups (the five
+//        394-tile products of the DeiT-S step): the launch ends when its slowest pair of co-resident tiles does, and 452 tiles of
+//        112 rows are 7/8 of the work of 394 tiles of 128 (VERDICT r4 #1b)
+using C112F = Cfg<1, 4, 2, 1, 2, 2, 2, 16, 7, 3>;        // (MI, NI = 2, 1: placeholders, the 16-blocks 7 x 3 count)
 //   C96: 256 x 96, 4 waves stacked along M (the same 64 x 96 wave tile): output widths that pad badly on 192 columns (N mod 192 in
 //        (0, 96]: the pruned / finetune widths 264, 480, 672, ...)
 using C96 = Cfg<4, 1, 2, 3, 3, 1, 2>;     // K16 stages: two K32 stages of a 256 x 96 tile x two workgroups do not fit the LDS
@@ -395,11 +406,12 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
   constexpr int BM = CF::BM, BN = CF::BN, WN = CF::WN, MI = CF::MI, NI = CF::NI, HA = CF::HA, NST = CF::NST, NW = CF::NW, KH = CF::KH;
   constexpr int STAGE = CF::STAGE, A_BYTES = CF::A_BYTES, QA = CF::QA, QB = CF::QB, HR = CF::HR, TROW = CF::TROW;
   constexpr int NBA = BM / 32, NBB = BN / 32;                 // 32-row blocks of each operand's tile
+  constexpr int BMT = CF::BMT, NPASS = CF::NPASS;             // rows the tile computes (its step along M); epilogue passes
   constexpr int MF = CF::MF, MB = CF::MB, NB = CF::NB;        // MFMA block size; blocks of the wave tile
   using acc_t = std::conditional_t<MF == 32, f32x16, f32x4>;
   __shared__ __attribute__((aligned(1024))) char lds[NST * STAGE];
   const int t = threadIdx.x, lane = t & 63, w = __builtin_amdgcn_readfirstlane(t >> 6), l31 = lane & 31, h = lane >> 5;
-  const int wm0 = (w / WN) * (32 * MI), wn0 = (w % WN) * (32 * NI);
+  const int wm0 = (w / WN) * (CF::MF * CF::MB), wn0 = (w % WN) * (CF::MF * CF::NB);
   const int a_ncb = g.a_ncb, b_ncb = g.b_ncb;
   const bool blast = w + NW * (QB - 1) < CF::B_PIECES;   // this wave moves a QB-th B piece per stage (wave-uniform)
   const int n_w = QA + QB - (blast ? 0 : 1);             // LDS-DMA instructions of this wave per stage
@@ -559,8 +571,8 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
     hs16x8 v = {lo4[0], lo4[1], lo4[2], lo4[3], hi4[0], hi4[1], hi4[2], hi4[3]};
     return __builtin_bit_cast(ofb_f16x8, v);
   };
-  constexpr int HM = MB / 2, HN = NB / 2;
-  ofb_f16x8 fa_lo[HM][2], fa_hi[HM][2], fb_l[HN][2], fb_r[HN][2];
+  constexpr int HML = (MB + 1) / 2, HMH = MB / 2, HNL = (NB + 1) / 2, HNR = NB / 2;       // lower / upper row blocks, left / right column blocks
+  ofb_f16x8 fa_lo[HML][2], fa_hi[HMH > 0 ? HMH : 1][2], fb_l[HNL][2], fb_r[HNR > 0 ? HNR : 1][2];
   // (the address registers a_q / b_q carry the stage buffer: flip16 moves them to the other one - ONE copy of the stage code serves
   //  both buffers with immediate offsets only; two copies, one per buffer, cost a register shuffle of all accumulators where they join
   //  and spilled in the copies behind the loop)
@@ -571,17 +583,19 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
     for (int k = 0; k < 4; ++k) { a_q[k] += d; b_q[k] += d; }
     q_buf = STAGE - q_buf;
   };
-  auto rdA16 = [&](ofb_f16x8 (&dst)[HM][2], int blk0) __attribute__((always_inline)) {
+  auto rdA16 = [&](auto& dst, int blk0, int n) __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < HM; ++i)
+    for (int i = 0; i < (int)(sizeof(dst) / sizeof(dst[0])); ++i)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) dst[i][pl] = frag16(lds, a_q, A_KC, (wm0 >> 4) + blk0 + i, pl);
+      for (int pl = 0; pl < 2; ++pl)
+        if (i < n) dst[i][pl] = frag16(lds, a_q, A_KC, (wm0 >> 4) + blk0 + i, pl);
   };
-  auto rdB16 = [&](ofb_f16x8 (&dst)[HN][2], int blk0) __attribute__((always_inline)) {
+  auto rdB16 = [&](auto& dst, int blk0, int n) __attribute__((always_inline)) {
 #pragma unroll
-    for (int j = 0; j < HN; ++j)
+    for (int j = 0; j < (int)(sizeof(dst) / sizeof(dst[0])); ++j)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) dst[j][pl] = frag16(lds + A_BYTES, b_q, B_KC, (wn0 >> 4) + blk0 + j, pl);
+      for (int pl = 0; pl < 2; ++pl)
+        if (j < n) dst[j][pl] = frag16(lds + A_BYTES, b_q, B_KC, (wn0 >> 4) + blk0 + j, pl);
   };
   // an odd number of K16 steps: the last stage's second K16 half does not exist (what lies there is another row group's data or
   // uninitialised slack); its k belongs to the lanes >= 32 of every fragment, which are cleared
@@ -602,17 +616,20 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
   constexpr int TA[4] = {1, 1, 0, 0}, TB[4] = {1, 0, 1, 0};
   constexpr int T0 = 4 - NTERM;
   constexpr int NMF = NTERM * HA * NI, RD1 = 4 * HA, RD2 = 4 * HA + 4 * NI;   // MFMAs per half step; fragment reads riding in the first / second half
-  constexpr int NMQ = NTERM * HM * HN, RQA = 4 * HM, RQB = 4 * HN;            // MF = 16: MFMAs per quarter step; fragment reads of an A / a B half
+  // MF = 16: MFMAs of the four quarter steps (lower / upper rows x left / right columns); fragment reads of the A / B halves
+  constexpr int NQ1 = NTERM * HML * HNL, NQ2 = NTERM * HMH * HNL, NQ3 = NTERM * HML * HNR, NQ4 = NTERM * HMH * HNR;
+  constexpr int RAL = 4 * HML, RAH = 4 * HMH, RBL = 4 * HNL, RBR = 4 * HNR;
+  static_assert(MF == 32 || (RAH <= 2 * NQ1 && RBR <= 2 * NQ2 && RBL <= 2 * NQ3 && RAL <= 2 * NQ4), "fragment reads per MFMA gap");
 #define OFB_MMA_HALF(AF, BF, BLK0)                                                                                                   \
   _Pragma("unroll") for (int q = T0; q < 4; ++q) _Pragma("unroll") for (int i = 0; i < HA; ++i) _Pragma("unroll") for (int j = 0; j < NI; ++j) \
       acc[BLK0 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(AF[i][TA[q]], BF[j][TB[q]], acc[BLK0 + i][j], 0, 0, 0);
 #if OFB_LAB_ABLATE == 3
-#define OFB_MMA_QUARTER(AF, BF, I0, J0)                                                                                              \
-  _Pragma("unroll") for (int i = 0; i < HM; ++i) _Pragma("unroll") for (int j = 0; j < HN; ++j)                                       \
+#define OFB_MMA_QUARTER(AF, NA_, BF, NB_, I0, J0)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < (NA_); ++i) _Pragma("unroll") for (int j = 0; j < (NB_); ++j)                                 \
       asm volatile("" :: "v"(AF[i][0]), "v"(AF[i][1]), "v"(BF[j][0]), "v"(BF[j][1]));
 #else
-#define OFB_MMA_QUARTER(AF, BF, I0, J0)                                                                                              \
-  _Pragma("unroll") for (int q = T0; q < 4; ++q) _Pragma("unroll") for (int i = 0; i < HM; ++i) _Pragma("unroll") for (int j = 0; j < HN; ++j) \
+#define OFB_MMA_QUARTER(AF, NA_, BF, NB_, I0, J0)                                                                                    \
+  _Pragma("unroll") for (int q = T0; q < 4; ++q) _Pragma("unroll") for (int i = 0; i < (NA_); ++i) _Pragma("unroll") for (int j = 0; j < (NB_); ++j) \
       acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(AF[i][TA[q]], BF[j][TB[q]], acc[I0 + i][J0 + j], 0, 0, 0);
 #endif
 #define OFB_INTERLEAVE(NM, ND)                                                               \
@@ -682,9 +699,9 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
       rdB(bb[0], 0, 0);
     } else {
       if (q_buf) flip16();                                    // every unit starts in buffer 0
-      rdA16(fa_lo, 0);
-      rdB16(fb_l, 0);
-      if (OFB_LAB_ABLATE == 4) { rdA16(fa_hi, HM); rdB16(fb_r, HN); }
+      rdA16(fa_lo, 0, HML);
+      rdB16(fb_l, 0, HNL);
+      if (OFB_LAB_ABLATE == 4) { rdA16(fa_hi, HML, HMH); rdB16(fb_r, HNL, HNR); }
     }
     // the hand-over inside the LAST sub-step of stage i: this wave is done reading buf(i), its pieces of stage i+1 have landed
     // (later stages may fly), everybody agrees (barrier), stage i + NST goes into buf(i)
@@ -703,27 +720,27 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
         // fragment reads of the halves that come next ride in the MFMA gaps: upper A, right B of this stage, then left B and lower A
         // of the next one (after the last stage they fetch a stale buffer that nothing consumes)
         __builtin_amdgcn_sched_barrier(0);
-        if (OFB_LAB_ABLATE != 4) rdA16(fa_hi, HM);
+        if (OFB_LAB_ABLATE != 4) rdA16(fa_hi, HML, HMH);
         if (!full) { clear_hi(fa_lo); clear_hi(fb_l); }
-        OFB_MMA_QUARTER(fa_lo, fb_l, 0, 0)
-        OFB_SPREAD(NMQ, RQA)
+        OFB_MMA_QUARTER(fa_lo, HML, fb_l, HNL, 0, 0)
+        OFB_SPREAD(NQ1, RAH)
         __builtin_amdgcn_sched_barrier(0);
-        if (OFB_LAB_ABLATE != 4) rdB16(fb_r, HN);
+        if (OFB_LAB_ABLATE != 4) rdB16(fb_r, HNL, HNR);
         if (!full) clear_hi(fa_hi);
-        OFB_MMA_QUARTER(fa_hi, fb_l, HM, 0)
-        OFB_SPREAD(NMQ, RQB)
+        OFB_MMA_QUARTER(fa_hi, HMH, fb_l, HNL, HML, 0)
+        OFB_SPREAD(NQ2, RBR)
         __builtin_amdgcn_sched_barrier(0);
         if (full) handover(i, buf);
         flip16();
         __builtin_amdgcn_sched_barrier(0);
-        if (OFB_LAB_ABLATE != 4) rdB16(fb_l, 0);
+        if (OFB_LAB_ABLATE != 4) rdB16(fb_l, 0, HNL);
         if (!full) clear_hi(fb_r);
-        OFB_MMA_QUARTER(fa_lo, fb_r, 0, HN)
-        OFB_SPREAD(NMQ, RQB)
+        OFB_MMA_QUARTER(fa_lo, HML, fb_r, HNR, 0, HNL)
+        OFB_SPREAD(NQ3, RBL)
         __builtin_amdgcn_sched_barrier(0);
-        if (OFB_LAB_ABLATE != 4) rdA16(fa_lo, 0);
-        OFB_MMA_QUARTER(fa_hi, fb_r, HM, HN)
-        OFB_SPREAD(NMQ, RQA)
+        if (OFB_LAB_ABLATE != 4) rdA16(fa_lo, 0, HML);
+        OFB_MMA_QUARTER(fa_hi, HMH, fb_r, HNR, HML, HNL)
+        OFB_SPREAD(NQ4, RAL)
         __builtin_amdgcn_sched_barrier(0);
       } else if constexpr (KH == 1) {
         __builtin_amdgcn_sched_barrier(0);
@@ -849,13 +866,15 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
       const int rp_out = (g.M + 15) & ~15;
       // WIDE also serves tiles that stick out of the matrix on the COLUMN side (N = 264, 480, ... on 192-wide tiles: half of all
       // tiles of the pruned / finetune shapes): N is a multiple of 4 there, so a column quad lies wholly inside or wholly outside
-      const bool wide = TAIL || (cur.m0 + BM <= g.M && (p.stagger & 1) != 0);   // p.stagger bit 0: "wide epilogue allowed" (alignment checked on the host)
-      constexpr int NQ = BN / 4, NITEM = (HR / 4) * NQ, NIT = (NITEM + CF::NT - 1) / CF::NT;     // column quads per row; items per pass; per thread
+      const bool wide = TAIL || (cur.m0 + BMT <= g.M && (p.stagger & 1) != 0);   // p.stagger bit 0: "wide epilogue allowed" (alignment checked on the host)
+      constexpr int NQ = BN / 4, NIT = ((HR / 4) * NQ + CF::NT - 1) / CF::NT;         // column quads per row; items per full pass and thread
       __builtin_amdgcn_s_barrier();                                 // every wave has finished its fragment reads / its LDS-DMA
 #pragma unroll
-      for (int half = 0; half < BM / HR; ++half) {
-        if (wm0 / HR == half) {
-          if constexpr (MF == 32) {
+      for (int half = 0; half < NPASS; ++half) {
+        const int prow = (BMT - HR * half) < HR ? (BMT - HR * half) : HR;           // rows of this pass (the last one of a 112-row tile: 48)
+        const int NITEM = (prow / 4) * NQ;
+        if constexpr (MF == 32) {
+          if (wm0 / HR == half) {
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
@@ -863,14 +882,16 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                   T[((wm0 % HR) + 32 * mi + 8 * (r >> 2) + 4 * h + (r & 3)) * TLD + wn0 + 32 * ni + l31] = acc[mi][ni][r];
-          } else {                                                    // 16 x 16 block: column on lane & 15, rows 4 (lane >> 4) + r
+          }
+        } else {                                                      // 16 x 16 blocks (column on lane & 15, rows 4 (lane >> 4) + r): those of this pass
 #pragma unroll
-            for (int mi = 0; mi < MB; ++mi)
+          for (int mi = 0; mi < MB; ++mi) {
+            if ((wm0 + 16 * mi) / HR != half) continue;
 #pragma unroll
-              for (int ni = 0; ni < NB; ++ni)
+            for (int ni = 0; ni < NB; ++ni)
 #pragma unroll
-                for (int r = 0; r < 4; ++r)
-                  T[((wm0 % HR) + 16 * mi + 4 * (lane >> 4) + r) * TLD + wn0 + 16 * ni + (lane & 15)] = acc[mi][ni][r];
+              for (int r = 0; r < 4; ++r)
+                T[((wm0 + 16 * mi) % HR + 4 * (lane >> 4) + r) * TLD + wn0 + 16 * ni + (lane & 15)] = acc[mi][ni][r];
           }
         }
         __syncthreads();
@@ -881,7 +902,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
 #pragma unroll 1
           for (int k = 0; k < NIT; ++k) {
             const int id = t + CF::NT * k;
-            const bool initem = (NITEM % CF::NT == 0) || id < NITEM;
+            const bool initem = id < NITEM;
             const int rgl = initem ? id / NQ : 0, cq = initem ? id - (id / NQ) * NQ : 0;
             const int row0 = cur.m0 + HR * half + 4 * rgl, lcol = 4 * cq, col0 = cur.n0 + lcol;
             const bool live = initem && (TAIL || col0 < g.N);                       // this quad's columns exist
@@ -987,7 +1008,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
           }
           if (rn) {
             __syncthreads();                                          // every item's row parts are in
-            if (RN_OK && t < 4 * HR) {
+            if (RN_OK && t < 4 * prow) {
               const int rr = t >> 2, part = t & 3, row = cur.m0 + HR * half + rr;
               float ss = 0.f;
 #pragma unroll
@@ -1007,8 +1028,8 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
             if (t < BN && cur.n0 + t < g.N) {
               float sum = 0.f;
 #pragma unroll
-              for (int rg = 0; rg < HR / 4; ++rg) sum += S[rg * TLD + t];
-              float* cp = g.colpart + (size_t)(cur.m0 / BM) * g.N + cur.n0 + t;
+              for (int rg = 0; rg < HR / 4; ++rg) sum += (4 * rg < prow) ? S[rg * TLD + t] : 0.f;
+              float* cp = g.colpart + (size_t)(cur.m0 / BMT) * g.N + cur.n0 + t;
               if (half == 0) *cp = sum; else *cp += sum;
             }
           }
@@ -1022,6 +1043,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
 #pragma unroll 1
           for (int k = 0; k < NRG; ++k) {
             const int rgl = w + NW * k, row0 = cur.m0 + HR * half + 4 * rgl;
+            if (4 * rgl >= prow) continue;                              // (a short last pass)
             float rss[4] = {0.f, 0.f, 0.f, 0.f};                        // E_RN: this lane's share of the four rows' sums of squares
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
@@ -1085,16 +1107,16 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
               float sum = 0.f;
 #pragma unroll
               for (int ww = 0; ww < NW; ++ww) sum += T[ww * TLD + t];
-              float* cp = g.colpart + (size_t)(cur.m0 / BM) * g.N + cur.n0 + t;
+              float* cp = g.colpart + (size_t)(cur.m0 / BMT) * g.N + cur.n0 + t;
               if (half == 0) *cp = sum; else *cp += sum;
             }
           }
         }
-        if (half + 1 < BM / HR) __syncthreads();                    // T is rewritten by the next pass (the next unit starts with a barrier)
+        if (half + 1 < NPASS) __syncthreads();                    // T is rewritten by the next pass (the next unit starts with a barrier)
       }
       if (rn) {
         __syncthreads();
-        if (t == 0) g.rn_out[(cur.m0 / BM) * p.nt + cur.n0 / BN] = Rmx[0];
+        if (t == 0) g.rn_out[(cur.m0 / BMT) * p.nt + cur.n0 / BN] = Rmx[0];
       }
     }
     OFB_HSTAMP(3);
@@ -1190,6 +1212,15 @@ int h_tile_choice(const ofb_gemm_h_args& g) {
   if (h_tune[OFB_TUNE_GEMM_TILE] == 1281 || h_tune[OFB_TUNE_GEMM_TILE] == 1283) return h_tune[OFB_TUNE_GEMM_TILE];
   if (forced == 1281 || forced == 1283) return forced;
 #endif
+  // The 112-row tile (C112F): token-row products (A reduced along its columns) whose 128-row tiles fill more than half a round but
+  // not more than one round of the 2 x CUs workgroups, and whose 112-row tiles still fit one round: the launch ends with its slowest
+  // co-resident pair either way, and that pair has 7/8 of the rows.  OFB_GEMM_H_TILE=128 / ofb_tune keeps the 128-row tile.
+  if (g.a_kc && !g.colpart && forced != 96 && forced != 97 && h_switch(OFB_TUNE_GEMM_MFMA, "OFB_GEMM_H_MFMA", 16) == 16 &&
+      h_switch(OFB_TUNE_GEMM_T112, "OFB_GEMM_H_T112", 0) != 0) {
+    const int W2 = h_cu_count() * C128F::WGS, nt = ofb_cdiv(g.N, C128F::BN);
+    const long long n128 = (long long)ofb_cdiv(g.M, C128F::BMT) * nt, n112 = (long long)ofb_cdiv(g.M, C112F::BMT) * nt;
+    if (2 * n128 > W2 && n128 <= W2 && n112 <= W2) return 112;
+  }
   if (g.a_kc && !g.colpart && !g.rn_out && g.M >= 4 * C96::BM) {
     const int c192 = ofb_cdiv(g.N, 192) * 192, c96 = ofb_cdiv(g.N, 96) * 96;
     if (forced == 96) return 96;
@@ -1215,10 +1246,11 @@ Plan plan_h(const ofb_gemm_h_args& g) {
     if (dw_wgs < 0) { const char* e = getenv("OFB_GEMM_H_DW_WGS"); dw_wgs = e ? atoi(e) : 1; }
     if (dw_wgs > 0 && dw_wgs < CF::WGS) W = h_cu_count() * dw_wgs;
   }
-  const int tiles = ofb_cdiv(g.M, CF::BM) * ofb_cdiv(g.N, CF::BN);
+  const int tiles = ofb_cdiv(g.M, CF::BMT) * ofb_cdiv(g.N, CF::BN);
   const long long iters = (long long)tiles * ofb_cdiv(g.K, 16);
   if (iters < W) W = (int)iters;
-  Plan p = make_plan(g.M, g.N, g.K, W, CF::BM, CF::BN, 16);
+  Plan p = make_plan(g.M, g.N, g.K, W, CF::BMT, CF::BN, 16);
+  if (CF::BMT != CF::BM && p.R > 0) { p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0; }   // (no stream-K form of the 112-row tile)
   if (p.R > 0 && g.rn_out) { p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0; }   // (the fix-up kernel has no row-norm form)
   if (p.R > 0 && g.colpart && p.R % p.nt != 0) {                     // column sums of tail tiles come from the fix-up kernel, which
     p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;         // addresses them per whole tile row
@@ -1397,6 +1429,7 @@ extern "C" int64_t ofb_gemm_h_workspace_bytes(const ofb_gemm_h_args* args) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
   const int tile = h_tile_choice(*args);
   if (tile == 96) { const Plan p = plan_h<C96>(*args); return p.R ? (int64_t)2 * p.W * C96::BM * C96::BN * (int64_t)sizeof(float) : 0; }
+  if (tile == 112) return 0;                                  // (whole rounds only)
   const Plan p = plan_h<C128>(*args);
   return p.R ? (int64_t)2 * p.W * C128::BM * C128::BN * (int64_t)sizeof(float) : 0;
 }
@@ -1417,8 +1450,9 @@ extern "C" int32_t ofb_gemm_h_rn_tiles(const ofb_gemm_h_args* args, int32_t* col
   g.rn_out = nullptr;
   if (h_tile_choice(g) == 96) return 0;
   g.rn_out = reinterpret_cast<float*>(16);                  // the geometry of the launch that WILL carry rn_out
-  const bool c96 = h_tile_choice(g) == 96;
-  const int bm = c96 ? C96::BM : C128::BM, bn = c96 ? C96::BN : C128::BN;
+  const int tile = h_tile_choice(g);
+  const bool c96 = tile == 96;
+  const int bm = c96 ? C96::BM : tile == 112 ? C112F::BMT : C128::BM, bn = c96 ? C96::BN : C128::BN;
   const int nt = ofb_cdiv(args->N, bn);
   if (col_tiles) *col_tiles = nt;
   return ofb_cdiv(args->M, bm) * nt;
@@ -1444,9 +1478,9 @@ extern "C" int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream) {
   const int tile = h_tile_choice(g);
   const int mf = h_switch(OFB_TUNE_GEMM_MFMA, "OFB_GEMM_H_MFMA", 16);
 #ifdef OFB_GEMM_H_LAB
-  const int rc = tile == 1283 ? run_h<C128S>(g, s) : tile == 1281 ? run_h<C128K1>(g, s) : (tile == 96 ? run_h<C96>(g, s) : (mf == 16 ? run_h<C128F>(g, s) : run_h<C128>(g, s)));
+  const int rc = tile == 1283 ? run_h<C128S>(g, s) : tile == 1281 ? run_h<C128K1>(g, s) : tile == 112 ? run_h<C112F>(g, s) : (tile == 96 ? run_h<C96>(g, s) : (mf == 16 ? run_h<C128F>(g, s) : run_h<C128>(g, s)));
 #else
-  const int rc = tile == 96 ? run_h<C96>(g, s) : (mf == 16 ? run_h<C128F>(g, s) : run_h<C128>(g, s));
+  const int rc = tile == 96 ? run_h<C96>(g, s) : tile == 112 ? run_h<C112F>(g, s) : (mf == 16 ? run_h<C128F>(g, s) : run_h<C128>(g, s));
 #endif
   ofb_prof_post(0, s);
   return rc;

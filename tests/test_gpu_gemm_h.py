@@ -79,16 +79,24 @@ SHAPES = [(256, 256, 64), (394, 384, 384), (591, 1152, 384), (130, 70, 36), (128
           # widths that pad badly on 192 columns and M >= 1024: the 256 x 96 tile (C96) takes the token-row forms (kc,kc / kc,kr);
           # the pruned / finetune widths of configs[4] (264, 480, 672, 160, 224, 576, 960) and odd ones
           (1100, 264, 200), (2048, 480, 264), (1500, 96, 64), (1300, 672, 264), (1024, 100, 40), (5000, 224, 160), (1234, 77, 264),
-          (1027, 576, 264), (1500, 960, 264)]
+          (1027, 576, 264), (1500, 960, 264),
+          # more than half a round but at most one round of 128-row tiles (2 x CUs workgroups): the token-row forms run on the
+          # 112 x 192 tile (C112F: 7 x 3 blocks per wave, a short second epilogue pass), incl. ragged widths and a last tile that is cut
+          (19200, 384, 64), (19000, 264, 72), (17001, 576, 40)]
 
 
-@pytest.fixture(params=[0, 96], ids=['tile128', 'tile96'])
+@pytest.fixture(params=[0, 96, 112], ids=['tile128', 'tile96', 'tile112'])
 def tile_choice(request):
-    """every shape on the default tile and, where it is legal (token-row forms, M >= 1024), on the 256 x 96 tile (32x32x16, K16 stages)"""
+    """every shape on the default tile and, where it is legal (token-row forms, M >= 1024), on the 256 x 96 tile (32x32x16, K16 stages);
+    112 = the 112 x 192 tile switched on (the host picks it for the token-row forms of the shapes marked below, the others skip)"""
     from ofb_amd import hip
-    hip.tune(hip.TUNE_GEMM_TILE, request.param)
+    if request.param == 112:
+        hip.tune(hip.TUNE_GEMM_T112, 1)
+    else:
+        hip.tune(hip.TUNE_GEMM_TILE, request.param)
     yield request.param
     hip.tune(hip.TUNE_GEMM_TILE, 0)
+    hip.tune(hip.TUNE_GEMM_T112, 0)
 
 
 @pytest.mark.parametrize('M,N,K', SHAPES)
@@ -96,6 +104,8 @@ def test_gemm_h_modes_and_outputs(M, N, K, tile_choice):
     from ofb_amd import hip
     if tile_choice == 96 and M < 1024:
         pytest.skip('the 256 x 96 tile needs M >= 1024')
+    if tile_choice == 112 and M < 17000:
+        pytest.skip('the 112 x 192 tile is only chosen between half a round and one round of 128-row tiles')
     a, b = _mk((M, K), 3), _mk((N, K), 4)                       # logical A[M][K], B[N][K]
     exact = a.double() @ b.double().t()
     ad, bd = a.cuda(), b.cuda()
@@ -121,11 +131,14 @@ def test_gemm_h_modes_and_outputs(M, N, K, tile_choice):
     _close(y, exact.t() @ a.double(), 'H-format output as KR operand (zero padding)', tol=2e-5)
 
 
-@pytest.mark.parametrize('M,N,K', [(394, 384, 384), (300, 1536, 384), (130, 70, 36), (1200, 264, 72), (1400, 480, 264), (2100, 672, 100)])
+@pytest.mark.parametrize('M,N,K', [(394, 384, 384), (300, 1536, 384), (130, 70, 36), (1200, 264, 72), (1400, 480, 264), (2100, 672, 100),
+                                   (19200, 384, 48), (18999, 264, 40)])          # (the last two: the 112 x 192 tile)
 def test_gemm_h_epilogues(M, N, K, tile_choice):
     from ofb_amd import hip
     if tile_choice == 96 and M < 1024:
         pytest.skip('the 256 x 96 tile needs M >= 1024')
+    if tile_choice == 112 and M < 17000:
+        pytest.skip('the 112 x 192 tile is only chosen between half a round and one round of 128-row tiles')
     x, w, b = _mk((M, K), 5), _mk((N, K), 6, 0.1), _mk((N,), 7)
     cs, res = _mk((N,), 8), _mk((M, N), 9)
     rs = _mk(((M + 196) // 197,), 10)
