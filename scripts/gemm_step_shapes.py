@@ -5,6 +5,12 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from ofb_amd import hip
 M, D, H3, HID = 128 * 197, 384, 1152, 1536
+# --dims=D,H3,HID[,M]: another block geometry (e.g. a post-compress block of the configs[4] subnet: --dims=264,576,768)
+for a in sys.argv[1:]:
+    if a.startswith('--dims='):
+        v = [int(x) for x in a[7:].split(',')]
+        D, H3, HID = v[:3]
+        if len(v) > 3: M = v[3]
 # --ab KEY=V1,V2[,V3]: every product is timed under each value of the run-time switch hip.TUNE_<KEY> (interleaved rounds in this one
 # process, MI355X guide rule 24); the table then carries one column per value
 AB = None
