@@ -112,6 +112,10 @@ int ofb_patchify_hformat(const float* img, int32_t B, int32_t Cin, int32_t H, in
 int ofb_to_hformat_multi(const ofb_hformat_job* jobs_dev, int32_t n_jobs, int32_t max_R, int32_t max_C, float* scratch, void* stream);
 int ofb_to_hformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
                           float* partial, const float* bound, void* stream);
+/* the same with the bound given as n_bound (>= 1) device floats whose MAXIMUM bounds |X * rowscale|: the per-workgroup maxima that
+ * ofb_attention_bwd_wgmax leaves (every block of the conversion reduces the same words in the same order; no atomics, no memset node) */
+int ofb_to_hformat_colsum_nb(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
+                             float* partial, const float* bound, int32_t n_bound, void* stream);
 int ofb_from_hformat(const void* P, int32_t R, int32_t C, float* X, int32_t ld, void* stream);   /* (h1 + h2) 2^-e */
 int32_t ofb_colsum_h_slabs(int32_t R);
 int ofb_colsum_h(const void* P, int32_t R, int32_t C, float* partial, void* stream);
@@ -215,6 +219,11 @@ int ofb_attention_fwd(const float* qkv, float* out, float* lse, int32_t B, int32
 int ofb_attention_bwd(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv, int32_t B,
                       int32_t N, int32_t H, int32_t dh, float scale, const float* qkv_bound, const float* dout_bound,
                       float* dqkv_amax, void* stream);
+/* The same with the maximum left as ONE WORD PER WORKGROUP: wg_amax[B * H] (required) is plainly written - no atomic max, and nothing to
+ * zero ahead of the launch (ofb_attention_bwd enqueues a 4-byte memset node for its scalar); hand the vector to ofb_to_hformat_colsum_nb */
+int ofb_attention_bwd_wgmax(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv, int32_t B,
+                            int32_t N, int32_t H, int32_t dh, float scale, const float* qkv_bound, const float* dout_bound,
+                            float* wg_amax, void* stream);
 /* Forward that also writes the output rows as H-format planes out_h[B*N][H*dh] (the operand of the projection GEMM; the values
  * of `out`; |out| <= max |v|, so the planes take the qkv exponent).  The caller zeroes out_h beforehand when B*N or H*dh is not a
  * multiple of 16. */

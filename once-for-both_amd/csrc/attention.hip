@@ -384,7 +384,7 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
                                                                  const float* __restrict__ lse, const float* __restrict__ dout,
                                                                  float* __restrict__ dqkv, int B, int N, int H, int dh, float scale,
                                                                  const float* __restrict__ qkv_bound, const float* __restrict__ dout_bound,
-                                                                 float* __restrict__ dqkv_amax, int kc) {
+                                                                 float* __restrict__ dqkv_amax, int kc, int amax_per_wg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* Kpl = smem;
   char* dSpl = smem + AB_OFF_DS;
@@ -764,7 +764,10 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
       float m = 0.f;
 #pragma unroll
       for (int i = 0; i < AB_NW; ++i) m = fmaxf(m, vmax[8 + i]);
-      ofb_atomic_max_pos(dqkv_amax, m);
+      // amax_per_wg: one word per workgroup, plainly stored (no atomics, nothing to zero beforehand; LONG: the later key chunks of a
+      // (batch, head) raise what the earlier launches left); the consumer reduces the B H words itself
+      if (amax_per_wg) dqkv_amax[blockIdx.x] = (LONG && kc > 0) ? fmaxf(dqkv_amax[blockIdx.x], m) : m;
+      else ofb_atomic_max_pos(dqkv_amax, m);
     }
   }
 }
@@ -837,9 +840,10 @@ extern "C" int ofb_attention_fwd_h(const float* qkv, float* out, void* out_h, fl
 
 // dqkv: same packing as qkv (dq | dk | dv).  Needs the forward's out and lse, the bound the forward used for qkv and a bound of
 // |dout| (device scalars).  dqkv_amax (optional device scalar): receives max |dqkv| - hand it to ofb_to_hformat_colsum as the bound.
-extern "C" int ofb_attention_bwd(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
-                                 int32_t B, int32_t N, int32_t H, int32_t dh, float scale, const float* qkv_bound,
-                                 const float* dout_bound, float* dqkv_amax, void* stream) {
+namespace {
+int attention_bwd_launch(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv, int32_t B, int32_t N,
+                         int32_t H, int32_t dh, float scale, const float* qkv_bound, const float* dout_bound, float* dqkv_amax,
+                         int amax_per_wg, void* stream) {
   if (!qkv || !out || !lse || !dout || !dqkv || !qkv_bound || !dout_bound) return OFB_EINVAL;
   if (int rc = check_shape(B, N, H, dh)) return rc;
   if (!ofb_aligned16(qkv) || !ofb_aligned16(out) || !ofb_aligned16(dout) || !ofb_aligned16(dqkv)) return OFB_EINVAL;
@@ -850,17 +854,33 @@ extern "C" int ofb_attention_bwd(const float* qkv, const float* out, const float
   if (hipFuncSetAttribute(lng ? (const void*)attn_bwd_kernel<true> : (const void*)attn_bwd_kernel<false>,
                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS) != hipSuccess)
     return (int)hipGetLastError();
-  if (dqkv_amax && hipMemsetAsync(dqkv_amax, 0, 4, s) != hipSuccess) return (int)hipGetLastError();
+  if (dqkv_amax && !amax_per_wg && hipMemsetAsync(dqkv_amax, 0, 4, s) != hipSuccess) return (int)hipGetLastError();
   ofb_prof_pre(4, s, 10.0 * B * H * (double)N * N * dh);
   if (!lng)
     hipLaunchKernelGGL(attn_bwd_kernel<false>, dim3(B * H), dim3(AB_THREADS), BWD_LDS, s, qkv, out, lse, dout, dqkv, B, N, H, dh, scale,
-                       qkv_bound, dout_bound, dqkv_amax, 0);
+                       qkv_bound, dout_bound, dqkv_amax, 0, amax_per_wg);
   else
     for (int kc = 0; kc * AB_NPOS < N; ++kc)               // dqkv_amax: the running dq sums are included, an upper bound of the final values
       hipLaunchKernelGGL(attn_bwd_kernel<true>, dim3(B * H), dim3(AB_THREADS), BWD_LDS, s, qkv, out, lse, dout, dqkv, B, N, H, dh, scale,
-                         qkv_bound, dout_bound, dqkv_amax, kc);
+                         qkv_bound, dout_bound, dqkv_amax, kc, amax_per_wg);
   ofb_prof_post(4, s);
   return ofb_launch_status();
+}
+}  // namespace
+
+extern "C" int ofb_attention_bwd(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
+                                 int32_t B, int32_t N, int32_t H, int32_t dh, float scale, const float* qkv_bound,
+                                 const float* dout_bound, float* dqkv_amax, void* stream) {
+  return attention_bwd_launch(qkv, out, lse, dout, dqkv, B, N, H, dh, scale, qkv_bound, dout_bound, dqkv_amax, 0, stream);
+}
+
+// The same with the maximum left as ONE WORD PER WORKGROUP: wg_amax[B * H] (required) is plainly written, so nothing has to be zeroed
+// ahead of the launch (no memset node) and no atomic is issued; ofb_to_hformat_colsum_nb takes the vector as its bound.
+extern "C" int ofb_attention_bwd_wgmax(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
+                                       int32_t B, int32_t N, int32_t H, int32_t dh, float scale, const float* qkv_bound,
+                                       const float* dout_bound, float* wg_amax, void* stream) {
+  if (!wg_amax) return OFB_EINVAL;
+  return attention_bwd_launch(qkv, out, lse, dout, dqkv, B, N, H, dh, scale, qkv_bound, dout_bound, wg_amax, 1, stream);
 }
 
 #ifdef OFB_ATT_STAMPS

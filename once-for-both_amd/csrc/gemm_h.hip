@@ -246,10 +246,21 @@ __global__ void to_hformat_multi_kernel(const ofb_hformat_job* __restrict__ jobs
 // writes the planes AND partial[slab][c] = sum of the slab's (scaled, NOT 2^e-scaled) rows, added in row order.
 __global__ __launch_bounds__(256) void to_hformat_colsum_kernel(const float* __restrict__ X, int R, int C, int ld, char* __restrict__ P,
                                                                 int ncb, int rgs, const float* __restrict__ rowscale, int rs_div,
-                                                                float* __restrict__ partial, const float* __restrict__ bound) {
+                                                                float* __restrict__ partial, const float* __restrict__ bound, int n_bound) {
   __shared__ float red[4][64];
   ofb_hhdr* hdr = reinterpret_cast<ofb_hhdr*>(P);
-  const float amax = bound ? bound[0] : hdr->amax;
+  float amax = bound ? bound[0] : hdr->amax;
+  if (bound && n_bound > 1) {
+    // a vector of partial maxima (one word per workgroup of the producer: ofb_attention_bwd_wgmax): every block reduces the same words
+    // in the same order (a few KB out of the L2) - no atomics and no memset node on the producer's side
+    float m = 0.f;
+    for (int i = threadIdx.x; i < n_bound; i += 256) m = fmaxf(m, bound[i]);
+    m = ofb_wave_max_pos(m);
+    if ((threadIdx.x & 63) == 0) red[0][threadIdx.x >> 6] = m;
+    __syncthreads();
+    amax = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+    __syncthreads();                                      // red is reused for the column sums below
+  }
   const int e = ofb_h_exp(amax);
   if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
     hdr->e = e;
@@ -1397,16 +1408,31 @@ extern "C" int ofb_to_hformat_multi(const ofb_hformat_job* jobs_dev, int32_t n_j
   return ofb_launch_status();
 }
 
-extern "C" int ofb_to_hformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
-                                     float* partial, const float* bound, void* stream) {
+namespace {
+int to_hformat_colsum_launch(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
+                             float* partial, const float* bound, int32_t n_bound, void* stream) {
   if (!X || !P || !partial || R <= 0 || C <= 0 || ld < C) return OFB_EINVAL;
   if (rowscale && rs_div <= 0) return OFB_EINVAL;
+  if (bound && n_bound <= 0) return OFB_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const int ncb = (C + 15) / 16, rgs = ((R + 15) / 16) * 4, slabs = (rgs + CS_SLAB_RG - 1) / CS_SLAB_RG;
   if (int rc = h_prepare_header(X, R, C, ld, P, rowscale, rs_div, bound, s)) return rc;
   hipLaunchKernelGGL(to_hformat_colsum_kernel, dim3((ncb * 16 + 63) / 64, slabs), dim3(256), 0, s, X, R, C, ld, (char*)P, ncb, rgs, rowscale,
-                     rs_div, partial, bound);
+                     rs_div, partial, bound, n_bound);
   return ofb_launch_status();
+}
+}  // namespace
+
+extern "C" int ofb_to_hformat_colsum(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
+                                     float* partial, const float* bound, void* stream) {
+  return to_hformat_colsum_launch(X, R, C, ld, P, rowscale, rs_div, partial, bound, 1, stream);
+}
+
+// bound: n_bound device floats whose maximum is >= max |x * rowscale| (the per-workgroup maxima of ofb_attention_bwd_wgmax)
+extern "C" int ofb_to_hformat_colsum_nb(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div,
+                                        float* partial, const float* bound, int32_t n_bound, void* stream) {
+  if (!bound) return OFB_EINVAL;
+  return to_hformat_colsum_launch(X, R, C, ld, P, rowscale, rs_div, partial, bound, n_bound, stream);
 }
 
 extern "C" int ofb_from_hformat(const void* P, int32_t R, int32_t C, float* X, int32_t ld, void* stream) {

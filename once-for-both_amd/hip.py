@@ -21,10 +21,10 @@ ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs', 'ofb_tune', 'ofb_gemm_h_rn_tiles',
+    'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_colsum_nb', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs', 'ofb_tune', 'ofb_gemm_h_rn_tiles',
     'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_fwd_h', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_h', 'ofb_layernorm_bwd_h_rn', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
-    'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_amax', 'ofb_attention_fwd', 'ofb_attention_fwd_h', 'ofb_attention_bwd',
+    'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_amax', 'ofb_attention_fwd', 'ofb_attention_fwd_h', 'ofb_attention_bwd', 'ofb_attention_bwd_wgmax',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
     'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
@@ -195,10 +195,16 @@ def to_hformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1, colsum_out=
     if colsum_out is not None:
         slabs, ldp = int(lib().ofb_colsum_h_slabs(_i(R))), pm.ncb * 16
         part = torch.empty(slabs, ldp, device=x.device, dtype=torch.float32)
-        check(lib().ofb_to_hformat_colsum(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(part), ptr(bound),
-                                          stream()), 'ofb_to_hformat_colsum')
+        if bound is not None and bound.numel() > 1:           # a vector of partial maxima (attention_bwd(..., wg_amax=...))
+            check(lib().ofb_to_hformat_colsum_nb(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(part), ptr(bound),
+                                                 _i(bound.numel()), stream()), 'ofb_to_hformat_colsum_nb')
+        else:
+            check(lib().ofb_to_hformat_colsum(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(part), ptr(bound),
+                                              stream()), 'ofb_to_hformat_colsum')
         colsum(part, ldp, slabs, Cc, colsum_out)
         return pm
+    if bound is not None and bound.numel() > 1:
+        raise OfbError('to_hformat: a vector bound is only taken together with colsum_out (ofb_to_hformat_colsum_nb)')
     check(lib().ofb_to_hformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(bound), stream()), 'ofb_to_hformat')
     return pm
 
@@ -677,12 +683,19 @@ def attention_fwd_h(qkv, out, outP, lse, B, N, H, dh, scale, qkv_bound=None):
     return qkv_bound
 
 
-def attention_bwd(qkv, out, lse, dout, dqkv, B, N, H, dh, scale, qkv_bound=None, dout_bound=None, dqkv_amax=None):
+def attention_bwd(qkv, out, lse, dout, dqkv, B, N, H, dh, scale, qkv_bound=None, dout_bound=None, dqkv_amax=None, wg_amax=None):
     """qkv_bound: the bound the forward used; dout_bound: device scalar >= max |dout|; dqkv_amax: device scalar that receives
-    max |dqkv| (the bound for its H-format copy)"""
+    max |dqkv| (the bound for its H-format copy); wg_amax [B * H] instead: one word per workgroup, written without atomics and without
+    a memset node ahead of the launch - to_hformat(..., colsum_out=..., bound=wg_amax) reduces the vector itself"""
     _check_lse(lse, B, N, H)
     qkv_bound = qkv_bound if qkv_bound is not None else amax(qkv)
     dout_bound = dout_bound if dout_bound is not None else amax(dout)
+    if wg_amax is not None:
+        if dqkv_amax is not None or wg_amax.numel() != B * H or wg_amax.dtype != torch.float32:
+            raise OfbError('attention_bwd: wg_amax must hold B * H floats (and excludes dqkv_amax)')
+        check(lib().ofb_attention_bwd_wgmax(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), _i(B), _i(N), _i(H), _i(dh), _f(scale),
+                                            ptr(qkv_bound), ptr(dout_bound), ptr(wg_amax), stream()), 'ofb_attention_bwd_wgmax')
+        return
     check(lib().ofb_attention_bwd(ptr(qkv), ptr(out), ptr(lse), ptr(dout), ptr(dqkv), _i(B), _i(N), _i(H), _i(dh), _f(scale),
                                   ptr(qkv_bound), ptr(dout_bound), ptr(dqkv_amax), stream()), 'ofb_attention_bwd')
 

@@ -426,11 +426,12 @@ class AttnBranch(torch.autograd.Function):
         dwp = dwp if dwp is not None else _new(d2, D, Hd)
         with (hip.side_work(d2.device, keep=[d2sP.buf, oP.buf]) if _side_ok(wproj, tokens=M) else _nullctx()):
             p_linear_bwd_weight(d2sP, oP, M, D, Hd, out=dwp)
-        # dq | dk | dv leave the attention kernel as f32 rows together with their maximum (one atomic max per workgroup): the
-        # conversion pass takes its exponent from it and sums the columns (the raw qkv bias gradient) on the way
+        # dq | dk | dv leave the attention kernel as f32 rows together with their maxima (one word per workgroup, plainly stored: no
+        # atomics, no memset node): the conversion pass reduces them to its exponent and sums the columns (the raw qkv bias
+        # gradient) on the way
         dbq_raw = _new(d2, 3 * Hd) if bqkv is not None else None
-        dqkv, dq_amax = torch.empty_like(qkv), _new(d2, 1)
-        hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale, qb, dob, dq_amax)
+        dqkv, dq_amax = torch.empty_like(qkv), _new(d2, B * heads)
+        hip.attention_bwd(qkv, o, lse, do, dqkv, B, N, heads, dh, scale, qb, dob, wg_amax=dq_amax)
         dqkvP = hip.to_hformat(dqkv, M, 3 * Hd, 3 * Hd, colsum_out=dbq_raw, bound=dq_amax)
         # fold = 3: the gate-fold kernel adds the q | k | v contributions to the gate gradient itself
         dx, dwq, dbq, dg3 = _p_gated_linear_bwd(dqkvP, lambda: dbq_raw, xP, M, wqkv, wqP, bqkv, g3, resid=d2 if self_resid else None, fold=3,
@@ -571,6 +572,32 @@ class PatchEmbedTokens(torch.autograd.Function):
         dcls = dpos[0].reshape(cshape).clone()
         return (None, dw.view(wshape), db, None if gshape is None else dgm[0].view(gshape), dpos.view(pshape), dcls,
                 None if mshape is None else dgm[1].view(mshape), None, None)
+
+
+class TokenTaps(torch.autograd.Function):
+    """The two readers of the final token stream (vision_transformer.py:735-744): cls rows [B][D] for the head and the MASKED patch rows
+    [n][D] for the decoder.  As two separate autograd ops (a slice and an index_select) the backward built TWO dense zero tensors of the
+    stream's size, scattered one gradient into each and added them (5 launches, ~230 MB of traffic at DeiT-S bs 128 for 1408 non-zero
+    rows); here ONE zero tensor receives both (cls rows and masked rows are disjoint and unique: plain copies, no accumulation)."""
+
+    @staticmethod
+    def forward(ctx, latent, tok_rows):
+        B, T, D = latent.shape
+        ctx.save_for_backward(tok_rows)
+        ctx.shape = (B, T, D)
+        return latent[:, 0].contiguous(), latent.reshape(B * T, D).index_select(0, tok_rows)
+
+    @staticmethod
+    def backward(ctx, dcls, dz):
+        (tok_rows,) = ctx.saved_tensors
+        B, T, D = ctx.shape
+        like = dcls if dcls is not None else dz
+        g = torch.zeros(B * T, D, device=like.device, dtype=like.dtype)
+        if dcls is not None:
+            g.view(B, T, D)[:, 0].copy_(dcls)
+        if dz is not None:
+            g.index_add_(0, tok_rows, dz)                     # (int32 indices are fine here; unique rows: 0 + x)
+        return g.view(B, T, D), None
 
 
 def norm_targets(imgs, ksize=47):

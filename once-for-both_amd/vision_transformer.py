@@ -390,13 +390,14 @@ class MIMVisionTransformer(MAEBaseModel):
     def forward(self, imgs):
         latent, mask, _, _ = self.forward_features(imgs)
         B, T, D = latent.shape
+        cls_rows = None
         if self.mae and mask is not None:
             L, P, Cc = T - 1, self.patch_size, self.in_chans
             # only masked patches reach the loss (M = 0 elsewhere, vision_transformer.py:724-729): decode just those rows.
             # token row of global patch id p = b*L + l is  b*(L+1) + 1 + l = p + p // L + 1
             ids = self._masked_ids
             tok_rows = ids + torch.div(ids, L, rounding_mode='floor') + 1
-            z = latent.reshape(B * T, D).index_select(0, tok_rows)
+            cls_rows, z = ops.TokenTaps.apply(latent, tok_rows)
             dec = self.decoder[0]
             rec = ops.Linear.apply(z, dec.weight.view(dec.weight.shape[0], -1), dec.bias)      # 1x1 conv, patch layout
             # norm_targets(imgs, 47) for the masked patches' pixels only: one fused kernel over their 62 x 62 windows
@@ -407,7 +408,7 @@ class MIMVisionTransformer(MAEBaseModel):
             decoder_loss = ops.PmimLoss.apply(rec, targets, mask, ids, B, L, P, Cc)
         else:
             decoder_loss = 0.
-        x = ops.Linear.apply(latent[:, 0].contiguous(), self.head.weight, self.head.bias)
+        x = ops.Linear.apply(cls_rows if cls_rows is not None else latent[:, 0].contiguous(), self.head.weight, self.head.bias)
         return x, (decoder_loss, None)
 
     # ---- losses (reference base_model.py:31-86) -------------------------------------------------

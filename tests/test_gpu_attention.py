@@ -64,6 +64,18 @@ def test_attention_fwd_bwd(B, N, H, dh):
         assert float(amax) == dqkv.abs().max().item()
     else:                                                   # chunked: the running dq sums of the earlier launches are included (an upper bound)
         assert dqkv.abs().max().item() <= float(amax) <= 4.0 * dqkv.abs().max().item()
+    # the per-workgroup form of the maximum (no atomics, no memset node): word (b, h) = max |dq|dk|dv| of that head; the conversion pass
+    # that takes the vector as its bound gives the same planes and column sums as the one that gets the scalar
+    third, wg = torch.empty_like(dqkv), torch.full((B * H,), float('nan'), device='cuda')
+    hip.attention_bwd(qd, o, lse, dout.cuda(), third, B, N, H, dh, scale, wg_amax=wg)
+    assert torch.equal(third, dqkv) and float(wg.max()) == float(amax)
+    if N <= 208:
+        per_head = dqkv.view(B, N, 3, H, dh).abs().amax(dim=(1, 2, 4)).reshape(-1)
+        assert torch.equal(wg, per_head)
+    cs_a, cs_b = torch.empty(3 * Hd, device='cuda'), torch.empty(3 * Hd, device='cuda')
+    pa = hip.to_hformat(dqkv, B * N, 3 * Hd, 3 * Hd, colsum_out=cs_a, bound=amax)
+    pb = hip.to_hformat(dqkv, B * N, 3 * Hd, 3 * Hd, colsum_out=cs_b, bound=wg)
+    assert pa.header() == pb.header() and torch.equal(pa.to_f32(), pb.to_f32()) and torch.equal(cs_a, cs_b)
     # a LOOSE bound (what the model hands over: Cauchy-Schwarz bounds, 4-30x the maximum) costs no accuracy
     loose_q, loose_d = hip.amax(qd) * 16.0, hip.amax(dout.cuda()) * 16.0
     o3, lse3, dq3 = torch.empty_like(o), torch.empty_like(lse), torch.empty_like(dqkv)
