@@ -465,7 +465,7 @@ def main():
         n, ms, work = prof[0]
         if n:
             ach = work / (ms * 1e-3) / 1e12
-            roof = dict(bound='mfma', kernel='gemm_h_kernel (f32 products as three v_mfma_f32_32x32x16_f16 terms of operands pre-split into two f16 planes '
+            roof = dict(bound='mfma', kernel='gemm_h_kernel (f32 products as three v_mfma_f32_16x16x32_f16 terms of operands pre-split into two f16 planes '
                                              'of a power-of-two scaled copy, LDS-DMA staged; bound pre-kernel + main + stream-K tail + fix-up launches of all '
                                              'ofb_gemm_h calls)',
                         achieved=round(ach, 2), peak=round(PEAK_GEMM_TFLOPS, 1), unit='TFLOP/s', frac=round(ach / PEAK_GEMM_TFLOPS, 4),

@@ -124,11 +124,12 @@ int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream);
 /* Run-time switches of the GEMM (same-process A/B of kernel variants; results are identical to rounding, only speed differs).
  * Unset keys take the environment variable named below, read once, else the default.  Not thread-safe against running calls. */
 #define OFB_TUNE_GEMM_MFMA 0   /* OFB_GEMM_H_MFMA: 16 (default) = v_mfma_f32_16x16x32_f16, 32 = v_mfma_f32_32x32x16_f16 on the 128 x 192 tile */
-#define OFB_TUNE_GEMM_SCHED 1  /* OFB_GEMM_H_SPREAD: 1 (default) = a partial last round of a multi-round launch is spread over all XCDs, 0 = contiguous */
+#define OFB_TUNE_GEMM_SCHED 1  /* OFB_GEMM_H_SPREAD: 2 (default) = 1 + a launch of ONE partial round gives every XCD an equal share of its tiles; 1 = a partial last round of a multi-round launch is spread over all XCDs; 0 = contiguous */
 #define OFB_TUNE_GEMM_TILE 2   /* OFB_GEMM_H_TILE: 0 (default) = the 128 x 192 tile everywhere, 96 = the 256 x 96 tile wherever it is legal, 97 = by the
                                   padded-columns model of rounds 3-4, 128 = forced */
 #define OFB_TUNE_GEMM_T112 3   /* OFB_GEMM_H_T112: 1 = the 112 x 192 tile for token-row products whose 128-row tiles fill between half a round and one round; 0 (default) = off: measured slower, profiles/r05_gemm_tile_112.txt */
-#define OFB_TUNE_COUNT 4
+#define OFB_TUNE_GEMM_YIELD 4  /* OFB_GEMM_H_YIELD: n in 1..7 = in single-round launches the first-dispatched workgroup of a CU that holds two sleeps 128 n cycles at each stage hand-over (default 4; 0 = off) */
+#define OFB_TUNE_COUNT 5
 int ofb_tune(int32_t key, int32_t value);
 
 /* out[i] = sum_s workspace[s*count + i] (+ out[i] if accumulate): sums per-chunk partial buffers (embed assembly) */

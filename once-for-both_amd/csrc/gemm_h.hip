@@ -683,6 +683,10 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
     fold_e = __builtin_amdgcn_readfirstlane(ofb_h_exp(bound));
     __syncthreads();                                      // red[] is read before the first stage lands on it
   }
+  // plan.stagger bits 4-6 (single-round launches, host: plan_h): the first-dispatched workgroup of a CU that has a second one (blockIdx +
+  // W / 2 holds a tile too) sleeps 128 n cycles at every stage hand-over - it runs its units ~1.4x faster than its neighbour and
+  // would otherwise finish early and leave the CU to the slower one: the launch ends when the LAST workgroup does
+  const int ysl = (!TAIL && (int)blockIdx.x + (p.W >> 1) < p.ntiles) ? (p.stagger >> 4) & 7 : 0;
   while (true) {
     const int nk16 = cur.it1 - cur.it0, nst = (nk16 + KH - 1) / KH;
     const bool last_full = nk16 == nst * KH;              // KH == 2: an odd number of K16 steps ends in a half stage
@@ -723,6 +727,15 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
       vm_wait(young * n_w);
       __builtin_amdgcn_s_barrier();
       if (i + NST < nst) issue(buf, a_base + (size_t)(i + NST) * a_step, b_base + (size_t)(i + NST) * b_step, 1);
+      if (ysl) {                                           // OFB_TUNE_GEMM_YIELD: the faster workgroup of the CU steps aside for 128 n cycles
+        if (ysl == 1) __builtin_amdgcn_s_sleep(2);
+        else if (ysl == 2) __builtin_amdgcn_s_sleep(4);
+        else if (ysl == 3) __builtin_amdgcn_s_sleep(6);
+        else if (ysl == 4) __builtin_amdgcn_s_sleep(8);
+        else if (ysl == 5) __builtin_amdgcn_s_sleep(10);
+        else if (ysl == 6) __builtin_amdgcn_s_sleep(12);
+        else __builtin_amdgcn_s_sleep(14);
+      }
     };
     auto stage = [&](int i, int buf, bool full) __attribute__((always_inline)) {
       const int nbuf = buf + 1 == NST ? 0 : buf + 1;
@@ -1208,7 +1221,7 @@ int h_cu_count() {
 }
 
 // Run-time switches (ofb_tune): -1 = not set yet (the environment variable of the same meaning is read once, then the default)
-int h_tune[OFB_TUNE_COUNT] = {-1, -1, -1, -1};
+int h_tune[OFB_TUNE_COUNT] = {-1, -1, -1, -1, -1};
 int h_switch(int key, const char* env, int dflt) {
   if (h_tune[key] < 0) { const char* e = getenv(env); h_tune[key] = e ? atoi(e) : dflt; }
   return h_tune[key];
@@ -1269,7 +1282,7 @@ Plan plan_h(const ofb_gemm_h_args& g) {
   // A remainder of at most half a round behind >= 2 full rounds runs as one more, partial round on the FIRST-dispatched workgroup of
   // every CU (get_seg's spread form): those run their units ~1.4x faster than the later-dispatched ones, so full_rounds + 1 of
   // their units end about when the others' full_rounds do - the remainder costs (almost) no time, no partial tiles, no fix-up launch
-  const bool spread_on = h_switch(OFB_TUNE_GEMM_SCHED, "OFB_GEMM_H_SPREAD", 1) != 0;
+  const bool spread_on = h_switch(OFB_TUNE_GEMM_SCHED, "OFB_GEMM_H_SPREAD", 2) != 0;
   if (spread_on && p.R > 0 && p.full_rounds >= 2 && 2 * p.R <= W && (g.a_kc || g.b_kc)) {
     p.full_rounds += 1; p.R = 0; p.q = 0; p.S = 0; p.qs = 0;
   }
@@ -1306,7 +1319,12 @@ Plan plan_h(const ofb_gemm_h_args& g) {
   const bool fold_ok = fold && (g.Cp || g.cbound_out) && p.full_rounds > 0 && side <= 8192;
   // bit 3: the partial last round of a multi-round launch is spread over the XCDs by the raw block index (gemm_plan.h: get_seg)
   const bool spread = spread_on && p.full_rounds >= 2 && p.R == 0 && p.ntiles < p.full_rounds * p.W;
-  p.stagger = (wide_ok ? 1 : 0) | (fold_ok ? 2 : 0) | (spread ? 8 : 0);
+  // bit 7: a launch of ONE partial round hands every XCD an equal share of the tiles, in dispatch order (gemm_plan.h: get_seg);
+  // bits 4-6: and the first-dispatched workgroup of every fully occupied CU yields at its stage hand-overs (gemm_h_kernel: ysl)
+  const int yl = h_switch(OFB_TUNE_GEMM_YIELD, "OFB_GEMM_H_YIELD", 4);
+  const bool balance1 = h_switch(OFB_TUNE_GEMM_SCHED, "OFB_GEMM_H_SPREAD", 2) >= 2 && p.R == 0 && p.full_rounds == 1 && p.ntiles < p.W && p.ntiles >= 8;
+  const bool one_round = balance1 && 2 * p.ntiles > p.W && CF::WGS == 2 && p.W == h_cu_count() * 2;
+  p.stagger = (wide_ok ? 1 : 0) | (fold_ok ? 2 : 0) | (spread ? 8 : 0) | ((yl > 0 && one_round) ? ((yl > 7 ? 7 : yl) << 4) : 0) | (balance1 ? 128 : 0);
   return p;
 }
 

@@ -53,7 +53,14 @@ __device__ __forceinline__ Seg get_seg(const Plan p, int v, int idx, int raw = -
   if (!TAIL) {
     if (idx >= p.full_rounds) return s;
     const bool spread = (p.stagger & 8) != 0 && idx + 1 == p.full_rounds && raw >= 0;
-    const int tile = (spread ? raw : v) + idx * p.W;
+    int tile = (spread ? raw : v) + idx * p.W;
+    if ((p.stagger & 128) && raw >= 0) {
+      // a launch of ONE partial round: the contiguous form fills the first XCDs with two workgroups per CU and leaves the last ones
+      // empty (394 tiles on 512 slots: XCDs 0-5 full, XCD 7 idle); here every XCD gets an equal, still contiguous share, handed to
+      // its workgroups in dispatch order - the first-dispatched workgroup of EVERY CU of the chip gets a tile before any second one
+      if (raw >= p.ntiles) return s;
+      tile = ofb_xcd_remap(raw, p.ntiles);
+    }
     if (tile >= p.ntiles) return s;
     tile_coord(p, tile, s.m0, s.n0); s.it0 = 0; s.it1 = p.I; s.ok = true;
     return s;

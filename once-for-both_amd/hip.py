@@ -164,7 +164,7 @@ class HMat:
         return int(h.view(torch.int32)[0]), float(f[1]), float(f[2]), float(f[3])
 
 
-TUNE_GEMM_MFMA, TUNE_GEMM_SCHED, TUNE_GEMM_TILE, TUNE_GEMM_T112 = 0, 1, 2, 3
+TUNE_GEMM_MFMA, TUNE_GEMM_SCHED, TUNE_GEMM_TILE, TUNE_GEMM_T112, TUNE_GEMM_YIELD = 0, 1, 2, 3, 4
 
 
 def tune(key, value):

@@ -26,8 +26,8 @@ def run(tag, fn, flops, count, iters=10):
         if AB: hip.tune(AB[0], v)
         for _ in range(2): fn()
     torch.cuda.synchronize()
-    for _ in range(3):
-        for v in variants:
+    for rnd in range(4):
+        for v in (variants if rnd % 2 == 0 else variants[::-1]):     # (the first variant after the idle sync runs on a cooler chip: alternate the order)
             if AB: hip.tune(AB[0], v)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
