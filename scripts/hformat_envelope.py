@@ -25,6 +25,7 @@ def main():
     ap.add_argument('--model', default='deit_small')
     ap.add_argument('--batch', type=int, default=128)
     ap.add_argument('--warm', type=int, default=3)
+    ap.add_argument('--per-tensor', action='store_true', help='also list every tensor of the sites whose worst tensor has > 1 %% of its non-zeros below the window, in creation order')
     args = ap.parse_args()
     import ofb_amd
     from ofb_amd import engine, hip
@@ -112,6 +113,12 @@ def main():
         worst_loose, worst_below = max(worst_loose, lo[-1]), max(worst_below, bl)
         print(f'{tag[:62]:62s} {str(shape):>14s} {len(recs):3d}  {lo[0]:8.2f} / {med:6.2f} / {lo[-1]:6.2f}  {bl:16.2e}  {zr:10.2e}  {wr:9.1f}')
     print(f'# worst looseness 2^{worst_loose:.2f}; largest share below the window {worst_below:.2e}')
+    if args.per_tensor:
+        print('# per tensor, in creation order (forward: block 0 first; backward: block 11 first), for the sites above 1 %:')
+        for (tag, shape), recs in rows_out.items():
+            if max(r['below'] for r in recs) > 0.01:
+                print(f'{tag[:62]} {shape}: below window ' + ' '.join(f'{r["below"]:.3f}' for r in recs))
+                print(f'{"":10s} zeros ' + ' '.join(f'{r["zeros"]:.3f}' for r in recs) + '   worst row ' + ' '.join(f'{r["worst_row"]:.0f}' for r in recs))
 
 
 if __name__ == '__main__':
