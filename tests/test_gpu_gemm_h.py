@@ -300,3 +300,30 @@ def test_patchify_planes_hold_the_patch_matrix(B, Cin, S, patch):
     assert (pm.R, pm.C) == tuple(ref.shape)
     assert pm.header()[1] == imgs.abs().max().item()
     assert ((pm.to_f32() - ref).abs() <= 2.0 ** -23 * imgs.abs().max()).all()
+
+
+def test_single_round_scheduling_switches_move_tiles_not_bits():
+    """A launch of ONE partial round (300 tiles on 512 slots): the XCD-balanced tile order (OFB_TUNE_GEMM_SCHED 2) and the yielding first
+    workgroup (OFB_TUNE_GEMM_YIELD) only decide WHICH workgroup computes a tile and when - the f32 output, the planes and the row norms
+    handed to LayerNorm backward are bit-identical to the contiguous order without yield."""
+    from ofb_amd import hip
+    M, N, K = 19200, 384, 200
+    x, w, res = _mk((M, K), 31).cuda(), _mk((N, K), 32, 0.1).cuda(), _mk((M, N), 33).cuda()
+    xp, wp = hip.to_hformat(x), hip.to_hformat(w)
+    gamma, rowfac = _mk((N,), 34).cuda(), _mk((M,), 35).abs().cuda()
+    outs = []
+    try:
+        for sched, yl in ((1, 0), (2, 0), (2, 4), (2, 7)):
+            hip.tune(hip.TUNE_GEMM_SCHED, sched)
+            hip.tune(hip.TUNE_GEMM_YIELD, yl)
+            out = torch.full((M, N), float('nan'), device='cuda')
+            rn = hip.gemm_h(xp, wp, 1, 1, M, N, K, C_out=out, ldc=N, resid=res, ldr=N, rn=(gamma, rowfac))
+            outs.append((out, None if rn is None else rn[0].clone()))
+    finally:
+        hip.tune(hip.TUNE_GEMM_SCHED, 2)
+        hip.tune(hip.TUNE_GEMM_YIELD, 4)
+    ref = x.double().cpu() @ w.double().cpu().t() + res.double().cpu()
+    _close(outs[0][0], ref, 'single-round product')
+    for out, rn in outs[1:]:
+        assert torch.equal(out, outs[0][0])
+        assert (rn is None) == (outs[0][1] is None) and (rn is None or torch.equal(rn, outs[0][1]))
