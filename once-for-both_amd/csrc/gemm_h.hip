@@ -29,7 +29,8 @@ typedef short hs16x8 __attribute__((ext_vector_type(8)));
 
 // lab only (scripts/lab/ablate_gemm_h.sh): -DOFB_LAB_ABLATE=n removes ONE ingredient of the 16x16x32 kernel (results are wrong) to see
 // what its time is made of: 1 = no B pieces after the prologue, 2 = no LDS-DMA at all after the prologue, 3 = no MFMAs (fragment reads
-// kept alive), 4 = no fragment reads after the prologue, 5 = no global stores in the wide epilogue
+// kept alive), 4 = no fragment reads after the prologue, 5 = no global stores in the wide epilogue, 6 = no GELU' (aux) stores, 7 = no
+// plane stores, 8 = the GELU pieces replaced by two FMAs, 9 = no epilogue at all
 #ifndef OFB_LAB_ABLATE
 #define OFB_LAB_ABLATE 0
 #endif
@@ -852,6 +853,14 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (a half last stage leaves its own DMA unwaited)
     OFB_HSTAMP(2);
 
+#if OFB_LAB_ABLATE == 9                                   // lab: no epilogue at all (the accumulators are kept alive)
+    if constexpr (MF == 16) {
+#pragma unroll
+      for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j) asm volatile("" :: "v"(acc[i][j]));
+    } else
+#endif
     {
       // Epilogue through LDS (the stage buffers are free now).  The accumulators of HR rows of the tile are parked ROW-major as
       // T[row][BN + 4] f32 and all waves finish those rows together.  WIDE form (interior tiles of launches whose f32 side tensors are
@@ -967,7 +976,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
                   val = ofb_gelu(val);
                 } else if (gelug) {
                   float Phi, phi;
-                  ofb_gelu_parts(val, Phi, phi);
+                  if (OFB_LAB_ABLATE == 8) { Phi = 0.5f + 0.1f * val; phi = 0.1f; } else ofb_gelu_parts(val, Phi, phi);
                   ax[tt][e] = Phi + val * phi;
                   val *= Phi;
                 } else if (dg) {
@@ -998,7 +1007,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
             }
             if (OFB_LAB_ABLATE == 5) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); if (gelu || gelug) asm volatile("" :: "v"(ax[0]), "v"(ax[1]), "v"(ax[2]), "v"(ax[3])); }
             if (live && OFB_LAB_ABLATE != 5) {
-              if ((gelu && auxw) || gelug) {
+              if (((gelu && auxw) || gelug) && OFB_LAB_ABLATE != 6) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) OFB_NT_STORE(ax[tt], reinterpret_cast<f32x4*>(auxw + (size_t)(row0 + tt) * g.ldaux + col));   // read by the backward only
               }
@@ -1006,7 +1015,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) *reinterpret_cast<f32x4*>(Cout + (size_t)(row0 + tt) * g.ldc + col) = o[tt];
               }
-              if (has_p) {
+              if (has_p && OFB_LAB_ABLATE != 7) {
                 // column e of the quad: rows 0..3 -> one 8-byte slot per plane; the quad's four slots are 32 contiguous bytes per plane
                 unsigned h1[4][2], h2[4][2];
 #pragma unroll
