@@ -4,16 +4,17 @@ Prints, per wave of workgroup 0, the cycles spent in each section of every query
 import ctypes as C
 import sys
 import torch
-sys.path.insert(0, '.')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from ofb_amd import hip
 B, N, H, dh = 128, 197, 6, 64
 torch.manual_seed(0)
 qkv = torch.randn(B * N, 3 * H * dh, device='cuda')
 o = torch.empty(B * N, H * dh, device='cuda'); lse = torch.empty(2 * B * H, N, device='cuda'); do = torch.randn_like(o)
-dP = hip.PMat.for_rows_written_by_kernel(B * N, 3 * H * dh, 'cuda'); cp = torch.empty(B, 3 * H * dh, device='cuda')
+dq = torch.empty_like(qkv)
 hip.attention_fwd(qkv, o, lse, B, N, H, dh, 0.125)
 for _ in range(5):
-    hip.attention_bwd_p(qkv, o, lse, do, dP, cp, B, N, H, dh, 0.125)
+    hip.attention_bwd(qkv, o, lse, do, dq, B, N, H, dh, 0.125)
 torch.cuda.synchronize()
 buf = (C.c_ulonglong * (8 * 64))()
 hip.lib().ofb_diag_att_stamps(buf)
