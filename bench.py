@@ -30,6 +30,13 @@ PEAK_F16_MFMA_TFLOPS = 2500.0                                                   
 GEMM_MFMA_TERMS = 3
 INIT_STEPS = 6
 PEAK_GEMM_TFLOPS = PEAK_F16_MFMA_TFLOPS / GEMM_MFMA_TERMS
+PEAK_HBM_TBS, HBM_COPY_TBS = 8.0, 6.29                                              # MI355X_MICROARCH.md: HBM3E spec / measured copy rate
+# algorithmic bytes of all ofb_gemm_h calls of one step (4-B H-format operands + outputs + epilogue side inputs, each
+# moved once), GB
+GEMM_ALGORITHMIC_GB = {('deit_small', 128): 28.5}
+ARITHMETIC = ('f32 inputs / outputs / accumulation / elementwise; every f32 PRODUCT of the GEMMs and of attention is three f16 MFMA terms of operands '
+              'split into two f16 planes of a power-of-two scaled copy - ONE exponent per tensor: 23 significant bits for elements within 2^18 of '
+              "the tensor's bound, an absolute 2^-39 of the bound below (measured weakest row of the step: ~17 bits; DESIGN 3)")
 
 
 def csrc_hash():
@@ -120,7 +127,20 @@ def cpu_baseline(log):
 
     tiny = run_case(O.DEIT_TINY, 2, 8)
     small = run_case(O.DEIT_SMALL, 1000, 32)
+    # how the port compares with the reference's own Python on one CPU (build container, 8 threads, same inputs:
+    # profiles/r01_reference_cpu_timing.json): the port is ~2x FASTER than the reference it restates (it fuses the gate / loss
+    # micro-ops), so the reference itself would sit at about value x reference_ratio on this host
+    ratio = None
+    try:
+        cases = json.load(open(os.path.join(ROOT, 'profiles', 'r01_reference_cpu_timing.json')))['cases']
+        ds = [c for c in cases if 'DeiT-S' in c['case']][0]
+        ratio = round(ds['reference_images_per_s'] / ds['oracle_images_per_s'], 3)
+    except (OSError, KeyError, IndexError, ValueError):
+        pass
     return dict(value=small['images_per_s'], unit='images/s', cores=torch.get_num_threads(), kind='port', cpu_model=_cpu_model(),
+                reference_ratio=ratio,
+                reference_ratio_note='reference engine.py search step / this port, DeiT-S bs 8, 8 threads of the build container '
+                                     '(profiles/r01_reference_cpu_timing.json): the port is the FASTER of the two',
                 sample=f'full OFB search steps (fwd + loss + bwd + 3x AdamW) of the oracle, fp32, {warm} warm-up + {timed} timed: '
                        f'DeiT-S bs 32 (value) and configs[0] DeiT-T 2-class bs 8',
                 cases={'deit_small_bs32': small, 'configs[0]_deit_tiny_2cls_bs8': tiny})
@@ -475,6 +495,16 @@ def main():
                         mfma_issued_tflops=round(ach * GEMM_MFMA_TERMS, 1),
                         launches_per_step=round(n / prof_steps, 1), avg_launch_us=round(ms / n * 1e3, 2),
                         share_of_step=round(ms / prof_steps / ms_step, 3), sampled_steps=prof_steps)
+            if args.mode == 'search' and not args.pruned and (args.model, args.batch) in GEMM_ALGORITHMIC_GB:
+                # the step's GEMMs sit ON the ridge with 4-byte operands (arithmetic intensity 95-151 flop/B against 104 = 833 TFLOP/s /
+                # 8 TB/s): their HBM floor is not below their matrix-pipe floor, so both fractions are quoted
+                gb = GEMM_ALGORITHMIC_GB[(args.model, args.batch)]
+                gemm_s = ms / prof_steps * 1e-3
+                roof['hbm_frac'] = round(gb * 1e9 / gemm_s / (PEAK_HBM_TBS * 1e12), 4)
+                roof['hbm_achieved_GBps'] = round(gb / gemm_s, 1)
+                roof['bound_detail'] = (f'ridge: matrix-pipe floor {work / prof_steps / (PEAK_GEMM_TFLOPS * 1e12) * 1e3:.2f} ms, HBM floor '
+                                        f'{gb / (PEAK_HBM_TBS * 1e3) * 1e3:.2f} ms at {PEAK_HBM_TBS:.0f} TB/s ({gb / HBM_COPY_TBS:.2f} ms at the '
+                                        f'{HBM_COPY_TBS} TB/s a copy kernel reaches), measured {gemm_s * 1e3:.2f} ms per step')
             if args.mode == 'search' and not args.pruned and (args.model, args.batch) == ('deit_small', 128):
                 tr, src = gemm_traffic_per_launch(n / prof_steps)
                 if tr:
@@ -485,7 +515,7 @@ def main():
                                                       'once: 28.5 GB per step = 187 MB per call')
     step_tflops = value * gflop_img / 1e3 / world
     log(f'loss_total {loss_val:.4f}; step {ms_step:.2f} ms; whole-step {step_tflops:.1f} TFLOP/s/GPU '
-        f'({step_tflops / PEAK_F32_MFMA_TFLOPS:.1%} of the f32 MFMA peak)')
+        f'({step_tflops / PEAK_GEMM_TFLOPS:.1%} of the three-term f16 ceiling {PEAK_GEMM_TFLOPS:.1f})')
     cfg_tag = 'configs[1]' if (args.model, args.batch) == ('deit_small', 128) else ('configs[3]' if args.model == 'deit_base' else 'off-config size')
     if args.mode == 'search' and args.pruned:
         metric = 'images/sec OFB-search step of a compress()-ed model (ragged shapes; NOT the BASELINE metric)'
@@ -510,7 +540,8 @@ def main():
                                            ranks=dist.get_world_size() if dist.is_initialized() else 1,
                                            buckets=len(reducer.buckets) if reducer is not None else 0), init_steps=INIT_STEPS,
                            hip_graph=bool(use_graph),
-                           step_tflops_per_gpu=round(step_tflops, 2), step_frac_of_3term_f16_ceiling=round(step_tflops / (2500.0 / 3.0), 4),
+                           step_tflops_per_gpu=round(step_tflops, 2), step_frac_of_3term_f16_ceiling=round(step_tflops / PEAK_GEMM_TFLOPS, 4),
+                           arithmetic=ARITHMETIC,
                            gflop_per_image=gflop_img, baseline_gflop_per_image=BASELINE_GFLOP_PER_IMG[args.model]),
                roofline=roof)
     if ft_info:

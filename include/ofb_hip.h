@@ -130,6 +130,10 @@ int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream);
 #define OFB_TUNE_GEMM_T112 3   /* OFB_GEMM_H_T112: 1 = the 112 x 192 tile for token-row products whose 128-row tiles fill between half a round and one round; 0 (default) = off: measured slower, profiles/r05_gemm_tile_112.txt */
 #define OFB_TUNE_GEMM_YIELD 4  /* OFB_GEMM_H_YIELD: n in 1..7 = in single-round launches the first-dispatched workgroup of a CU that holds two sleeps 128 n cycles at each stage hand-over (default 4; 0 = off) */
 #define OFB_TUNE_COUNT 5
+/* A value set here - 0 included - beats the environment variable of the same key.  OFB_EINVAL for a value outside the key's set
+ * (MFMA: 16 | 32; SCHED: 0..2; TILE: 0 | 96 | 97 | 128; T112: 0 | 1; YIELD: 0..32).  Process-wide and unsynchronised: do not change a
+ * switch between ofb_gemm_h_rn_tiles / ofb_gemm_h_workspace_bytes and the ofb_gemm_h call they size buffers for (the tile choice
+ * decides both), nor from a second thread while GEMMs are being launched. */
 int ofb_tune(int32_t key, int32_t value);
 
 /* out[i] = sum_s workspace[s*count + i] (+ out[i] if accumulate): sums per-chunk partial buffers (embed assembly) */

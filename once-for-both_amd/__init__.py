@@ -5,7 +5,7 @@ Device side: hand-written HIP kernels for gfx950 behind the C ABI in include/ofb
 (csrc/ -> csrc/libofb_hip.so, loaded with ctypes by `hip.py`).  There is no CPU fallback:
 every compute entry point raises if the HIP library or a GPU is missing.
 """
-from . import hip, ops, layers, vision_transformer, model, losses, optim, dp, engine, data  # noqa: F401
+from . import hip, ops, layers, vision_transformer, model, losses, optim, dp, engine, data, utils, lr_sched, lr_decay  # noqa: F401
 from .layers import (MAEPatchEmbed, MAESparseAttention, MAESparseMlp, SearchableAttention, SearchableMlp,  # noqa: F401
                      ModuleInjection, LayerNorm, PatchEmbed, Attention, Mlp)
 from .vision_transformer import (MIMVisionTransformer, VisionTransformerSearched, VisionTransformer, MAEBlock, Block,  # noqa: F401

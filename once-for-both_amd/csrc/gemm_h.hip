@@ -1239,7 +1239,7 @@ int h_switch(int key, const char* env, int dflt) {
 int h_tile_choice(const ofb_gemm_h_args& g) {
   static int env_forced = -1;
   if (env_forced < 0) { const char* e = getenv("OFB_GEMM_H_TILE"); env_forced = e ? atoi(e) : 0; }
-  const int forced = h_tune[OFB_TUNE_GEMM_TILE] > 0 ? h_tune[OFB_TUNE_GEMM_TILE] : env_forced;      // ofb_tune overrides the environment
+  const int forced = h_tune[OFB_TUNE_GEMM_TILE] >= 0 ? h_tune[OFB_TUNE_GEMM_TILE] : env_forced;     // ofb_tune (0 included) overrides the environment
   if (forced == 128) return 128;
 #ifdef OFB_GEMM_H_LAB
   if (h_tune[OFB_TUNE_GEMM_TILE] == 1281 || h_tune[OFB_TUNE_GEMM_TILE] == 1283) return h_tune[OFB_TUNE_GEMM_TILE];
@@ -1541,6 +1541,20 @@ extern "C" int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream) {
 
 extern "C" int ofb_tune(int32_t key, int32_t value) {
   if (key < 0 || key >= OFB_TUNE_COUNT || value < 0) return OFB_EINVAL;
+  bool ok = true;                                           // a value outside a key's set would silently select some other path
+  switch (key) {
+    case OFB_TUNE_GEMM_MFMA: ok = value == 16 || value == 32; break;
+    case OFB_TUNE_GEMM_SCHED: ok = value <= 2; break;
+    case OFB_TUNE_GEMM_TILE:
+      ok = value == 0 || value == 96 || value == 97 || value == 128;
+#ifdef OFB_GEMM_H_LAB
+      ok = ok || value == 1281 || value == 1283;
+#endif
+      break;
+    case OFB_TUNE_GEMM_T112: ok = value <= 1; break;
+    case OFB_TUNE_GEMM_YIELD: ok = value <= 32; break;
+  }
+  if (!ok) return OFB_EINVAL;
   h_tune[key] = value;
   return 0;
 }

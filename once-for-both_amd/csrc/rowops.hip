@@ -682,6 +682,7 @@ int ln_bwd_launch(const float* dy, const float* x, const float* gamma, const flo
                   float* partials, int rows, int D, char* dxP, const float* rowscale, int rs_div, hipStream_t s,
                   const float* rn = nullptr, int n_rn = 0, float rn_fac = 1.f) {
   const dim3 grid(ofb_layernorm_bwd_blocks(rows));
+  if (!rowscale || rs_div <= 0) rs_div = 1;                 // the kernels divide by it unconditionally; without a rowscale any value was legal
   ofb_prof_pre(3, s, (dxP ? 24.0 : 16.0) * rows * (double)D);
   // per-block maxima of the bound pass: the last 8 KB of the plane buffer (its slack past the matrix: never read as values)
   const float* stat = dxP ? reinterpret_cast<float*>(dxP + ofb_hformat_bytes(rows, D) - 8192) : nullptr;

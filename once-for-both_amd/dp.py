@@ -293,3 +293,46 @@ def average_scalars(tensors, process_group=None):
         out.append(flat[off:off + t.numel()].view_as(t))
         off += t.numel()
     return out
+
+
+class DistributedDataParallel(torch.nn.Module):
+    """The `.module`-exposing wrapper the reference's drivers swap in (`search.py:617-620`, `finetune.py:421-424`:
+    `model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[args.gpu], find_unused_parameters=True)`,
+    `model_without_ddp = model.module`, then `model.module.reset_mask_ratio(...)`, `model.module.get_flops()`, ... `:644-645,743,754`).
+
+    Same constructor surface for the arguments those call sites pass; the exchange itself is a `GradAllReducer` (persistent flat
+    buckets, asynchronous RCCL all-reduce from post-accumulate hooks) that the epoch engines pick up from `model.reducer` -
+    `engine.search_one_epoch(model, ...)` / `train_one_epoch(model, ...)` then finalize the exchange after every backward and
+    rebuild the buckets after `compress()` (which the reference's DDP silently does not, SURVEY D-6).  A hand-written loop calls
+    `model.reducer.finalize()` after `backward()`.  `state_dict()` keys carry the `module.` prefix, as torch's wrapper's do."""
+
+    def __init__(self, module, device_ids=None, output_device=None, dim=0, broadcast_buffers=True, process_group=None,
+                 bucket_cap_mb=25, find_unused_parameters=False, check_reduction=False, gradient_as_bucket_view=False,
+                 static_graph=False, first_bucket_bytes=4 * 1024 * 1024, force_collective=False):
+        super().__init__()
+        self.module = module
+        self.device_ids, self.output_device, self.find_unused_parameters = device_ids, output_device, find_unused_parameters
+        self.reducer = GradAllReducer(module.parameters(), bucket_bytes=int(bucket_cap_mb * 1024 * 1024), process_group=process_group,
+                                      force_collective=force_collective, first_bucket_bytes=first_bucket_bytes)
+
+    def forward(self, *inputs, **kwargs):
+        return self.module(*inputs, **kwargs)
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d['reducer'] = None                              # hooks and buckets are per-process state, not checkpoint content
+        return d
+
+    def no_sync(self):
+        """torch DDP's context manager: backward passes inside it only accumulate locally."""
+        import contextlib
+
+        @contextlib.contextmanager
+        def ctx():
+            was = self.reducer.sync
+            self.reducer.sync = False
+            try:
+                yield
+            finally:
+                self.reducer.sync = was
+        return ctx()

@@ -138,6 +138,8 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
         raise NotImplementedError('apex AMP path is off in the reference workflow')
     model.train(set_training_mode)
     net = model.module if hasattr(model, 'module') else model
+    if reducer is None:
+        reducer = getattr(model, 'reducer', None)        # dp.DistributedDataParallel carries its own
     accum_iter = args.accum_iter
     n_iter = len(data_loader)
     for opt in (optimizer_param, optimizer_decoder, optimizer_arch):
@@ -234,6 +236,8 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
     if use_amp:
         raise NotImplementedError('apex AMP path is off in the reference workflow')
     model.train(set_training_mode)
+    if reducer is None:
+        reducer = getattr(model, 'reducer', None)        # dp.DistributedDataParallel carries its own
     accum_iter = args.accum_iter
     optimizer.zero_grad(set_to_none=True)
     n_iter, stats = len(data_loader), {}
@@ -281,23 +285,54 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
     return stats
 
 
-@torch.no_grad()
-def evaluate(data_loader, model, device):
-    """reference engine.py:222-257 / evaluate_finetune :260-290: top-1 / top-5 accuracy and CE loss in eval mode.
-    Works for the search model (returns (logits, aux)) and the finetune model (returns logits)."""
+def _evaluate(data_loader, model, device, use_amp, search_model, across_ranks):
+    """shared body of evaluate / evaluate_finetune.  The meters of the reference's MetricLogger (engine.py:246-249, :283-286) are
+    kept as ONE device vector - [sum of per-batch mean losses, batches, top-1 hits, top-5 hits, samples] - that the host reads once,
+    after the last batch (the reference reads three scalars per batch)."""
+    if use_amp:
+        raise NotImplementedError('apex / autocast evaluation is off in the reference workflow (search.py:726, finetune.py:461 pass use_amp=False)')
     model.eval()
-    n, loss_sum, c1, c5 = 0, 0.0, 0.0, 0.0
+    acc = None
     for images, target in data_loader:
         images, target = images.to(device, non_blocking=True), target.to(device, non_blocking=True)
-        out = model(images)
-        logits = out[0] if isinstance(out, tuple) else out
-        logp = torch.log_softmax(logits.float(), -1)                      # metric bookkeeping, not on the training path
-        loss_sum += float(-logp.gather(1, target.view(-1, 1)).sum())
-        top = logits.topk(min(5, logits.shape[1]), 1).indices
-        c1 += float((top[:, 0] == target).sum())
-        c5 += float((top == target.view(-1, 1)).any(1).sum())
-        n += target.numel()
-    return {'loss': loss_sum / max(n, 1), 'acc1': 100.0 * c1 / max(n, 1), 'acc5': 100.0 * c5 / max(n, 1)}
+        output = model(images)
+        if search_model and isinstance(output, tuple):          # engine.py:241 `output, _ = model(images)`
+            output = output[0]
+        output = output.float()
+        if output.is_cuda:
+            from . import ops
+            loss = ops.LabelSmoothingCE.apply(output, target, 0.0)            # torch.nn.CrossEntropyLoss(): mean NLL of the batch
+        else:
+            loss = torch.nn.functional.cross_entropy(output, target)
+        hit = output.topk(min(5, output.shape[1]), 1).indices == target.view(-1, 1)      # timm.utils.accuracy(topk=(1, 5))
+        one = torch.ones((), dtype=torch.float64, device=output.device)
+        row = torch.stack([loss.double(), one, hit[:, 0].sum().double(), hit.sum().double(), one * target.numel()])
+        acc = row if acc is None else acc + row
+    if acc is None:
+        acc = torch.zeros(5, dtype=torch.float64, device=device)
+    if across_ranks:                                            # engine.py:288 metric_logger.synchronize_between_processes() (C4)
+        from .dp import sum_across_ranks
+        acc, _ = sum_across_ranks(acc, getattr(getattr(model, 'reducer', None), 'group', None))
+    loss_sum, batches, c1, c5, n = acc.tolist()
+    # MetricLogger.global_avg: the loss meter is updated with n = 1 per batch (mean of the batch means), the accuracy meters with
+    # n = batch size (sample-weighted)
+    stats = {'loss': loss_sum / max(batches, 1.0), 'acc1': 100.0 * c1 / max(n, 1.0), 'acc5': 100.0 * c5 / max(n, 1.0)}
+    print('* Acc@1 {acc1:.3f} Acc@5 {acc5:.3f} loss {loss:.3f}'.format(**stats))
+    return stats
+
+
+@torch.no_grad()
+def evaluate(data_loader, model, device, use_amp=False):
+    """reference engine.py:222-257: top-1 / top-5 accuracy and CE loss of the SEARCH model (it returns (logits, aux)) in eval mode,
+    on this rank's loader only (the reference's rank reduction is commented out there, :253; search.py:725-726 calls it on rank 0)."""
+    return _evaluate(data_loader, model, device, use_amp, True, False)
+
+
+@torch.no_grad()
+def evaluate_finetune(data_loader, model, device, use_amp=False):
+    """reference engine.py:260-290: the same for the plain (pruned) ViT of finetune.py, whose forward returns the logits; the meters
+    are summed over the ranks (:288)."""
+    return _evaluate(data_loader, model, device, use_amp, False, True)
 
 
 def param_groups(model, weight_decay=1e-3):

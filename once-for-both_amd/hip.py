@@ -204,7 +204,13 @@ def to_hformat(x, R=None, Cc=None, ld=None, rowscale=None, rs_div=1, colsum_out=
         colsum(part, ldp, slabs, Cc, colsum_out)
         return pm
     if bound is not None and bound.numel() > 1:
-        raise OfbError('to_hformat: a vector bound is only taken together with colsum_out (ofb_to_hformat_colsum_nb)')
+        # a vector of partial maxima without a consumer for the column sums (a qkv layer without bias): the entry point that reduces
+        # the vector is the column-sum form; its partial sums land in a scratch buffer nobody reads
+        slabs, ldp = int(lib().ofb_colsum_h_slabs(_i(R))), pm.ncb * 16
+        part = torch.empty(slabs, ldp, device=x.device, dtype=torch.float32)
+        check(lib().ofb_to_hformat_colsum_nb(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(part), ptr(bound),
+                                             _i(bound.numel()), stream()), 'ofb_to_hformat_colsum_nb')
+        return pm
     check(lib().ofb_to_hformat(ptr(x), _i(R), _i(Cc), _i(ld), ptr(pm.buf), ptr(rowscale), _i(rs_div), ptr(bound), stream()), 'ofb_to_hformat')
     return pm
 

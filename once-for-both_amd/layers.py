@@ -75,8 +75,12 @@ class LayerNorm(nn.Module):
         self.weight = nn.Parameter(torch.ones(*normalized_shape))
         self.bias = nn.Parameter(torch.zeros(*normalized_shape))
 
-    def forward(self, x):
-        return ops.layer_norm(x, self.weight, self.bias, self.eps)
+    def reset_parameters(self):
+        nn.init.ones_(self.weight)
+        nn.init.zeros_(self.bias)
+
+    def forward(self, input):
+        return ops.layer_norm(input, self.weight, self.bias, self.eps)
 
     def extra_repr(self):
         return f'{self.normalized_shape}, eps={self.eps}'
@@ -150,6 +154,23 @@ class _Searchable:
 
     def get_alpha(self):
         return self.alpha, self.switch_cell.to(self.alpha.device)
+
+    def decompress(self):
+        """reference layers.py:340-343, 730-733, 1027-1030: re-open a finished module's search."""
+        self.execute_prune = False
+        self.alpha.requires_grad = True
+        self.finish_search = False
+
+    def _wm_sum(self):
+        """sum of this module's staircase (`self.weighted_mask.sum()` of the reference's FLOPs / parameter model); the staircase is
+        an output of the gate kernel of the last forward - a module that has not run yet computes its gate alone."""
+        if getattr(self, 'weighted_mask', None) is None:
+            self._single_gate()
+        return self.weighted_mask.sum()
+
+    def _embed_sum(self, default):
+        wme = getattr(self, 'weighted_mask_embed', None)
+        return default if wme is None else wme.sum()
 
     def gate_plan(self):
         """static + current description of this module's gate for ops.BiMaskGates."""
@@ -340,6 +361,20 @@ class MAEPatchEmbed(PatchEmbed, _Searchable):
         self.proj.weight = nn.Parameter(self.proj.weight.data * sc.view(-1, 1, 1, 1))
         self.proj.bias = nn.Parameter(self.proj.bias.data * sc)
 
+    def get_params_count(self):
+        """reference layers.py:345-352: (total, active, active width); `active*` are tensors that depend on alpha."""
+        dim1, dim2 = self.proj.in_channels, self.embed_dim
+        k = self.proj.kernel_size[0] * self.proj.kernel_size[1]
+        act = self._wm_sum()
+        return dim1 * dim2 * k + dim2 + dim2 * 2, dim1 * act * k + act + act * 2, act
+
+    def get_flops(self, num_patches):
+        """reference layers.py:354-360."""
+        total_params, active_params, act = self.get_params_count()
+        total = (total_params - self.embed_dim * 2) * num_patches + (4 * self.embed_dim + 1) * num_patches
+        active = (active_params - act * 2) * num_patches + (4 * act + 1) * num_patches
+        return total, active
+
     @staticmethod
     def from_patchembed(patchmodule, embed_search=True):
         return MAEPatchEmbed(patchmodule, embed_search)
@@ -370,6 +405,22 @@ class Attention(nn.Module):
     def forward(self, x):
         zero = torch.zeros_like(x)
         return self._branch(x, zero, None, None, self.num_heads)
+
+    def get_params_count(self):
+        """reference layers.py:396-402 (current, possibly pruned, shapes)."""
+        total = self.qkv.in_features * self.qkv.out_features + self.qkv.out_features
+        return total + self.proj.in_features * self.proj.out_features + self.proj.out_features
+
+    def get_flops(self, num_patches):
+        """reference layers.py:404-414: MACs of one pass over `num_patches` tokens."""
+        H, N = self.num_heads, num_patches
+        d = self.qkv.out_features // H // 3
+        e = self.proj.out_features
+        flops = N * (e * (3 * H * d)) + 3 * N * H * d           # qkv
+        flops += H * N * d * N + H * N * N                       # q @ k
+        flops += 5 * H * N * N                                   # softmax
+        flops += H * N * N * d                                   # attn @ v
+        return flops + N * (H * d * e) + N * e                   # proj
 
 
 class MAESparseAttention(Attention, _Searchable):
@@ -511,6 +562,24 @@ class MAESparseAttention(Attention, _Searchable):
         if self.qkv.bias is not None:
             self.qkv.bias = nn.Parameter(self.qkv.bias.data * sc)
 
+    def get_params_count(self):
+        """reference layers.py:735-745: (total, active)."""
+        dim, act_dim = self.in_features, self.qkv.in_features
+        wme = getattr(self, 'weighted_mask_embed', None)
+        act_e = wme.sum() if wme is not None and bool(((wme < 1) & (wme > 0)).any()) else act_dim
+        sd = self._wm_sum()
+        total = dim * dim * 3 + dim * 3 + dim * dim + dim
+        return total, act_e * sd * 3 + sd * 3 + sd * act_e + act_e
+
+    def get_flops(self, num_patches, active_patches):
+        """reference layers.py:747-766: (total, active) MACs; the active part is differentiable in alpha through the staircase sums."""
+        H, aH, N, n, d = self.num_heads, self.active_heads(), num_patches, active_patches, self.head_dim
+        sd, e = self._wm_sum(), self._embed_sum(self.qkv.in_features)
+        total = N * (H * d * (3 * H * d)) + 3 * N * H * d + H * N * d * N + H * N * N + 5 * H * N * N + H * N * N * d \
+            + N * (H * d * (H * d)) + N * H * d
+        active = n * (e * (3 * sd)) + 3 * n * sd + n * n * sd + aH * n * n + 5 * aH * n * n + n * n * sd + n * (sd * e) + n * e
+        return total, active
+
     @staticmethod
     def from_attn(attn_module, head_search=False, channel_search=False, attn_search=True):
         return MAESparseAttention(attn_module, head_search, channel_search, attn_search)
@@ -535,6 +604,15 @@ class Mlp(nn.Module):
 
     def forward(self, x):
         return self._branch(x, torch.zeros_like(x), None, None)
+
+    def get_params_count(self):
+        """reference layers.py:792-797."""
+        d1, d2, d3 = self.fc1.in_features, self.fc1.out_features, self.fc2.out_features
+        return d1 * d2 + d2 * d3 + d2 + d3
+
+    def get_flops(self, num_patches):
+        """reference layers.py:799-801."""
+        return self.get_params_count() * num_patches
 
 
 class MAESparseMlp(Mlp, _Searchable):
@@ -629,6 +707,17 @@ class MAESparseMlp(Mlp, _Searchable):
         sc = self.score.data.reshape(-1)
         self.fc1.weight = nn.Parameter(self.fc1.weight.data * sc.unsqueeze(-1))
         self.fc1.bias = nn.Parameter(self.fc1.bias.data * sc)
+
+    def get_params_count(self):
+        """reference layers.py:1032-1040: (total, active)."""
+        dim1, dim2 = self.in_features, self.hidden_features
+        act2, act_e = self._wm_sum(), self._embed_sum(self.fc1.in_features)
+        return 2 * (dim1 * dim2) + dim1 + dim2, act_e * act2 + act2 * act_e + act_e + act2
+
+    def get_flops(self, num_patches, active_patches):
+        """reference layers.py:1042-1044."""
+        total, active = self.get_params_count()
+        return total * num_patches, active * active_patches
 
     @staticmethod
     def from_mlp(mlp_module, mlp_search=True):

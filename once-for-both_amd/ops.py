@@ -223,9 +223,22 @@ _RN_HANDOVER = os.environ.get('OFB_RN_HANDOVER', '1') != '0'
 
 
 def _put_rn(dx, rn):
+    # The entry HOLDS dx: while it is parked nothing can free the gradient and hand its address to another tensor, and autograd
+    # cannot accumulate into it in place without moving its version - that is what makes the (data_ptr, version) match in _take_rn
+    # sound.  The price is that an entry nobody takes (LayerNorm fell back to its f32 kernel, `y` had a second consumer so autograd
+    # summed into a new tensor, an exception mid-backward) would pin an M x D gradient: every LayerNorm backward drops the entry of
+    # its dy whether it used it or not, and the tables are emptied at the start of every forward pass (_drop_handovers).
     if len(_rn) >= 4:
         _rn.clear()
     _rn[dx.data_ptr()] = (dx, dx._version, rn)
+
+
+def _drop_handovers():
+    _rn.clear()
+    _grad_p.clear()
+
+
+hip._forward_hooks.append(_drop_handovers)
 
 
 def _take_rn(dy, rows, D):
@@ -290,7 +303,9 @@ class LayerNorm(torch.autograd.Function):
             rowscale = ctx.up[0]
             part = _new(x, nb, 3 * D)
             dxP = hip.HMat.for_rows_written_by_kernel(rows, D, x.device)
-            rn = _take_rn(dy, rows, D) if dres is None else None
+            rn = _take_rn(dy, rows, D)                     # (always taken out of the table: see _put_rn)
+            if dres is not None:
+                rn = None
             if rn is not None:                             # the GEMM that produced dy left the bound's ingredients (see _rn above)
                 hip.layernorm_bwd_h_rn(dy, x, gamma, mean, rstd, dx, part, dxP, rowscale, _rs_div(rowscale, rows), rows, D, rn[0], rn[1])
             else:
@@ -300,6 +315,7 @@ class LayerNorm(torch.autograd.Function):
             _ln_colsum(part, 3 * D, nb, dgb, ctx)
             _put_grad_p(dx, dxP, dgb[2 * D:], rowscale)
             return dx, dgb[:D], dgb[D:2 * D], None, None, None
+        _rn.pop(dy.data_ptr(), None)                       # a row-norm hand-over parked for this dy has no taker on the f32 path
         part = _new(x, nb, 2 * D)
         hip.layernorm_bwd(_c(dy), x, gamma, mean, rstd, _c(dres) if dres is not None else None, dx, part, rows, D)
         dgb = _new(x, 2 * D)

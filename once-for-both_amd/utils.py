@@ -162,3 +162,116 @@ def install_reference_aliases():
             sys.modules.setdefault(name, types.ModuleType(name))
         sys.modules['timm.models.layers.drop'].DropPath = DropPath
         sys.modules['timm.models.layers'].DropPath = DropPath
+
+
+# ---- process-group contract of the drivers (reference utils.py:177-244; SURVEY 5: one process per GPU, env:// rendezvous) ---------
+def is_dist_avail_and_initialized():
+    return torch.distributed.is_available() and torch.distributed.is_initialized()
+
+
+def get_world_size():
+    return torch.distributed.get_world_size() if is_dist_avail_and_initialized() else 1
+
+
+def get_rank():
+    return torch.distributed.get_rank() if is_dist_avail_and_initialized() else 0
+
+
+def is_main_process():
+    return get_rank() == 0
+
+
+def save_on_master(*args, **kwargs):
+    """`torch.save` on rank 0 only (search.py:674,713,734,784; finetune.py:450,470)."""
+    if is_main_process():
+        torch.save(*args, **kwargs)
+
+
+def setup_for_distributed(is_master):
+    """silence `print` on the other ranks unless called with force=True (reference utils.py:177-188)."""
+    import builtins
+    plain = builtins.print
+
+    def rank0_print(*args, **kwargs):
+        force = kwargs.pop('force', False)
+        if is_master or force:
+            plain(*args, **kwargs)
+
+    builtins.print = rank0_print
+
+
+def init_distributed_mode(args):
+    """reference utils.py:221-244: RANK / WORLD_SIZE / LOCAL_RANK from the launcher (or SLURM_PROCID), one process per GPU, backend
+    'nccl' (= RCCL over xGMI on this machine), `args.dist_url` rendezvous, a barrier, rank-0-only printing.  Fills in
+    args.rank / world_size / gpu / distributed / dist_backend."""
+    import os
+    if isinstance(getattr(args, 'gpu', None), str):      # the reference exports the --gpu list before anything touches the device
+        os.environ['CUDA_VISIBLE_DEVICES'] = args.gpu
+    if 'RANK' in os.environ and 'WORLD_SIZE' in os.environ:
+        args.rank, args.world_size, args.gpu = int(os.environ['RANK']), int(os.environ['WORLD_SIZE']), int(os.environ['LOCAL_RANK'])
+    elif 'SLURM_PROCID' in os.environ:
+        args.rank = int(os.environ['SLURM_PROCID'])
+        args.gpu = args.rank % torch.cuda.device_count()
+    else:
+        print('Not using distributed mode')
+        args.distributed = False
+        return
+    args.distributed = True
+    torch.cuda.set_device(args.gpu)
+    args.dist_backend = 'nccl'
+    print('| distributed init (rank {}): {}'.format(args.rank, args.dist_url), flush=True)
+    torch.distributed.init_process_group(backend=args.dist_backend, init_method=args.dist_url, world_size=args.world_size,
+                                         rank=args.rank)
+    torch.distributed.barrier()
+    setup_for_distributed(args.rank == 0)
+
+
+def _load_checkpoint_for_ema(model_ema, checkpoint):
+    """reference utils.py:167-174: hand an already-loaded checkpoint object to ModelEma._load_checkpoint (search.py:367)."""
+    import io
+    buf = io.BytesIO()
+    torch.save(checkpoint, buf)
+    buf.seek(0)
+    model_ema._load_checkpoint(buf)
+
+
+def get_grad_norm_(parameters, norm_type: float = 2.0):
+    """reference utils.py:317-330: norm of all gradients (a metric; one small reduction per tensor)."""
+    if isinstance(parameters, torch.Tensor):
+        parameters = [parameters]
+    grads = [p.grad.detach() for p in parameters if p.grad is not None]
+    if not grads:
+        return torch.tensor(0.)
+    if norm_type == float('inf'):
+        return max(g.abs().max() for g in grads)
+    return torch.norm(torch.stack([torch.norm(g, float(norm_type)) for g in grads]), float(norm_type))
+
+
+class NativeScalerWithGradNormCount:
+    """reference utils.py:282-314.  The drivers construct it and checkpoint its state (search.py:560,681; finetune.py:385,456) but
+    the fp32 epoch engines never scale with it (SURVEY D-8).  Kept with the same call contract on a scale of 1 (this path has no
+    reduced-precision autocast): backward, optional clipping, optimizer steps; `state_dict` has GradScaler's keys so that
+    checkpoints written by either side load in the other."""
+    state_dict_key = 'amp_scaler'
+
+    def __init__(self):
+        self._state = {'scale': 1.0, 'growth_factor': 2.0, 'backoff_factor': 0.5, 'growth_interval': 2000, '_growth_tracker': 0}
+
+    def __call__(self, loss, optimizer, clip_grad=None, parameters=None, create_graph=False, update_grad=True):
+        loss.backward(create_graph=create_graph)
+        if not update_grad:
+            return None
+        if clip_grad is not None:
+            assert parameters is not None
+            norm = torch.nn.utils.clip_grad_norm_(parameters, clip_grad)
+        else:
+            norm = get_grad_norm_(parameters)
+        for opt in (optimizer if isinstance(optimizer, list) else [optimizer]):
+            opt.step()
+        return norm
+
+    def state_dict(self):
+        return dict(self._state)
+
+    def load_state_dict(self, state_dict):
+        self._state.update(state_dict)

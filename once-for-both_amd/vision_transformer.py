@@ -52,6 +52,42 @@ class MAEBaseModel(nn.Module):
     def get_flops(self):
         raise NotImplementedError
 
+    # Generic forms of the two architecture losses over the per-module API (get_alpha / get_weight / get_flops), for subclasses that
+    # only provide that API.  MIMVisionTransformer overrides both: there all 25 modules' terms come out of ONE gate kernel.
+    def get_flops_loss(self, target_flops):
+        """reference base_model.py:31-35 (without its per-call print, SURVEY D-10)."""
+        total, searched = self.get_flops()
+        return (((searched - target_flops) / total) ** 2).mean()
+
+    @staticmethod
+    def _one_hot_terms(alpha, switch, entropy, var, per_cell):
+        """entropy + tan(pi/2 - pi * sigma / sigma_target) of softmax(alpha[live]) (base_model.py:41-50, 62-72)."""
+        n = int(switch.sum())
+        pr = torch.softmax(alpha[switch], dim=-1)
+        loss = -(pr * pr.log()).sum() if entropy else alpha.new_zeros(())
+        if var:
+            sigma = ((pr - pr.mean()) ** 2).sum() / (1.0 - 1.0 / n)
+            loss = loss + torch.tan(math.pi / 2 - math.pi * sigma) / (n if per_cell else 1)
+        return loss
+
+    def get_sparsity_loss(self, device, entropy=True, var=True, norm=True):
+        """reference base_model.py:37-86: (attention, MLP, patch, embedding) adaptive one-hot terms."""
+        zero = torch.zeros((), device=device)
+        sw_p = self.switch_cell_patch.to(device)
+        loss_patch = self._one_hot_terms(self.alpha_patch, sw_p, True, True, False) if int(sw_p.sum()) != 1 else zero.clone()
+        sums = {'attn': zero.clone(), 'mlp': zero.clone(), 'embed': zero.clone()}
+        for m in self.searchable_modules:
+            alpha, switch = m.get_alpha()
+            if int(switch.sum()) == 1:
+                continue
+            loss = self._one_hot_terms(alpha, switch, entropy, var, True)
+            is_attn = hasattr(m, 'num_heads')
+            if norm:
+                loss = loss + m.get_weight()[1].sum() * (4e-4 if is_attn else 1e-4)
+            key = 'attn' if is_attn else ('embed' if hasattr(m, 'embed_ratio_list') else 'mlp')
+            sums[key] = sums[key] + loss
+        return sums['attn'], sums['mlp'], loss_patch, sums['embed']
+
     def correct_require_grad(self, w_head, w_mlp, w_patch, w_embedding):
         for m in self.searchable_modules:
             is_attn, is_embed = hasattr(m, 'num_heads'), hasattr(m, 'embed_ratio_list')
@@ -61,8 +97,13 @@ class MAEBaseModel(nn.Module):
             self.alpha_patch.requires_grad = False
 
     def get_params(self):
+        """reference base_model.py:104-109: (trainable parameters, the same with every searchable module counted at its active size)."""
         total = sum(p.numel() for p in self.parameters() if p.requires_grad)
-        return total, total
+        searched = total
+        for m in self.searchable_modules:
+            cnt = m.get_params_count()
+            searched = searched - cnt[0] + cnt[1]
+        return total, searched.item() if isinstance(searched, torch.Tensor) else searched
 
 
 class Block(nn.Module):
@@ -87,6 +128,10 @@ class Block(nn.Module):
         y, xr = ops.layer_norm_fork(x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
         return self.mlp._branch(y, xr, None, self._row_scale(x))
 
+    def get_flops(self, num_patches):
+        """reference vision_transformer.py:162-170."""
+        return 2 * self.norm1.normalized_shape[0] * num_patches + self.attn.get_flops(num_patches) + self.mlp.get_flops(num_patches)
+
 
 class MAEBlock(nn.Module):
     """reference :173-220.  While the embed search is live the reference normalises the residual stream itself
@@ -105,6 +150,13 @@ class MAEBlock(nn.Module):
         self.norm2 = norm_layer(dim)
         mlp = Mlp(in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer, drop=drop)
         self.mlp = ModuleInjection.make_searchable_maemlp(mlp, mlp_search)
+
+    def __getstate__(self):
+        """checkpoint / deepcopy view: the embed staircase handed through the blocks is an autograd output of the last forward."""
+        d = self.__dict__.copy()
+        if isinstance(d.get('weighted_mask_embed'), torch.Tensor):
+            d['weighted_mask_embed'] = d['weighted_mask_embed'].detach()
+        return d
 
     def run(self, x, replace_stream, g_attn, g_mlp, rs_attn, rs_mlp):
         heads = self.attn.active_heads() if hasattr(self.attn, 'active_heads') else self.attn.num_heads
@@ -126,6 +178,18 @@ class MAEBlock(nn.Module):
         g_a = self.attn.current_gate() if hasattr(self.attn, 'current_gate') else None
         g_m = self.mlp.current_gate() if hasattr(self.mlp, 'current_gate') else None
         return self.run(x, replace, g_a, g_m, rs(), rs()), weighted_mask_embed
+
+    def get_flops(self, num_patches, active_patches):
+        """reference vision_transformer.py:207-220: (total, searched) MACs of this block."""
+        flops = 2 * self.in_feature * num_patches
+        searched = 2 * self.norm1.normalized_shape[0] * active_patches
+        for m in (self.attn, self.mlp):
+            if hasattr(m, 'finish_search'):
+                f, sf = m.get_flops(num_patches, active_patches)
+            else:
+                f = sf = m.get_flops(num_patches)
+            flops, searched = flops + f, searched + sf
+        return flops, searched
 
 
 class VisionTransformer(nn.Module):
@@ -160,9 +224,26 @@ class VisionTransformer(nn.Module):
         trunc_normal_(self.cls_token, std=.02)
         self.apply(_init_vit_weights)
 
+    def _init_weights(self, m):
+        _init_vit_weights(m)
+
     @torch.jit.ignore
     def no_weight_decay(self):
         return ['pos_embed', 'cls_token', 'dist_token']
+
+    def get_classifier(self):
+        return self.head
+
+    def reset_classifier(self, num_classes, global_pool=''):
+        """reference vision_transformer.py:315-319 (no distillation head on this path)."""
+        self.num_classes = num_classes
+        self.head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    def get_flops(self):
+        """reference vision_transformer.py:360-377: MACs of the (pruned) subnet from its CURRENT shapes; finetune.py:426 logs it."""
+        P, N, D = self.patch_embed.patch_size[0], self.patch_embed.num_patches, self.patch_embed.proj.out_channels
+        blocks = sum(b.get_flops(N) for b in self.blocks)
+        return N * D * 3 * P ** 2 + blocks + D * self.num_classes
 
     def forward_features(self, x):
         hip.begin_forward()                                  # planes of the weights are re-made by the first GEMM of this pass
@@ -291,6 +372,20 @@ class MIMVisionTransformer(MAEBaseModel):
     def get_classifier(self):
         return self.head
 
+    def reset_classifier(self, num_classes, global_pool=''):
+        """reference vision_transformer.py:566-570."""
+        self.num_classes = num_classes
+        self.head = nn.Linear(self.embed_dim, num_classes) if num_classes > 0 else nn.Identity()
+
+    def _init_weights(self, m):
+        _init_vit_weights(m)
+
+    def patch_masking(self, x):
+        """reference vision_transformer.py:586-612 as a stand-alone call: (x with the removed patches zeroed, mask) - the fused forward
+        folds the same mask into the token assembly kernel instead (`patch_masking_mask`)."""
+        mask = self.patch_masking_mask(x.shape[0], x.device)
+        return (x, None) if mask is None else (x * (1.0 - mask).unsqueeze(-1), mask)
+
     # ---- gates (all searchable modules, one launch) ---------------------------------------------
     def _live_modules(self):
         return [m for m in self.searchable_modules if not m.finish_search]
@@ -361,6 +456,12 @@ class MIMVisionTransformer(MAEBaseModel):
         # the reference tests the embed staircase for entries strictly inside (0,1) on the device every block
         # (:193); that is equivalent to "more than one embed cell is still on", which is host state.
         replace = (not pe.finish_search) and int(pe.switch_cell.sum()) > 1 if hasattr(pe, 'switch_cell') else False
+        # what the reference hands through the blocks as `weighted_mask_embedding` (:617-624) and every module keeps for its FLOPs /
+        # parameter model (layers.py:735-766,1032-1040): the restored embed staircase while that search is live, else the kept mask
+        if hasattr(pe, 'switch_cell'):
+            wme = pe._wr_view() if not pe.finish_search else getattr(pe, 'weighted_mask', None)
+            for blk in self.blocks:
+                blk.weighted_mask_embed = blk.attn.weighted_mask_embed = blk.mlp.weighted_mask_embed = wme
         depth = len(self.blocks)
         rates = [float(getattr(b.drop_path, 'drop_prob', 0.0)) for b in self.blocks]
         u = None

@@ -789,3 +789,54 @@ def fuse_params(cfg: Config, p, st: SearchState):
         p[f'blocks.{i}.mlp.fc1.weight'] = p[f'blocks.{i}.mlp.fc1.weight'] * sc.unsqueeze(-1)
         p[f'blocks.{i}.mlp.fc1.bias'] = p[f'blocks.{i}.mlp.fc1.bias'] * sc
     st.fused = True
+
+
+# ----------------------------------------------------------------------------------------
+# evaluation meters (engine.py:222-290) and the FLOPs / parameter bookkeeping beside the loss
+# (vision_transformer.py:144-170,360-377; layers.py:345-360,396-414,735-766,792-801,1032-1044; base_model.py:104-109)
+# ----------------------------------------------------------------------------------------
+def evaluate_meters(batches):
+    """engine.py:234-257 / :271-290 for a list of (logits, labels) batches: `loss` is the mean over BATCHES of
+    CrossEntropyLoss()(logits, labels) (MetricLogger.update(loss=...) counts one per call, :246 / :283), `acc1` / `acc5` are the
+    sample-weighted means of timm's accuracy() percentages (meters updated with n = batch size, :247-248)."""
+    loss_sum, hits1, hits5, n = 0.0, 0, 0, 0
+    for logits, labels in batches:
+        logp = torch.log_softmax(logits.double(), -1)
+        loss_sum += float(-logp.gather(1, labels.view(-1, 1)).mean())
+        top = torch.argsort(logits, dim=1, descending=True, stable=True)[:, :min(5, logits.shape[1])]
+        hit = top == labels.view(-1, 1)
+        hits1, hits5, n = hits1 + int(hit[:, 0].sum()), hits5 + int(hit.sum()), n + labels.numel()
+    return {'loss': loss_sum / len(batches), 'acc1': 100.0 * hits1 / n, 'acc5': 100.0 * hits5 / n}
+
+
+def plain_vit_flops(embed, blocks, num_patches=196, patch=16, num_classes=1000):
+    """VisionTransformer.get_flops() (vision_transformer.py:360-377) of a plain / pruned ViT.  blocks: [(heads, head_dim, hidden)];
+    per block Block.get_flops (:162-170) = LayerNorm 2 D N + Attention.get_flops (layers.py:404-414) + Mlp.get_flops (:799-801)."""
+    N, D = num_patches, embed
+    total = N * D * 3 * patch ** 2 + D * num_classes
+    for H, d, hid in blocks:
+        total += 2 * D * N
+        total += N * (D * 3 * H * d) + 3 * N * H * d + H * N * d * N + H * N * N + 5 * H * N * N + H * N * N * d + N * (H * d * D) + N * D
+        total += (D * hid + hid * D + hid + D) * N
+    return total
+
+
+def module_counts(cfg: Config, gates, name, num_patches, active_patches, heads=None):
+    """(params (total, active), flops (total, active)) of one searchable module from the staircases `gates[...][2]` of the current
+    forward: MAEPatchEmbed layers.py:345-360 (it also returns its active width), MAESparseAttention :735-766, MAESparseMlp :1032-1044.
+    The embed staircase of the SAME forward is what the blocks receive as weighted_mask_embed (vision_transformer.py:617-624)."""
+    D, H, d, hid, P2 = cfg.embed_dim, cfg.num_heads, cfg.head_dim, cfg.hidden, cfg.patch_size ** 2
+    N, n = num_patches, active_patches
+    e = gates['patch_embed'][2].sum()
+    if name == 'patch_embed':
+        tp, ap = 3 * D * P2 + D + D * 2, 3 * e * P2 + e + e * 2
+        return (tp, ap, e), ((tp - 2 * D) * N + (4 * D + 1) * N, (ap - 2 * e) * N + (4 * e + 1) * N)
+    wm = gates[name][2].sum()
+    if name.endswith('attn'):
+        aH = H if heads is None else heads
+        tp, ap = D * D * 3 + D * 3 + D * D + D, e * wm * 3 + wm * 3 + wm * e + e
+        tf = N * (H * d * 3 * H * d) + 3 * N * H * d + H * N * d * N + H * N * N + 5 * H * N * N + H * N * N * d + N * (H * d * H * d) + N * H * d
+        af = n * (e * 3 * wm) + 3 * n * wm + n * n * wm + aH * n * n + 5 * aH * n * n + n * n * wm + n * (wm * e) + n * e
+        return (tp, ap), (tf, af)
+    tp, ap = 2 * D * hid + D + hid, e * wm + wm * e + e + wm
+    return (tp, ap), (tp * N, ap * n)

@@ -140,3 +140,35 @@ def test_attention_branch_planes(B, N):
         err = (t.grad.cpu().double() - r.grad).abs().max().item() / (r.grad.abs().max().item() + 1e-30)
         print(f'  {name}: rel err {err:.2e}')
         assert err < 2e-5, name
+
+
+def test_attention_branch_without_qkv_bias():
+    """`Attention`, `Block` and `MAEBlock` default to qkv_bias=False (reference layers.py:369, vision_transformer.py:145,174): the backward
+    then has no consumer for the column sums of dq|dk|dv but still hands the per-workgroup maxima to the conversion pass
+    (that combination raised)."""
+    from ofb_amd import ops
+    B, N, H, dh, D = 3, 197, 2, 32, 64
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, N, D, generator=g)
+    wq = torch.randn(3 * H * dh, D, generator=g) * 0.1
+    wp, bp = torch.randn(D, H * dh, generator=g) * 0.1, torch.randn(D, generator=g) * 0.1
+    dout = torch.randn(B, N, D, generator=g)
+    tens = [t.cuda().requires_grad_(True) for t in (x, wq, wp, bp)]
+    out = ops.attn_branch(tens[0], None, tens[1], None, tens[2], tens[3], None, None, H, dh ** -0.5)
+    out.backward(dout.cuda())
+    ref = [t.double().requires_grad_(True) for t in (x, wq, wp, bp)]
+    qkv = (ref[0] @ ref[1].t()).reshape(B, N, 3, H, dh).permute(2, 0, 3, 1, 4)
+    att = torch.softmax(qkv[0] @ qkv[1].transpose(-2, -1) * dh ** -0.5, -1) @ qkv[2]
+    o_ref = ref[0] + att.transpose(1, 2).reshape(B, N, H * dh) @ ref[2].t() + ref[3]
+    o_ref.backward(dout.double())
+    assert (out.detach().cpu().double() - o_ref.detach()).abs().max().item() < 1e-5
+    for t, r, name in zip(tens, ref, ('dx', 'dWqkv', 'dWproj', 'dbproj')):
+        err = (t.grad.cpu().double() - r.grad).abs().max().item() / (r.grad.abs().max().item() + 1e-30)
+        assert err < 2e-5, name
+    # and through the module API with the reference's default constructor arguments
+    import ofb_amd
+    blk = ofb_amd.Block(D, H).cuda()
+    assert blk.attn.qkv.bias is None
+    y = blk(tens[0].detach().requires_grad_(True))
+    y.sum().backward()
+    assert torch.isfinite(blk.attn.qkv.weight.grad).all()

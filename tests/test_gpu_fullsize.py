@@ -1,6 +1,7 @@
 """BASELINE configs[1]-[4] at FULL size (DeiT-S bs 128; the same under a one-rank RCCL exchange with the default 25-MB buckets;
-DeiT-B bs 64; the pruned finetune subnet at bs 256): the oracle cannot run these in seconds, so the HIP step is checked through
-size-independent properties - run-to-run bit-identity (every reduction has a fixed order), batch-chunk consistency of the
+DeiT-B bs 64; the pruned finetune subnet at bs 256).  configs[1] - the size the metric is quoted on - is compared with the fp64 oracle
+ELEMENT by element (the oracle walks the batch in chunks: tests/fullsize_util.py, ~1 minute of host time, once); all four are checked
+through size-independent properties - run-to-run bit-identity (every reduction has a fixed order), batch-chunk consistency of the
 forward, and central finite differences of the full loss with respect to parameters."""
 import pytest
 import torch
@@ -30,6 +31,74 @@ def _loss(m, crit, imgs, labels):
     logits, (dec, _) = m(imgs)
     base, arch = crit(imgs, logits, labels, m, 'arch', 1.0, False)
     return base + arch + (base / dec).detach() * dec, logits
+
+
+def elementwise_report(got, ref, rel=1e-3, floor_bits=20):
+    """the two per-tensor measures of VERDICT r5 #2: norm-wise ||a - b|| / ||b||, and the worst element against the bound
+    |a - b| <= rel * |b| + 2^-floor_bits * max|b| (returned as a fraction of the bound: <= 1 passes)."""
+    a, b = got.double().reshape(-1), ref.double().reshape(-1)
+    diff = (a - b).abs()
+    bound = rel * b.abs() + 2.0 ** -floor_bits * float(b.abs().max())
+    return float(diff.norm() / (b.norm() + 1e-300)), float((diff / bound).max())
+
+
+def test_deit_small_bs128_matches_the_fp64_oracle_element_by_element():
+    """configs[1] at the size `bench.py` times: one search micro-step of DeiT-S at batch 128 (epoch-0 state: w_p 0.99, keep ratio 0.95,
+    DropPath 0.1, random-normal images, the constructor's random initialisation with a non-zero classifier so that both losses send
+    gradients into the trunk) against the fp64 oracle on the same parameters and inputs.  Every gradient tensor must meet (a) the
+    norm-wise 1e-3 of north_star AND (b) the element-wise bound |a - b| <= 1e-3 |b| + 2^-20 max|b|; the weight gradients fed by the
+    two plane tensors that DESIGN section 3 lists as mostly below the H-format window (`dH` -> fc1.weight / fc1.bias, the LayerNorm-backward
+    planes -> proj / fc2 / qkv weights) are also checked per group of 128 rows."""
+    import time
+    from oracle import ofb_oracle as O
+    from ofb_amd.layers import trunc_normal_
+    from tests.fullsize_util import chunked_oracle_step
+    m, crit, imgs, labels = _setup()
+    with torch.no_grad():
+        trunc_normal_(m.head.weight, std=.02)                # (the constructor zeroes it: a pretrained classifier is not zero)
+    m.train()
+    total, logits = _loss(m, crit, imgs, labels)
+    total.backward()
+    torch.cuda.synchronize()
+    cfg = O.Config(**O.DEIT_SMALL, num_classes=1000, drop_path_rate=0.1)
+    st = O.SearchState(w_p=0.99, keep_ratio=0.95)
+    assert abs(m.patch_ratio_list[0] - 0.95) < 1e-12 and all(abs(x.w_p - 0.99) < 1e-12 for x in m.searchable_modules)
+    p = {k: v.detach().cpu().double().requires_grad_(k != 'alpha_patch') for k, v in m.state_dict().items()}
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, __import__('os').cpu_count() or 16))
+    t0 = time.time()
+    try:
+        ref = chunked_oracle_step(cfg, p, st, imgs.cpu().double(), labels.cpu(), m._forced['patch_noise'].cpu().double(),
+                                  m._forced['droppath_u'].cpu().double(), chunk=16)
+    finally:
+        torch.set_num_threads(threads)
+    print(f'fp64 oracle, DeiT-S bs 128 in chunks of 16: {time.time() - t0:.1f} s on the host')
+    lg_n, lg_e = elementwise_report(logits.detach().cpu(), ref['logits'])
+    print(f'logits: norm-wise {lg_n:.2e}, worst element {lg_e:.3f} of its bound')
+    assert lg_n < 1e-4 and lg_e <= 1.0
+    got_total = float(total.detach())
+    assert abs(got_total - float(ref['loss_total'])) <= 1e-4 * abs(float(ref['loss_total'])), (got_total, float(ref['loss_total']))
+    worst_n, worst_e, worst_g = (0.0, ''), (0.0, ''), (0.0, '')
+    checked = 0
+    for k, prm in m.named_parameters():
+        rg = p[k].grad
+        if rg is None or float(rg.norm()) < 1e-12 or k.endswith('qkv.bias'):       # (k third of a qkv bias gradient: a mathematical zero)
+            continue
+        g = prm.grad.detach().cpu()
+        n_err, e_err = elementwise_report(g, rg)
+        checked += 1
+        worst_n = max(worst_n, (n_err, k))
+        worst_e = max(worst_e, (e_err, k))
+        assert n_err < 1e-3, (k, n_err)
+        assert e_err <= 1.0, (k, e_err)
+        if g.dim() == 2 and g.shape[0] % 128 == 0 and any(t in k for t in ('fc1.weight', 'fc2.weight', 'proj.weight', 'qkv.weight')):
+            a, b = g.double().view(-1, 128, g.shape[1]), rg.view(-1, 128, g.shape[1])
+            grp = (a - b).flatten(1).norm(dim=1) / b.flatten(1).norm(dim=1).clamp_min(1e-300)
+            worst_g = max(worst_g, (float(grp.max()), k))
+            assert float(grp.max()) < 1e-3, (k, float(grp.max()))
+    assert checked > 180, checked
+    print(f'{checked} gradient tensors; worst norm-wise {worst_n[0]:.2e} ({worst_n[1]}); worst element {worst_e[0]:.3f} of its bound '
+          f'({worst_e[1]}); worst 128-row group of a weight gradient {worst_g[0]:.2e} ({worst_g[1]})')
 
 
 def test_full_size_step_is_bit_reproducible():

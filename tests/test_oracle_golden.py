@@ -105,3 +105,34 @@ def test_keep_mask_counts():
     for keep in (0.95, 0.75):
         m = O.keep_mask_from_noise(n, int(196 * keep))
         assert m.sum(1).tolist() == [196 - int(196 * keep)] * 4
+
+
+def test_chunked_oracle_step_equals_the_one_shot_step():
+    """tests/fullsize_util.chunked_oracle_step (the fp64 oracle over a batch it cannot hold at once: the bs-128 parity test of
+    tests/test_gpu_fullsize.py) is the same function of the parameters as O.search_step_loss: every gradient to fp64 rounding."""
+    from oracle import fill
+    from tests.fullsize_util import chunked_oracle_step
+    cfg = O.Config(**O.MICRO, drop_path_rate=0.1)
+    st = O.SearchState(w_p=0.8, keep_ratio=0.85)
+    B = 5
+    imgs, labels = torch.from_numpy(fill.images(B)).double(), torch.from_numpy(fill.labels(B, cfg.num_classes))
+    noise, u = torch.from_numpy(fill.patch_noise(B, cfg.num_patches)).double(), torch.from_numpy(fill.droppath_noise(2 * cfg.depth, B)).double()
+
+    def params():
+        p = {k: v.requires_grad_(True) for k, v in O.formula_params(cfg, torch.float64).items()}
+        p['alpha_patch'].requires_grad_(False)
+        return p
+
+    p1 = params()
+    ref = O.search_step_loss(cfg, p1, st, imgs, labels, noise, u)
+    ref['loss_total'].backward()
+    p2 = params()
+    got = chunked_oracle_step(cfg, p2, st, imgs, labels, noise, u, chunk=2)
+    for k in ('base', 'arch', 'decoder_loss', 'loss_total'):
+        assert abs(float(got[k]) - float(ref[k].detach())) < 1e-12 * max(1.0, abs(float(ref[k].detach()))), k
+    assert float((got['logits'] - ref['logits'].detach()).abs().max()) < 1e-12
+    for k in p1:
+        if p1[k].grad is None:
+            assert p2[k].grad is None, k
+            continue
+        assert float((p1[k].grad - p2[k].grad).abs().max()) <= 1e-11 * max(1e-30, float(p1[k].grad.abs().max())), k
