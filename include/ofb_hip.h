@@ -30,6 +30,14 @@ extern "C" {
 /* the forward saves the DERIVATIVE (it has Phi and phi in hand already), the backward epilogue is one multiply */
 #define OFB_ACT_GELU_GRAD 3 /* aux <- gelu_erf'(pre) (aux required), C <- gelu_erf(pre)       */
 #define OFB_ACT_MULAUX 4    /* C <- value * aux[m][n]                                         */
+/* the same pair with aux in "T-layout" (ofb_gemm_h_aux_t_floats(M, N) floats, 16-byte aligned; ldaux unused): the saved derivative only
+ * ever travels from the epilogue of the product that computes gelu(..) to the epilogue of the product that forms the gradient of the
+ * pre-activation - two ofb_gemm_h launches with the same [M][N] - so it may be stored the way a wave of the 128 x 192 tile holds its
+ * accumulators (csrc/gemm_h.hip: aux_t_index).  With an H-format-only output and no row scale / residual these forms take the DIRECT
+ * epilogue: planes and aux move straight between the accumulator registers and memory (no LDS pass) and the next tile's first
+ * stages are requested underneath.  The layout is private to ofb_gemm_h: pass the buffer from one launch to the other, nothing else. */
+#define OFB_ACT_GELU_GRAD_T 5
+#define OFB_ACT_MULAUX_T 6
 
 /* ---------------------------------------------------------------------------------------------
  * Dense f32-class contraction on the f16 matrix pipe (csrc/gemm_h.hip, csrc/hformat.h):
@@ -103,6 +111,7 @@ typedef struct ofb_gemm_h_args {
 } ofb_gemm_h_args;
 int32_t ofb_gemm_h_rn_tiles(const ofb_gemm_h_args* args, int32_t* col_tiles);   /* entries of rn_out (0: this shape should not ask for it); *col_tiles = tiles along N */
 int32_t ofb_gemm_h_colpart_rows(const ofb_gemm_h_args* args);
+int64_t ofb_gemm_h_aux_t_floats(int32_t M, int32_t N);       /* floats of a T-layout aux tensor for an [M][N] output (OFB_ACT_*_T) */
 int64_t ofb_hformat_bytes(int32_t R, int32_t C);
 /* bound (optional device scalar >= max |X * rowscale|): skips the statistics pass that otherwise measures amax / row norms first */
 int ofb_to_hformat(const float* X, int32_t R, int32_t C, int32_t ld, void* P, const float* rowscale, int32_t rs_div, const float* bound,
@@ -129,9 +138,10 @@ int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream);
                                   padded-columns model of rounds 3-4, 128 = forced */
 #define OFB_TUNE_GEMM_T112 3   /* OFB_GEMM_H_T112: 1 = the 112 x 192 tile for token-row products whose 128-row tiles fill between half a round and one round; 0 (default) = off: measured slower, profiles/r05_gemm_tile_112.txt */
 #define OFB_TUNE_GEMM_YIELD 4  /* OFB_GEMM_H_YIELD: n in 1..7 = in single-round launches the first-dispatched workgroup of a CU that holds two sleeps 128 n cycles at each stage hand-over (default 4; 0 = off) */
-#define OFB_TUNE_COUNT 5
+#define OFB_TUNE_GEMM_DIRECT 5 /* OFB_GEMM_H_DIRECT: 1 (default) = the T-layout activation forms take the direct epilogue on interior tiles; 0 = every tile parks in LDS (same results) */
+#define OFB_TUNE_COUNT 6
 /* A value set here - 0 included - beats the environment variable of the same key.  OFB_EINVAL for a value outside the key's set
- * (MFMA: 16 | 32; SCHED: 0..2; TILE: 0 | 96 | 97 | 128; T112: 0 | 1; YIELD: 0..32).  Process-wide and unsynchronised: do not change a
+ * (MFMA: 16 | 32; SCHED: 0..2; TILE: 0 | 96 | 97 | 128; T112: 0 | 1; YIELD: 0..32; DIRECT: 0 | 1).  Process-wide and unsynchronised: do not change a
  * switch between ofb_gemm_h_rn_tiles / ofb_gemm_h_workspace_bytes and the ofb_gemm_h call they size buffers for (the tile choice
  * decides both), nor from a second thread while GEMMs are being launched. */
 int ofb_tune(int32_t key, int32_t value);

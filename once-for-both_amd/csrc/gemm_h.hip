@@ -330,21 +330,38 @@ __global__ __launch_bounds__(256) void colsum_h_kernel(const char* __restrict__ 
 // ---- the GEMM -----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ int swz(int tg) { return ((tg >> 1) & 3) << 1; }
 
+// T-layout of the aux tensor (OFB_ACT_GELU_GRAD_T / OFB_ACT_MULAUX_T; include/ofb_hip.h): the saved GELU derivative travels only from
+// the fc1 product's epilogue to the epilogue of the product that forms dH - two launches of this kernel with the same output shape -
+// so it is kept the way a wave of the 128 x 192 tile holds its accumulators: [tile (m / 128, n / 192)][wave 2 (r / 64) + (c / 96)]
+// [16 x 16 block (4 row x 6 column blocks of the wave)][lane 16 ((r % 16) / 4) + c % 16][r % 4].  One wave instruction then moves
+// 1 KB of it (16 bytes per lane, contiguous) straight between memory and the accumulators' registers: no trip through LDS.  Every
+// other epilogue form (parked tiles, the narrow form, the fix-up kernel) addresses the same layout element by element.
+__host__ __device__ __forceinline__ size_t aux_t_index(int row, int col, int nt192) {
+  const int tm = row >> 7, r = row & 63, tn = col / 192, c = col - tn * 192;
+  const int wq = (((row >> 6) & 1) << 1) + (c >= 96 ? 1 : 0), cc = c >= 96 ? c - 96 : c;
+  const int blk = (r >> 4) * 6 + (cc >> 4), ln = (((r & 15) >> 2) << 4) + (cc & 15);
+  return ((((size_t)tm * nt192 + tn) * 4 + wq) * 24 + blk) * 256 + ln * 4 + (r & 3);
+}
+__host__ __device__ __forceinline__ bool act_is_t(int act) { return act == OFB_ACT_GELU_GRAD_T || act == OFB_ACT_MULAUX_T; }
+__host__ __device__ __forceinline__ bool act_is_gelug(int act) { return act == OFB_ACT_GELU_GRAD || act == OFB_ACT_GELU_GRAD_T; }
+__host__ __device__ __forceinline__ bool act_is_mulaux(int act) { return act == OFB_ACT_MULAUX || act == OFB_ACT_MULAUX_T; }
+
 // v = alpha*acc (+bias)(*colscale); act; (*rowscale); (+resid)   -- the fix-up kernel's form of the fused epilogue
 __device__ __forceinline__ float epi_value(const ofb_gemm_h_args& g, float alpha, float accv, int row, int col, float bias, float cs, bool ok) {
   float v = (accv * alpha + bias) * cs;
+  const size_t ai = act_is_t(g.act) ? aux_t_index(row, col, (g.N + 191) / 192) : (size_t)row * g.ldaux + col;
   if (g.act == OFB_ACT_GELU) {
-    if (g.aux && ok) g.aux[(size_t)row * g.ldaux + col] = v;
+    if (g.aux && ok) g.aux[ai] = v;
     v = ofb_gelu(v);
-  } else if (g.act == OFB_ACT_GELU_GRAD) {
+  } else if (act_is_gelug(g.act)) {
     float Phi, phi;
     ofb_gelu_parts(v, Phi, phi);
-    if (ok) g.aux[(size_t)row * g.ldaux + col] = Phi + v * phi;
+    if (ok) g.aux[ai] = Phi + v * phi;
     v *= Phi;
   } else if (g.act == OFB_ACT_DGELU) {
-    v *= ofb_dgelu(ok ? g.aux[(size_t)row * g.ldaux + col] : 0.f);
-  } else if (g.act == OFB_ACT_MULAUX) {
-    v *= ok ? g.aux[(size_t)row * g.ldaux + col] : 0.f;
+    v *= ofb_dgelu(ok ? g.aux[ai] : 0.f);
+  } else if (act_is_mulaux(g.act)) {
+    v *= ok ? g.aux[ai] : 0.f;
   }
   if (g.rowscale) v *= ok ? g.rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
   if (g.resid) v += ok ? g.resid[(size_t)row * g.ldr + col] : 0.f;
@@ -411,7 +428,7 @@ __device__ __forceinline__ void vm_wait(int n) {           // n is wave-uniform
 
 // Epilogue forms are compile-time (EPI = set of E_* bits): with run-time flags hipcc has to assume that a side-input load may
 // follow an aliasing store and puts s_waitcnt vmcnt(0) between the stores of every element.
-enum : int { E_C = 1, E_P = 2, E_GELU = 4, E_DGELU = 8, E_RS = 16, E_RES = 32, E_ANY = 64, E_GELUG = 128, E_MULAUX = 256, E_RN = 512 };
+enum : int { E_C = 1, E_P = 2, E_GELU = 4, E_DGELU = 8, E_RS = 16, E_RES = 32, E_ANY = 64, E_GELUG = 128, E_MULAUX = 256, E_RN = 512, E_AUXT = 1024 };
 
 template <class CF, bool A_KC, bool B_KC, bool TAIL, int EPI>
 __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_h_args g, const Plan p) {
@@ -688,6 +705,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
   // W / 2 holds a tile too) sleeps 128 n cycles at every stage hand-over - it runs its units ~1.4x faster than its neighbour and
   // would otherwise finish early and leave the CU to the slower one: the launch ends when the LAST workgroup does
   const int ysl = (!TAIL && (int)blockIdx.x + (p.W >> 1) < p.ntiles) ? (p.stagger >> 4) & 7 : 0;
+  bool prefetched = false;                                // the unit's first stages were requested by the previous unit (direct epilogue)
   while (true) {
     const int nk16 = cur.it1 - cur.it0, nst = (nk16 + KH - 1) / KH;
     const bool last_full = nk16 == nst * KH;              // KH == 2: an odd number of K16 steps ends in a half stage
@@ -702,12 +720,19 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
     const char* a_base = Apl + (A_KC ? (size_t)(cur.m0 / 4) * a_ncb * GRAN : (size_t)(cur.m0 / 16) * GRAN) + cur.it0 * a_k16;
     const char* b_base = Bpl + (B_KC ? (size_t)(cur.n0 / 4) * b_ncb * GRAN : (size_t)(cur.n0 / 16) * GRAN) + cur.it0 * b_k16;
     OFB_HSTAMP(0);
-    __builtin_amdgcn_s_barrier();                        // every wave is past the previous unit's LDS traffic
-    issue(0, a_base, b_base);
-    if (nst > 1) issue(1, a_base + a_step, b_base + b_step);
-    if (NST > 2 && nst > 2) issue(2, a_base + 2 * a_step, b_base + 2 * b_step);
-    if (NST > 3 && nst > 3) issue(3, a_base + 3 * a_step, b_base + 3 * b_step);
-    vm_wait(((nst < NST ? nst : NST) - 1) * n_w);        // stage 0 landed; the other prologue stages may be in flight
+    if (prefetched) {
+      // the previous unit's direct epilogue requested this unit's first stages before it touched its accumulators (below); its stores
+      // are YOUNGER than those pieces and of a number only the compiler knows: wait for everything
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      prefetched = false;
+    } else {
+      __builtin_amdgcn_s_barrier();                      // every wave is past the previous unit's LDS traffic
+      issue(0, a_base, b_base);
+      if (nst > 1) issue(1, a_base + a_step, b_base + b_step);
+      if (NST > 2 && nst > 2) issue(2, a_base + 2 * a_step, b_base + 2 * b_step);
+      if (NST > 3 && nst > 3) issue(3, a_base + 3 * a_step, b_base + 3 * b_step);
+      vm_wait(((nst < NST ? nst : NST) - 1) * n_w);      // stage 0 landed; the other prologue stages may be in flight
+    }
     __builtin_amdgcn_s_barrier();
     OFB_HSTAMP(1);
     if constexpr (MF == 32) {
@@ -852,6 +877,94 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                       // the trailing (unused) fragment reads
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                         // (a half last stage leaves its own DMA unwaited)
     OFB_HSTAMP(2);
+    const Seg nxt = get_seg<TAIL>(p, v, sidx + 1, (int)blockIdx.x);
+
+    // DIRECT epilogue (the two products that write 8 bytes per output element: fc1 -> GELU planes + GELU', dH <- GELU' -> planes): a
+    // lane of a 16x16x32 accumulator block holds 4 consecutive rows of ONE column - exactly one 8-byte column slot of each H-format
+    // plane - and the saved derivative travels in T-layout (aux_t_index: 16 contiguous bytes per lane and block), so the whole
+    // epilogue runs from the accumulator registers: no LDS park, no read-back, no barriers.  LDS is then free while the epilogue
+    // runs: the NEXT unit's first stages are requested before the accumulators are touched (their DMA round trip hides under the
+    // epilogue's arithmetic and stores).  Row- and column-interior tiles only (whole tile inside the matrix); the others park.
+    constexpr bool DIRECT_CT = MF == 16 && !TAIL && CF::WM == 2 && WN == 2 && MB == 4 && NB == 6 && BMT == 128 && BN == 192 && NST == 2 &&
+                               (EPI == (E_P | E_GELUG | E_AUXT) || EPI == (E_P | E_MULAUX | E_AUXT));
+    bool direct_done = false;
+    if constexpr (DIRECT_CT) {
+      if ((p.stagger & 256) != 0 && cur.m0 + BMT <= g.M && cur.n0 + BN <= g.N) {
+        direct_done = true;
+        constexpr bool GELUG = (EPI & E_GELUG) != 0;
+        if (nxt.ok) {
+          const int n_nk16 = nxt.it1 - nxt.it0, n_nst = (n_nk16 + KH - 1) / KH;
+          const char* na = Apl + (A_KC ? (size_t)(nxt.m0 / 4) * a_ncb * GRAN : (size_t)(nxt.m0 / 16) * GRAN) + nxt.it0 * a_k16;
+          const char* nb = Bpl + (B_KC ? (size_t)(nxt.n0 / 4) * b_ncb * GRAN : (size_t)(nxt.n0 / 16) * GRAN) + nxt.it0 * b_k16;
+          __builtin_amdgcn_s_barrier();                             // every wave has read its last fragments: the stage buffers are free
+          issue(0, na, nb);
+          if (n_nst > 1) issue(1, na + a_step, nb + b_step);
+          prefetched = true;
+        }
+        const float so = ofb_h_pow2((p.stagger & 2) ? fold_e : reinterpret_cast<const ofb_hhdr*>(g.Cp)->e);
+        const int c16 = lane & 15, g4 = lane >> 4, nt192 = (g.N + 191) / 192;
+        char* Cpl = (char*)g.Cp + OFB_HHDR;
+        float* auxq = g.aux + ((size_t)(((cur.m0 >> 7) * nt192 + cur.n0 / BN) * 4 + w) * 24) * 256 + lane * 4;   // this lane's entries, 256 floats per block
+        float bv[NB], gv[NB];
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+          const int col = cur.n0 + wn0 + 16 * ni + c16;
+          bv[ni] = g.bias ? g.bias[col] : 0.f;
+          gv[ni] = g.colscale ? g.colscale[col] : 1.f;
+        }
+        f32x4 sa[2][MB];                                             // MULAUX: the saved derivative of column block ni, requested one block ahead
+        if constexpr (!GELUG) {
+#pragma unroll
+          for (int mi = 0; mi < MB; ++mi) sa[0][mi] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(auxq + (mi * NB) * 256));
+        }
+#pragma unroll
+        for (int ni = 0; ni < NB; ++ni) {
+          if constexpr (!GELUG) {
+            if (ni + 1 < NB) {
+#pragma unroll
+              for (int mi = 0; mi < MB; ++mi) sa[(ni + 1) & 1][mi] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(auxq + (mi * NB + ni + 1) * 256));
+            }
+          }
+          const int col = cur.n0 + wn0 + 16 * ni + c16;
+          float csum = 0.f;
+#pragma unroll
+          for (int mi = 0; mi < MB; ++mi) {
+            float o[4];
+            f32x4 ax;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float val = (acc[mi][ni][r] * alpha + bv[ni]) * gv[ni];
+              if constexpr (GELUG) {
+                float Phi, phi;
+                ofb_gelu_parts(val, Phi, phi);
+                ax[r] = Phi + val * phi;
+                val *= Phi;
+              } else {
+                val *= sa[ni & 1][mi][r];
+              }
+              o[r] = val;
+            }
+            if constexpr (GELUG) OFB_NT_STORE(ax, reinterpret_cast<f32x4*>(auxq + (mi * NB + ni) * 256));      // read by the backward only
+            unsigned h1a, h2a, h1b, h2b;
+            ofb_hsplit_pair(o[0] * so, o[1] * so, h1a, h2a);
+            ofb_hsplit_pair(o[2] * so, o[3] * so, h1b, h2b);
+            char* slot = Cpl + ((size_t)(((cur.m0 + wm0 + 16 * mi) >> 2) + g4) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            OFB_NT_STORE(((u32x2){h1a, h1b}), reinterpret_cast<u32x2*>(slot));
+            OFB_NT_STORE(((u32x2){h2a, h2b}), reinterpret_cast<u32x2*>(slot + 128));
+            csum += (o[0] + o[1]) + (o[2] + o[3]);
+          }
+          if (g.colpart) {
+            // column sums of the wave's 64 rows: the four lane groups hold four row quads of the column; the tile's two wave rows
+            // leave one partial row each (rows 2 tile, 2 tile + 1: ofb_gemm_h_colpart_rows counts them)
+            csum += __shfl_xor(csum, 16, 64);
+            csum += __shfl_xor(csum, 32, 64);
+            if (lane < 16) g.colpart[(size_t)(2 * (cur.m0 / BMT) + (w / WN)) * g.N + col] = csum;
+          }
+        }
+      }
+    }
+    if (!direct_done)
 
 #if OFB_LAB_ABLATE == 9                                   // lab: no epilogue at all (the accumulators are kept alive)
     if constexpr (MF == 16) {
@@ -877,7 +990,9 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
       constexpr bool ANY = (EPI & E_ANY) != 0;
       const bool has_c = ANY ? g.C != nullptr : (EPI & E_C) != 0, has_p = ANY ? g.Cp != nullptr : (EPI & E_P) != 0;
       const bool gelu = ANY ? g.act == OFB_ACT_GELU : (EPI & E_GELU) != 0, dg = ANY ? g.act == OFB_ACT_DGELU : (EPI & E_DGELU) != 0;
-      const bool gelug = ANY ? g.act == OFB_ACT_GELU_GRAD : (EPI & E_GELUG) != 0, mula = ANY ? g.act == OFB_ACT_MULAUX : (EPI & E_MULAUX) != 0;
+      const bool gelug = ANY ? act_is_gelug(g.act) : (EPI & E_GELUG) != 0, mula = ANY ? act_is_mulaux(g.act) : (EPI & E_MULAUX) != 0;
+      const bool auxt = ANY ? act_is_t(g.act) : (EPI & E_AUXT) != 0;           // the aux tensor is in T-layout (aux_t_index)
+      const int nt192 = (g.N + 191) / 192;
       const bool has_rs = ANY ? g.rowscale != nullptr : (EPI & E_RS) != 0, has_res = ANY ? g.resid != nullptr : (EPI & E_RES) != 0;
       // E_RN (rn_out): per tile, max over its rows of rn_rowfac[row] * |rn_gamma (.) output row, this tile's columns|_2 - what the
       // LayerNorm backward that consumes this gradient needs for the exponent of ITS output planes (rowops.hip: the bound pass it
@@ -962,8 +1077,19 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
             for (int tt = 0; tt < 4; ++tt) {
               const int row = row0 + tt;
               rsv[tt] = has_rs ? rowscale[g.rs_div == 1 ? row : row / g.rs_div] : 1.f;
-              if (dg || mula) sa[tt] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(auxr + (size_t)row * g.ldaux + col));   // last use of the saved derivative
+              if ((dg || mula) && !auxt) sa[tt] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(auxr + (size_t)row * g.ldaux + col));   // last use of the saved derivative
               if (has_res) sr[tt] = *reinterpret_cast<const f32x4*>(resid + (size_t)row * g.ldr + col);
+            }
+            if (mula && auxt) {
+              // T-layout: the item's four columns are four adjacent lanes' 16-byte entries (each: the four rows of one column)
+              const float* q = auxr + aux_t_index(row0, col, nt192);
+              f32x4 ft[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) ft[e] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(q + 4 * e));
+#pragma unroll
+              for (int tt = 0; tt < 4; ++tt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sa[tt][e] = ft[e][tt];
             }
             f32x4 o[4], ax[4];
 #pragma unroll
@@ -1007,7 +1133,11 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
             }
             if (OFB_LAB_ABLATE == 5) { asm volatile("" :: "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3])); if (gelu || gelug) asm volatile("" :: "v"(ax[0]), "v"(ax[1]), "v"(ax[2]), "v"(ax[3])); }
             if (live && OFB_LAB_ABLATE != 5) {
-              if (((gelu && auxw) || gelug) && OFB_LAB_ABLATE != 6) {
+              if (gelug && auxt && OFB_LAB_ABLATE != 6) {
+                float* q = auxw + aux_t_index(row0, col, nt192);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) OFB_NT_STORE(((f32x4){ax[0][e], ax[1][e], ax[2][e], ax[3][e]}), reinterpret_cast<f32x4*>(q + 4 * e));
+              } else if (((gelu && auxw) || gelug) && OFB_LAB_ABLATE != 6) {
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) OFB_NT_STORE(ax[tt], reinterpret_cast<f32x4*>(auxw + (size_t)(row0 + tt) * g.ldaux + col));   // read by the backward only
               }
@@ -1062,8 +1192,10 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
               float sum = 0.f;
 #pragma unroll
               for (int rg = 0; rg < HR / 4; ++rg) sum += (4 * rg < prow) ? S[rg * TLD + t] : 0.f;
-              float* cp = g.colpart + (size_t)(cur.m0 / BMT) * g.N + cur.n0 + t;
-              if (half == 0) *cp = sum; else *cp += sum;
+              // (a launch that may take the direct epilogue keeps TWO partial rows per tile: a parked tile fills the first, zeroes the second)
+              const bool two = DIRECT_CT && (p.stagger & 256) != 0;
+              float* cp = g.colpart + (size_t)((two ? 2 : 1) * (cur.m0 / BMT)) * g.N + cur.n0 + t;
+              if (half == 0) { *cp = sum; if (two) cp[g.N] = 0.f; } else *cp += sum;
             }
           }
         } else {
@@ -1092,18 +1224,19 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
                 const bool ok = colok && row < g.M;
                 const int rowc = row < g.M ? row : g.M - 1;
                 float val = (T[(4 * rgl + tt) * TLD + lcol] * alpha + biasv) * csv;
+                const size_t ai = auxt ? aux_t_index(rowc, colc, nt192) : (size_t)rowc * g.ldaux + colc;      // (== (row, col) wherever ok)
                 if (gelu) {
-                  if (auxw && ok) auxw[(size_t)row * g.ldaux + col] = val;
+                  if (auxw && ok) auxw[ai] = val;
                   val = ofb_gelu(val);
                 } else if (gelug) {
                   float Phi, phi;
                   ofb_gelu_parts(val, Phi, phi);
-                  if (ok) auxw[(size_t)row * g.ldaux + col] = Phi + val * phi;
+                  if (ok) auxw[ai] = Phi + val * phi;
                   val *= Phi;
                 } else if (dg) {
-                  val *= ofb_dgelu(auxr[(size_t)rowc * g.ldaux + colc]);
+                  val *= ofb_dgelu(auxr[ai]);
                 } else if (mula) {
-                  val *= auxr[(size_t)rowc * g.ldaux + colc];
+                  val *= auxr[ai];
                 }
                 if (has_rs) val *= rowscale[g.rs_div == 1 ? rowc : rowc / g.rs_div];
                 if (has_res) val += resid[(size_t)rowc * g.ldr + colc];
@@ -1140,8 +1273,10 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
               float sum = 0.f;
 #pragma unroll
               for (int ww = 0; ww < NW; ++ww) sum += T[ww * TLD + t];
-              float* cp = g.colpart + (size_t)(cur.m0 / BMT) * g.N + cur.n0 + t;
-              if (half == 0) *cp = sum; else *cp += sum;
+              // (a launch that may take the direct epilogue keeps TWO partial rows per tile: a parked tile fills the first, zeroes the second)
+              const bool two = DIRECT_CT && (p.stagger & 256) != 0;
+              float* cp = g.colpart + (size_t)((two ? 2 : 1) * (cur.m0 / BMT)) * g.N + cur.n0 + t;
+              if (half == 0) { *cp = sum; if (two) cp[g.N] = 0.f; } else *cp += sum;
             }
           }
         }
@@ -1153,7 +1288,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
       }
     }
     OFB_HSTAMP(3);
-    const Seg nxt = get_seg<TAIL>(p, v, ++sidx, (int)blockIdx.x);
+    ++sidx;
     if (!nxt.ok) break;
     cur = nxt;
   }
@@ -1230,7 +1365,7 @@ int h_cu_count() {
 }
 
 // Run-time switches (ofb_tune): -1 = not set yet (the environment variable of the same meaning is read once, then the default)
-int h_tune[OFB_TUNE_COUNT] = {-1, -1, -1, -1, -1};
+int h_tune[OFB_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1};
 int h_switch(int key, const char* env, int dflt) {
   if (h_tune[key] < 0) { const char* e = getenv(env); h_tune[key] = e ? atoi(e) : dflt; }
   return h_tune[key];
@@ -1268,6 +1403,14 @@ int h_tile_choice(const ofb_gemm_h_args& g) {
     }
   }
   return 128;
+}
+
+// the launch has the form of the direct epilogue (gemm_h_kernel: DIRECT_CT): planes out only, the saved derivative in T-layout, no row
+// scale / residual / row-norm request, the 128 x 192 tile on 16x16x32.  OFB_TUNE_GEMM_DIRECT / OFB_GEMM_H_DIRECT=0: every tile parks.
+bool h_direct_ok(const ofb_gemm_h_args& g) {
+  return act_is_t(g.act) && g.Cp && !g.C && !g.rowscale && !g.resid && !g.rn_out && g.aux && g.c_ncb * 16 >= g.N &&
+         h_switch(OFB_TUNE_GEMM_DIRECT, "OFB_GEMM_H_DIRECT", 1) != 0 && h_switch(OFB_TUNE_GEMM_MFMA, "OFB_GEMM_H_MFMA", 16) == 16 &&
+         h_tile_choice(g) == 128;
 }
 
 template <class CF>
@@ -1333,7 +1476,10 @@ Plan plan_h(const ofb_gemm_h_args& g) {
   const int yl = h_switch(OFB_TUNE_GEMM_YIELD, "OFB_GEMM_H_YIELD", 4);
   const bool balance1 = h_switch(OFB_TUNE_GEMM_SCHED, "OFB_GEMM_H_SPREAD", 2) >= 2 && p.R == 0 && p.full_rounds == 1 && p.ntiles < p.W && p.ntiles >= 8;
   const bool one_round = balance1 && 2 * p.ntiles > p.W && CF::WGS == 2 && p.W == h_cu_count() * 2;
-  p.stagger = (wide_ok ? 1 : 0) | (fold_ok ? 2 : 0) | (spread ? 8 : 0) | ((yl > 0 && one_round) ? ((yl > 7 ? 7 : yl) << 4) : 0) | (balance1 ? 128 : 0);
+  // bit 8: interior tiles of this launch take the direct epilogue (gemm_h_kernel: DIRECT_CT; h_direct_ok: the launch has the form)
+  const bool direct = std::is_same<CF, C128F>::value && p.R == 0 && h_direct_ok(g);
+  p.stagger = (wide_ok ? 1 : 0) | (fold_ok ? 2 : 0) | (spread ? 8 : 0) | ((yl > 0 && one_round) ? ((yl > 7 ? 7 : yl) << 4) : 0) | (balance1 ? 128 : 0) |
+              (direct ? 256 : 0);
   return p;
 }
 
@@ -1347,7 +1493,7 @@ int launch_h(const ofb_gemm_h_args& g, const Plan& p, hipStream_t s) {
   if ((g.Cp || g.cbound_out) && !(p.stagger & 2)) hipLaunchKernelGGL(gemm_h_bound_kernel, dim3(1), dim3(256), 0, s, g);
   if (p.full_rounds > 0) {
     const int f = (g.C ? E_C : 0) | (g.Cp ? E_P : 0) | (g.act == OFB_ACT_GELU ? E_GELU : 0) | (g.act == OFB_ACT_DGELU ? E_DGELU : 0) |
-                  (g.act == OFB_ACT_GELU_GRAD ? E_GELUG : 0) | (g.act == OFB_ACT_MULAUX ? E_MULAUX : 0) |
+                  (act_is_gelug(g.act) ? E_GELUG : 0) | (act_is_mulaux(g.act) ? E_MULAUX : 0) | (act_is_t(g.act) ? E_AUXT : 0) |
                   (g.rowscale ? E_RS : 0) | (g.resid ? E_RES : 0) | (g.rn_out ? E_RN : 0);
     switch (f) {     // the forms the model issues; anything else takes the generic (run-time flags) instantiation
       case E_C: launch_full<CF, A_KC, B_KC, E_C>(g, p, s); break;
@@ -1357,6 +1503,8 @@ int launch_h(const ofb_gemm_h_args& g, const Plan& p, hipStream_t s) {
       case E_C | E_RS | E_RES: launch_full<CF, A_KC, B_KC, E_C | E_RS | E_RES>(g, p, s); break;
       case E_P | E_GELUG: launch_full<CF, A_KC, B_KC, E_P | E_GELUG>(g, p, s); break;
       case E_P | E_MULAUX: launch_full<CF, A_KC, B_KC, E_P | E_MULAUX>(g, p, s); break;
+      case E_P | E_GELUG | E_AUXT: launch_full<CF, A_KC, B_KC, E_P | E_GELUG | E_AUXT>(g, p, s); break;
+      case E_P | E_MULAUX | E_AUXT: launch_full<CF, A_KC, B_KC, E_P | E_MULAUX | E_AUXT>(g, p, s); break;
       case E_P: launch_full<CF, A_KC, B_KC, E_P>(g, p, s); break;
       default: launch_full<CF, A_KC, B_KC, E_ANY>(g, p, s); break;
     }
@@ -1491,8 +1639,15 @@ extern "C" int32_t ofb_gemm_h_colpart_rows(const ofb_gemm_h_args* args) {
   if (!args || args->M <= 0 || args->N <= 0 || args->K <= 0) return 0;
   ofb_gemm_h_args g = *args;
   if (!g.colpart) g.colpart = reinterpret_cast<float*>(16);
-  const Plan p = plan_h<C128>(g);
+  const Plan p = plan_h<C128F>(g);                            // (C128 and C128F share the tile geometry; the direct form is C128F's)
+  if (p.stagger & 256) return 2 * p.mt;                       // direct epilogue: one partial row per wave row of a tile
   return p.R ? (p.mt - p.R / p.nt) + (p.R / p.nt) * (C128::BM / 4) : p.mt;
+}
+
+/* floats of an aux tensor in T-layout (OFB_ACT_GELU_GRAD_T / OFB_ACT_MULAUX_T) for an [M][N] output: whole 128 x 192 tiles */
+extern "C" int64_t ofb_gemm_h_aux_t_floats(int32_t M, int32_t N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (int64_t)((M + 127) / 128) * ((N + 191) / 192) * 128 * 192;
 }
 
 extern "C" int32_t ofb_gemm_h_rn_tiles(const ofb_gemm_h_args* args, int32_t* col_tiles) {
@@ -1518,8 +1673,9 @@ extern "C" int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream) {
   if (g.a_kc == 0 && g.b_kc == 1) return OFB_ELIMIT;           // A^T * B^T is not on the path
   if (g.colpart && C128::BM != 128) return OFB_ELIMIT;
   if (g.rowscale && g.rs_div <= 0) return OFB_EINVAL;
-  if (g.act < OFB_ACT_NONE || g.act > OFB_ACT_MULAUX) return OFB_EINVAL;
-  if ((g.act == OFB_ACT_DGELU || g.act == OFB_ACT_GELU_GRAD || g.act == OFB_ACT_MULAUX) && !g.aux) return OFB_EINVAL;
+  if (g.act < OFB_ACT_NONE || g.act > OFB_ACT_MULAUX_T) return OFB_EINVAL;
+  if ((g.act == OFB_ACT_DGELU || act_is_gelug(g.act) || act_is_mulaux(g.act)) && !g.aux) return OFB_EINVAL;
+  if (act_is_t(g.act) && !ofb_aligned16(g.aux)) return OFB_EINVAL;
   if (g.C && g.ldc < g.N) return OFB_EINVAL;
   if (g.Cp && g.c_ncb < (g.N + 15) / 16) return OFB_EINVAL;
   if (g.rn_out && (!g.rn_gamma || !g.rn_rowfac || !ofb_aligned16(g.rn_gamma))) return OFB_EINVAL;
@@ -1553,6 +1709,7 @@ extern "C" int ofb_tune(int32_t key, int32_t value) {
       break;
     case OFB_TUNE_GEMM_T112: ok = value <= 1; break;
     case OFB_TUNE_GEMM_YIELD: ok = value <= 32; break;
+    case OFB_TUNE_GEMM_DIRECT: ok = value <= 1; break;
   }
   if (!ok) return OFB_EINVAL;
   h_tune[key] = value;

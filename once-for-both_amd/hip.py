@@ -17,11 +17,11 @@ class OfbError(RuntimeError):
     pass
 
 
-ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX, ACT_GELU_GRAD_T, ACT_MULAUX_T = 0, 1, 2, 3, 4, 5, 6
 
 # every symbol include/ofb_hip.h declares (tests/test_abi.py checks the .so exports exactly these)
 SYMBOLS = [
-    'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_colsum_nb', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs', 'ofb_tune', 'ofb_gemm_h_rn_tiles',
+    'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_gemm_h_aux_t_floats', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_colsum_nb', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs', 'ofb_tune', 'ofb_gemm_h_rn_tiles',
     'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
     'ofb_layernorm_fwd', 'ofb_layernorm_fwd_h', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_h', 'ofb_layernorm_bwd_h_rn', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_amax', 'ofb_attention_fwd', 'ofb_attention_fwd_h', 'ofb_attention_bwd', 'ofb_attention_bwd_wgmax',
@@ -164,7 +164,7 @@ class HMat:
         return int(h.view(torch.int32)[0]), float(f[1]), float(f[2]), float(f[3])
 
 
-TUNE_GEMM_MFMA, TUNE_GEMM_SCHED, TUNE_GEMM_TILE, TUNE_GEMM_T112, TUNE_GEMM_YIELD = 0, 1, 2, 3, 4
+TUNE_GEMM_MFMA, TUNE_GEMM_SCHED, TUNE_GEMM_TILE, TUNE_GEMM_T112, TUNE_GEMM_YIELD, TUNE_GEMM_DIRECT = 0, 1, 2, 3, 4, 5
 
 
 def tune(key, value):
@@ -549,6 +549,21 @@ def gemm_h(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bia
     if part is not None:
         colsum(part, N, part.shape[0], N, colsum_out)
     return rn_out
+
+
+def aux_t(M, N, device):
+    """buffer for the saved GELU derivative in T-layout (ACT_GELU_GRAD_T -> ACT_MULAUX_T; include/ofb_hip.h): private to the two
+    GEMM launches that write and read it."""
+    lib().ofb_gemm_h_aux_t_floats.restype = C.c_int64
+    return torch.empty(int(lib().ofb_gemm_h_aux_t_floats(_i(M), _i(N))), device=device, dtype=torch.float32)
+
+
+def aux_t_to_rows(aux, M, N):
+    """T-layout -> [M][N] (tests / diagnostics only: the model path never looks inside)."""
+    tm, tn = (M + 127) // 128, (N + 191) // 192
+    a = aux.view(tm, tn, 2, 2, 4, 6, 4, 16, 4)            # tile m, tile n, wave row, wave col, row block, col block, row quad, col, row in quad
+    a = a.permute(0, 2, 4, 6, 8, 1, 3, 5, 7).reshape(tm * 128, tn * 192)
+    return a[:M, :N]
 
 
 def splitk_reduce(ws, splits, count, out, accumulate=False):

@@ -48,15 +48,15 @@ qb = torch.empty(1, device='cuda')
 tot += run('fwd qkv  KC,KC bias+gate -> f32 (+bound)', lambda: G(xp, wp, 1, 1, M, H3, D, C_out=y, ldc=H3, bias=b, colscale=g, cbound_out=qb), 2.*M*H3*D, 12)
 w2, b2 = r(D, D), r(D); y2 = torch.empty(M, D, device='cuda'); w2p = P(w2)
 tot += run('fwd proj KC,KC bias+rowscale+resid -> f32', lambda: G(xp, w2p, 1, 1, M, D, D, C_out=y2, ldc=D, bias=b2, rowscale=rs, resid=x, ldr=D), 2.*M*D*D, 12)
-w3, b3, g3 = r(HID, D), r(HID), torch.rand(HID, device='cuda'); hpre = torch.empty(M, HID, device='cuda'); hP = hip.HMat(M, HID, 'cuda'); w3p = P(w3)
-tot += run("fwd fc1  KC,KC bias+gate+GELU' aux -> planes", lambda: G(xp, w3p, 1, 1, M, HID, D, Cp=hP, bias=b3, colscale=g3, act=hip.ACT_GELU_GRAD, aux=hpre, ldaux=HID), 2.*M*HID*D, 12)
+w3, b3, g3 = r(HID, D), r(HID), torch.rand(HID, device='cuda'); hpre = hip.aux_t(M, HID, 'cuda'); hP = hip.HMat(M, HID, 'cuda'); w3p = P(w3)
+tot += run("fwd fc1  KC,KC bias+gate+GELU' aux -> planes", lambda: G(xp, w3p, 1, 1, M, HID, D, Cp=hP, bias=b3, colscale=g3, act=hip.ACT_GELU_GRAD_T, aux=hpre, ldaux=HID), 2.*M*HID*D, 12)
 w4 = r(D, HID); w4p = P(w4)
 tot += run('fwd fc2  KC,KC bias+rowscale+resid -> f32', lambda: G(hP, w4p, 1, 1, M, D, HID, C_out=y2, ldc=D, bias=b2, rowscale=rs, resid=x, ldr=D), 2.*M*D*HID, 12)
 dq = r(M, H3); dqp = P(dq)
 tot += run('bwd dX qkv  KC,KR +resid (K=1152) -> f32', lambda: G(dqp, wp, 1, 0, M, D, H3, C_out=y2, ldc=D, resid=x, ldr=D), 2.*M*H3*D, 12)
 tot += run('bwd dO proj KC,KR (K=384) -> f32 (+bound)', lambda: G(xp, w2p, 1, 0, M, D, D, C_out=y2, ldc=D, cbound_out=qb), 2.*M*D*D, 12)
 dhP = hip.HMat(M, HID, 'cuda')
-tot += run('bwd dH fc2  KC,KR x aux -> planes + colsums', lambda: G(xp, w4p, 1, 0, M, HID, D, Cp=dhP, act=hip.ACT_MULAUX, aux=hpre, ldaux=HID, want_colpart=True), 2.*M*HID*D, 12)
+tot += run('bwd dH fc2  KC,KR x aux -> planes + colsums', lambda: G(xp, w4p, 1, 0, M, HID, D, Cp=dhP, act=hip.ACT_MULAUX_T, aux=hpre, ldaux=HID, want_colpart=True), 2.*M*HID*D, 12)
 tot += run('bwd dX fc1  KC,KR +resid (K=1536) -> f32', lambda: G(dhP, w3p, 1, 0, M, D, HID, C_out=y2, ldc=D, resid=x, ldr=D), 2.*M*HID*D, 12)
 dw = torch.empty(H3, D, device='cuda')
 tot += run('bwd dW qkv  KR,KR', lambda: G(dqp, xp, 0, 0, H3, D, M, C_out=dw, ldc=D), 2.*M*H3*D, 12)

@@ -175,6 +175,88 @@ def test_gemm_h_epilogues(M, N, K, tile_choice):
     _close(cs2, dref.sum(0), 'column sums (saved-derivative form)', tol=1e-5)
 
 
+@pytest.mark.parametrize('M,N,K', [(394, 384, 384), (300, 1536, 384), (130, 70, 36), (1200, 264, 72), (1400, 480, 264), (512, 768, 96),
+                                   (19200, 384, 48), (18999, 264, 40)])
+def test_gemm_h_saved_derivative_in_t_layout(M, N, K, tile_choice):
+    """OFB_ACT_GELU_GRAD_T / OFB_ACT_MULAUX_T (include/ofb_hip.h): the saved GELU derivative in the layout of the 128 x 192 tile's
+    accumulators.  Same numbers as the row-major pair on every epilogue form - interior tiles straight from the registers (direct
+    epilogue), edge tiles / other tile shapes / unaligned launches / the fix-up kernel through the index map - and the direct
+    epilogue switched off (OFB_TUNE_GEMM_DIRECT = 0) gives bit-identical planes and derivative."""
+    from ofb_amd import hip
+    if tile_choice == 96 and M < 1024:
+        pytest.skip('the 256 x 96 tile needs M >= 1024')
+    if tile_choice == 112 and M < 17000:
+        pytest.skip('the 112 x 192 tile is only chosen between half a round and one round of 128-row tiles')
+    x, w, b, cs = _mk((M, K), 5), _mk((N, K), 6, 0.1), _mk((N,), 7), _mk((N,), 8)
+    xp, wp, bd, csd = hip.to_hformat(x.cuda()), hip.to_hformat(w.cuda()), b.cuda(), cs.cuda()
+    pre = ((x.double() @ w.double().t() + b.double()) * cs.double()).requires_grad_(True)
+    torch.nn.functional.gelu(pre).sum().backward()
+    dref = (x.double() @ w.double().t()) * pre.grad
+    # row-major reference pair
+    gaux, hp = torch.empty(M, N, device='cuda'), hip.HMat(M, N, 'cuda')
+    hip.gemm_h(xp, wp, 1, 1, M, N, K, Cp=hp, bias=bd, colscale=csd, aux=gaux, ldaux=N, act=hip.ACT_GELU_GRAD)
+    dp, csum = hip.HMat(M, N, 'cuda'), torch.empty(N, device='cuda')
+    hip.gemm_h(xp, wp, 1, 1, M, N, K, Cp=dp, aux=gaux, ldaux=N, act=hip.ACT_MULAUX, colsum_out=csum)
+    got = {}
+    for direct in (1, 0):
+        hip.tune(hip.TUNE_GEMM_DIRECT, direct)
+        try:
+            taux = hip.aux_t(M, N, 'cuda')
+            taux.fill_(float('nan'))
+            hp_t = hip.HMat(M, N, 'cuda')
+            hp_t.buf.fill_(0x7f)
+            hip.gemm_h(xp, wp, 1, 1, M, N, K, Cp=hp_t, bias=bd, colscale=csd, aux=taux, act=hip.ACT_GELU_GRAD_T)
+            dp_t, cs_t = hip.HMat(M, N, 'cuda'), torch.full((N,), float('nan'), device='cuda')
+            dp_t.buf.fill_(0x7f)
+            hip.gemm_h(xp, wp, 1, 1, M, N, K, Cp=dp_t, aux=taux, act=hip.ACT_MULAUX_T, colsum_out=cs_t)
+            # without the column sums (the form of a bias-less fc1)
+            dp_n = hip.HMat(M, N, 'cuda')
+            hip.gemm_h(xp, wp, 1, 1, M, N, K, Cp=dp_n, aux=taux, act=hip.ACT_MULAUX_T)
+        finally:
+            hip.tune(hip.TUNE_GEMM_DIRECT, 1)
+        rows = hip.aux_t_to_rows(taux, M, N)
+        assert torch.equal(rows, gaux), f'saved derivative (direct {direct})'
+        assert torch.equal(hp_t.to_f32(), hp.to_f32()) and torch.equal(dp_t.to_f32(), dp.to_f32()), f'planes (direct {direct})'
+        assert torch.equal(dp_n.to_f32(), dp.to_f32())
+        _close(cs_t, dref.sum(0), f'column sums (direct {direct})', tol=1e-5)
+        got[direct] = (hp_t.buf.clone(), dp_t.buf.clone(), cs_t.clone())
+    _close(gaux, pre.grad, 'saved gelu derivative')
+    _close(dp.to_f32(), dref, 'value x saved derivative')
+    # the padding of the H-format outputs is written the same way by both forms (real zeros: checked by the KR-operand test above)
+    ncb = (N + 15) // 16
+    for k in (0, 1):
+        a, b2 = got[1][k], got[0][k]
+        assert torch.equal(a[256:256 + ((M + 15) // 16) * 4 * ncb * 256], b2[256:256 + ((M + 15) // 16) * 4 * ncb * 256]), 'plane bytes incl. padding'
+
+
+def test_gemm_h_direct_epilogue_full_size_fc1_and_dh():
+    """the two launches the direct epilogue exists for, at the DeiT-S bs-128 size (25216 x 1536, K = 384: 1576 interior tiles, three rounds
+    + a partial one; every unit but a workgroup's first starts from stages its predecessor's epilogue requested): a strided row sample
+    against fp64, the column sums against the planes, run-to-run bit-identity."""
+    from ofb_amd import hip
+    M, D, N = 128 * 197, 384, 1536
+    x, w, b, cs = _mk((M, D), 21), _mk((N, D), 22, 0.05), _mk((N,), 23), _mk((N,), 24)
+    xp, wp = hip.to_hformat(x.cuda()), hip.to_hformat(w.cuda())
+    rows = torch.arange(0, M, 61)
+    taux, hp = hip.aux_t(M, N, 'cuda'), hip.HMat(M, N, 'cuda')
+    hip.gemm_h(xp, wp, 1, 1, M, N, D, Cp=hp, bias=b.cuda(), colscale=cs.cuda(), aux=taux, act=hip.ACT_GELU_GRAD_T)
+    pre = ((x[rows].double() @ w.double().t() + b.double()) * cs.double()).requires_grad_(True)
+    act = torch.nn.functional.gelu(pre)
+    act.sum().backward()
+    _close(hp.to_f32()[rows.cuda()], act.detach(), 'gelu planes, full size')
+    _close(hip.aux_t_to_rows(taux, M, N)[rows.cuda()], pre.grad, 'saved derivative, full size')
+    dy = _mk((M, D), 25)
+    dyp, w2p = hip.to_hformat(dy.cuda()), hip.to_hformat(w.cuda().t().contiguous())          # dH = dY W2, W2 [D][hid] read along its rows
+    dp, csum = hip.HMat(M, N, 'cuda'), torch.full((N,), float('nan'), device='cuda')
+    hip.gemm_h(dyp, w2p, 1, 0, M, N, D, Cp=dp, aux=taux, act=hip.ACT_MULAUX_T, colsum_out=csum)
+    got = dp.to_f32()
+    _close(got[rows.cuda()], (dy[rows].double() @ w.double().t()) * pre.grad, 'dH planes, full size')
+    _close(csum, got.double().sum(0).cpu(), 'column sums of dH', tol=2e-6)
+    dp2, csum2 = hip.HMat(M, N, 'cuda'), torch.empty(N, device='cuda')
+    hip.gemm_h(dyp, w2p, 1, 0, M, N, D, Cp=dp2, aux=taux, act=hip.ACT_MULAUX_T, colsum_out=csum2)
+    assert torch.equal(dp.buf[256:], dp2.buf[256:]) and torch.equal(csum, csum2)
+
+
 def test_gemm_h_deit_small_layer_shapes():
     """the bs-128 DeiT-S shapes (25216 tokens): full rounds + streamed tail; strided row sample against fp64"""
     from ofb_amd import hip
