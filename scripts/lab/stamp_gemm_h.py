@@ -18,7 +18,11 @@ b, b2, b3, g3 = r(H3), r(D), r(HID), torch.rand(HID, device='cuda')
 G(xp, w3, 1, 1, M, HID, D, Cp=hP, bias=b3, colscale=g3, act=hip.ACT_GELU_GRAD, aux=hpre, ldaux=HID)
 G(xp, w4, 1, 0, M, HID, D, Cp=dhP, act=hip.ACT_MULAUX, aux=hpre, ldaux=HID)
 dw3 = torch.empty(HID, D, device='cuda')
+hpre_t = hip.aux_t(M, HID, 'cuda')
+G(xp, w3, 1, 1, M, HID, D, Cp=hP, bias=b3, colscale=g3, act=hip.ACT_GELU_GRAD_T, aux=hpre_t)
 calls = {
+    'fc1t': (lambda: G(xp, w3, 1, 1, M, HID, D, Cp=hP, bias=b3, colscale=g3, act=hip.ACT_GELU_GRAD_T, aux=hpre_t), 2. * M * HID * D),
+    'dht': (lambda: G(xp, w4, 1, 0, M, HID, D, Cp=dhP, act=hip.ACT_MULAUX_T, aux=hpre_t, want_colpart=True), 2. * M * HID * D),
     'qkv': (lambda: G(xp, w, 1, 1, M, H3, D, C_out=y, ldc=H3, bias=b), 2. * M * H3 * D),
     'proj': (lambda: G(xp, w2, 1, 1, M, D, D, C_out=y2, ldc=D, bias=b2, rowscale=rs, resid=x, ldr=D), 2. * M * D * D),
     'fc1': (lambda: G(xp, w3, 1, 1, M, HID, D, Cp=hP, bias=b3, colscale=g3, act=hip.ACT_GELU_GRAD, aux=hpre, ldaux=HID), 2. * M * HID * D),

@@ -217,7 +217,7 @@ def test_gemm_h_saved_derivative_in_t_layout(M, N, K, tile_choice):
         rows = hip.aux_t_to_rows(taux, M, N)
         assert torch.equal(rows, gaux), f'saved derivative (direct {direct})'
         assert torch.equal(hp_t.to_f32(), hp.to_f32()) and torch.equal(dp_t.to_f32(), dp.to_f32()), f'planes (direct {direct})'
-        assert torch.equal(dp_n.to_f32(), dp.to_f32())
+        _close(dp_n.to_f32(), dref, 'value x saved derivative, no column sums')       # (may run on another tile than the colsum form)
         _close(cs_t, dref.sum(0), f'column sums (direct {direct})', tol=1e-5)
         got[direct] = (hp_t.buf.clone(), dp_t.buf.clone(), cs_t.clone())
     _close(gaux, pre.grad, 'saved gelu derivative')
