@@ -139,9 +139,10 @@ int ofb_gemm_h(const ofb_gemm_h_args* args, void* stream);
 #define OFB_TUNE_GEMM_T112 3   /* OFB_GEMM_H_T112: 1 = the 112 x 192 tile for token-row products whose 128-row tiles fill between half a round and one round; 0 (default) = off: measured slower, profiles/r05_gemm_tile_112.txt */
 #define OFB_TUNE_GEMM_YIELD 4  /* OFB_GEMM_H_YIELD: n in 1..7 = in single-round launches the first-dispatched workgroup of a CU that holds two sleeps 128 n cycles at each stage hand-over (default 4; 0 = off) */
 #define OFB_TUNE_GEMM_DIRECT 5 /* OFB_GEMM_H_DIRECT: 1 (default) = the T-layout activation forms take the direct epilogue on interior tiles; 0 = every tile parks in LDS (same results) */
-#define OFB_TUNE_COUNT 6
+#define OFB_TUNE_GEMM_CUS 6    /* OFB_GEMM_H_CUS: n > 0 = the GEMM plans its persistent workgroups for n CUs instead of all of them (a data-parallel job whose exchange kernels hold CUs during backward: ofb_amd.dp); 0 (default) = every CU */
+#define OFB_TUNE_COUNT 7
 /* A value set here - 0 included - beats the environment variable of the same key.  OFB_EINVAL for a value outside the key's set
- * (MFMA: 16 | 32; SCHED: 0..2; TILE: 0 | 96 | 97 | 128; T112: 0 | 1; YIELD: 0..32; DIRECT: 0 | 1).  Process-wide and unsynchronised: do not change a
+ * (MFMA: 16 | 32; SCHED: 0..2; TILE: 0 | 96 | 97 | 128; T112: 0 | 1; YIELD: 0..32; DIRECT: 0 | 1; CUS: 0..1024).  Process-wide and unsynchronised: do not change a
  * switch between ofb_gemm_h_rn_tiles / ofb_gemm_h_workspace_bytes and the ofb_gemm_h call they size buffers for (the tile choice
  * decides both), nor from a second thread while GEMMs are being launched. */
 int ofb_tune(int32_t key, int32_t value);
@@ -159,6 +160,9 @@ int ofb_prof_enable(int32_t on);   /* on: bit t set -> bracket the launches of t
 int ofb_prof_collect(double* out, int32_t ntags);
 /* diagnostic: `blocks` workgroups x 4 waves each issue 4*iters back-to-back f32 MFMAs (measures the sustained roof) */
 int ofb_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, void* stream);
+/* measurement only: `blocks` 256-thread workgroups that occupy their CU slots (and lds_bytes of LDS each) for usec microseconds on
+ * `stream` - a stand-in for another stream's resident kernels (RCCL channels) while a step is timed (scripts/cu_thief.py) */
+int ofb_diag_cu_thief(int32_t blocks, int32_t usec, int32_t lds_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * LayerNorm over the last dim (eps inside the sqrt), one wavefront per token row; D <= 1024.

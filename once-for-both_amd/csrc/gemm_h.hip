@@ -1352,6 +1352,15 @@ __global__ __launch_bounds__(CF::BN) void gemm_h_fixup_kernel(const ofb_gemm_h_a
     g.colpart[((size_t)(p.mt - p.R / p.nt) + (size_t)(r / p.nt) * (BM / 4) + rgl) * g.N + col] = (pv[0] + pv[1]) + (pv[2] + pv[3]);
 }
 
+// Run-time switches (ofb_tune): -1 = not set yet (the environment variable of the same meaning is read once, then the default)
+int h_tune[OFB_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1, -1};
+int h_switch(int key, const char* env, int dflt) {
+  if (h_tune[key] < 0) { const char* e = getenv(env); h_tune[key] = e ? atoi(e) : dflt; }
+  return h_tune[key];
+}
+
+// CUs the plans count on: the device's, or fewer when the caller says that some are held by another stream's kernels
+// (OFB_TUNE_GEMM_CUS: a data-parallel exchange during backward) - the persistent grid then leaves those slots to the hardware
 int h_cu_count() {
   static int n = 0;
   if (n == 0) {
@@ -1361,14 +1370,8 @@ int h_cu_count() {
     if (hipGetDevice(&devid) == hipSuccess && hipGetDeviceProperties(&prop, devid) == hipSuccess && prop.multiProcessorCount > 0)
       n = prop.multiProcessorCount;
   }
-  return n;
-}
-
-// Run-time switches (ofb_tune): -1 = not set yet (the environment variable of the same meaning is read once, then the default)
-int h_tune[OFB_TUNE_COUNT] = {-1, -1, -1, -1, -1, -1};
-int h_switch(int key, const char* env, int dflt) {
-  if (h_tune[key] < 0) { const char* e = getenv(env); h_tune[key] = e ? atoi(e) : dflt; }
-  return h_tune[key];
+  const int lim = h_switch(OFB_TUNE_GEMM_CUS, "OFB_GEMM_H_CUS", 0);
+  return (lim > 0 && lim < n) ? lim : n;
 }
 
 int h_tile_choice(const ofb_gemm_h_args& g) {
@@ -1710,6 +1713,7 @@ extern "C" int ofb_tune(int32_t key, int32_t value) {
     case OFB_TUNE_GEMM_T112: ok = value <= 1; break;
     case OFB_TUNE_GEMM_YIELD: ok = value <= 32; break;
     case OFB_TUNE_GEMM_DIRECT: ok = value <= 1; break;
+    case OFB_TUNE_GEMM_CUS: ok = value <= 1024; break;
   }
   if (!ok) return OFB_EINVAL;
   h_tune[key] = value;

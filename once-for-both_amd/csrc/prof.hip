@@ -73,3 +73,22 @@ extern "C" int ofb_diag_mfma_peak(float* out, int32_t blocks, int32_t iters, voi
   hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, iters);
   return (int)hipGetLastError();
 }
+
+// Diagnostic: `blocks` workgroups of 256 threads that do nothing but hold their place for `usec` microseconds (s_memrealtime: 100 MHz;
+// they sleep between looks at the clock) - a stand-in for the kernels of ANOTHER stream that sit on some CUs while the step runs (an
+// RCCL all-reduce holds a workgroup per channel for the whole exchange).  lds_bytes > 0: the workgroup also holds that much LDS; the
+// GEMM's two workgroups per CU use all 160 KB, so ANY LDS here keeps one of them off the CU (scripts/cu_thief.py).  Bounded: every
+// wave leaves after `usec` (at most 1 s).
+__global__ __launch_bounds__(256) void cu_thief_kernel(unsigned long long ticks, int* sink) {
+  extern __shared__ int thief_lds[];
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0 && sink == reinterpret_cast<int*>(1)) thief_lds[0] = 1;     // (keeps the allocation referenced)
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+extern "C" int ofb_diag_cu_thief(int32_t blocks, int32_t usec, int32_t lds_bytes, void* stream) {
+  if (blocks <= 0 || blocks > 1024 || usec <= 0 || usec > 1000000 || lds_bytes < 0 || lds_bytes > 163840) return OFB_EINVAL;
+  hipLaunchKernelGGL(cu_thief_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, (unsigned long long)usec * 100ull,
+                     (int*)nullptr);
+  return (int)hipGetLastError();
+}

@@ -281,6 +281,19 @@ def sum_across_ranks(vec, process_group=None):
     return out, dist.get_world_size(process_group)
 
 
+def common_length(n, device=None, process_group=None):
+    """the number of iterations EVERY rank can run: min over the ranks of `n` (one tiny all-reduce per epoch).  The reference relies on
+    its samplers handing every rank the same count (RASampler / DistributedSampler truncate or pad, samplers.py:35-53); a rank whose
+    loader came up one batch short would otherwise leave the others waiting in the gradient exchange of a step it never runs (C1) or
+    in the statistics reduction at its own early epoch end (C4).  A no-op without a process group."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return n
+    dev = device if (device is not None and dist.get_backend(process_group) == 'nccl') else 'cpu'
+    t = torch.tensor([int(n)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=process_group)
+    return int(t.item())
+
+
 def average_scalars(tensors, process_group=None):
     """one fused all-reduce for a list of tiny tensors (alphas at compress time: collective C3)."""
     if not dist.is_initialized() or dist.get_world_size(process_group) == 1:

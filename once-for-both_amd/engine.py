@@ -51,6 +51,17 @@ def search_step(model, criterion, samples, targets, target_flops, optimizers, fi
     return base, arch, decoder_loss, total
 
 
+def _agreed_length(data_loader, device, reducer):
+    """iterations of this epoch: len(data_loader), or - with a data-parallel reducer - the smallest length among the ranks (dp.common_length:
+    every rank runs the same number of steps, so nobody waits in a collective for a rank whose loader came up short; the schedules
+    t = epoch + it / n_iter of engine.py:102 then use that common length on every rank)"""
+    n = len(data_loader)
+    if reducer is None:
+        return n
+    from .dp import common_length
+    return common_length(n, device, reducer.group)
+
+
 class GraphedStep:
     """One whole training step (forward, losses, backward, optimizer steps) captured ONCE into a hipGraph and replayed: ~650
     kernel launches per step leave the host as a single hipGraphLaunch (the launch-bound sizes - small batches, pruned models - are
@@ -141,7 +152,7 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
     if reducer is None:
         reducer = getattr(model, 'reducer', None)        # dp.DistributedDataParallel carries its own
     accum_iter = args.accum_iter
-    n_iter = len(data_loader)
+    n_iter = _agreed_length(data_loader, device, reducer)
     for opt in (optimizer_param, optimizer_decoder, optimizer_arch):
         if opt is not None:
             opt.zero_grad(set_to_none=True)
@@ -154,7 +165,7 @@ def search_one_epoch(model, criterion, target_flops, data_loader, optimizer_para
     # of the values a meter received / how many it received): running sums of the four losses and of the three learning rates, a
     # count of non-finite totals and the number of updates of the three meter families; the host reads them at print points only
     sums, stats, hsum = None, {}, [0.0] * 6
-    for it, (samples, targets) in enumerate(data_loader):
+    for it, (samples, targets) in zip(range(n_iter), data_loader):
         samples = samples.to(device, non_blocking=True)
         targets = targets.to(device, non_blocking=True)
         if mixup_fn is not None:
@@ -240,12 +251,12 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
         reducer = getattr(model, 'reducer', None)        # dp.DistributedDataParallel carries its own
     accum_iter = args.accum_iter
     optimizer.zero_grad(set_to_none=True)
-    n_iter, stats = len(data_loader), {}
+    n_iter, stats = _agreed_length(data_loader, device, reducer), {}
     if device is not None and torch.device(device).type == 'cuda':
         from . import hip
         hip.reset_nonfinite(device)
     sums, hsum = None, [0.0, 0.0]                        # device: [sum of losses, non-finite losses]; host: [sum of lr, iterations]
-    for it, (samples, targets) in enumerate(data_loader):
+    for it, (samples, targets) in zip(range(n_iter), data_loader):
         samples, targets = samples.to(device, non_blocking=True), targets.to(device, non_blocking=True)
         if mixup_fn is not None:
             samples, targets = mixup_fn(samples, targets)

@@ -27,7 +27,7 @@ SYMBOLS = [
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_amax', 'ofb_attention_fwd', 'ofb_attention_fwd_h', 'ofb_attention_bwd', 'ofb_attention_bwd_wgmax',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
-    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak',
+    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak', 'ofb_diag_cu_thief',
     'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm', 'ofb_random_erase',
     'ofb_randaug_layer', 'ofb_normalize_u8', 'ofb_jpeg_parse', 'ofb_jpeg_decode_coefficients', 'ofb_jpeg_plan_batch', 'ofb_jpeg_decode_batch', 'ofb_jpeg_decode_pixels',
 ]
@@ -164,7 +164,7 @@ class HMat:
         return int(h.view(torch.int32)[0]), float(f[1]), float(f[2]), float(f[3])
 
 
-TUNE_GEMM_MFMA, TUNE_GEMM_SCHED, TUNE_GEMM_TILE, TUNE_GEMM_T112, TUNE_GEMM_YIELD, TUNE_GEMM_DIRECT = 0, 1, 2, 3, 4, 5
+TUNE_GEMM_MFMA, TUNE_GEMM_SCHED, TUNE_GEMM_TILE, TUNE_GEMM_T112, TUNE_GEMM_YIELD, TUNE_GEMM_DIRECT, TUNE_GEMM_CUS = 0, 1, 2, 3, 4, 5, 6
 
 
 def tune(key, value):

@@ -469,6 +469,10 @@ class AttnBranch(torch.autograd.Function):
         return dx.view(B, N, D), dres, dwq, dbq, dwp, dbp, dg, None, None, None, None
 
 
+# OFB_AUX_T=0: the saved GELU derivative stays row-major and both MLP epilogues park their tiles in LDS (the round-5 path; same-box A/B)
+_AUX_T = os.environ.get('OFB_AUX_T', '1') != '0'
+
+
 class MlpBranch(torch.autograd.Function):
     """out = resid + rowscale[token] * fc2(gelu(g * fc1(x)))   (layers.py:843-865 + residual/DropPath).
     rowscale is the per-sample DropPath factor expanded to one entry per token ([B*N])."""
@@ -481,7 +485,7 @@ class MlpBranch(torch.autograd.Function):
         x2d = x.view(M, D)
         gv = None if g is None else _c(g.reshape(-1))
         hid = w1.shape[0]
-        hpre = hip.aux_t(M, hid, x.device)                   # T-layout (the GEMM's own): see below
+        hpre = hip.aux_t(M, hid, x.device) if _AUX_T else _new(x, M, hid)      # T-layout (the GEMM's own): see below
         r2d = x2d if resid is None else _c(resid).view(M, D)
         xP, w1P, w2P = _P(x, M, D), hip.weight_h(w1), hip.weight_h(w2)
         ctx.wp = (w1P, w2P)
@@ -490,7 +494,8 @@ class MlpBranch(torch.autograd.Function):
         # GELU'(pre-activation) is kept in f32 (`hpre` holds the derivative here): the epilogue has Phi and phi in hand, and the
         # backward epilogue becomes a single multiply.  It is stored the way the GEMM's waves hold their accumulators (T-layout): both
         # epilogues then run straight from the accumulator registers (gemm_h.hip: the direct epilogue)
-        _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU_GRAD_T, aux=hpre, want_f32=False, want_p=True)
+        _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU_GRAD_T if _AUX_T else hip.ACT_GELU_GRAD, aux=hpre, want_f32=False,
+                             want_p=True)
         if gv is not None:
             hip.gated_register(w1, gv, hid, D)
         out, _ = p_linear_fwd(hP, M, hid, w2P, b2, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
@@ -515,12 +520,12 @@ class MlpBranch(torch.autograd.Function):
         w1P, w2P = ctx.wp
         # the fc1 bias gradient (column sums of this H-format-only result) rides on the epilogue
         if b1 is not None:
-            _, dhP, part = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX_T, aux=hpre, want_f32=False, want_p=True,
+            _, dhP, part = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX_T if _AUX_T else hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True,
                                               want_colpart=True)
             db1_raw = (part, part.shape[0])                  # per-tile partial sums: added up by their consumer
         else:
             db1_raw = None
-            _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX_T, aux=hpre, want_f32=False, want_p=True)
+            _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX_T if _AUX_T else hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True)
         dw2 = grad_slot(w2)
         dw2 = dw2 if dw2 is not None else _new(d2, D, hid)
         with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2, tokens=M) else _nullctx()):

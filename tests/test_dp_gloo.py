@@ -193,6 +193,56 @@ def test_epoch_statistics_are_averaged_over_ranks_world2():
         assert dict(out) == {0: 1, 1: 1}
 
 
+def _worker_uneven_loaders(rank, world, port, out):
+    """one rank's loader is ONE iteration short (3 vs 4 batches): without an agreement on the epoch's length rank 1 would wait forever in
+    the gradient exchange of step 3 (C1) and rank 0 in the statistics reduction at its epoch end (C4).  Both engines: every rank runs
+    the 3 common iterations, the statistics are those of 2 x 3 steps, nobody hangs (the spawn below has a timeout)."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    import types
+    import ofb_amd
+    from ofb_amd import engine
+    from ofb_amd.dp import GradAllReducer
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(4, 1)
+    red = GradAllReducer(list(lin.parameters()), bucket_bytes=1024)
+    steps = []
+
+    class Opt:
+        param_groups = [{'lr': 0.1}]
+        def step(self): steps.append(1)
+        def zero_grad(self, set_to_none=True):
+            for p in lin.parameters():
+                p.grad = None
+
+    class Sched:
+        def step_update(self, k): pass
+
+    n_mine = 4 - rank                                           # rank 0: 4 batches, rank 1: 3
+    data = [(torch.full((2, 4), float(rank + 1 + i)), torch.zeros(2)) for i in range(n_mine)]
+    crit = lambda x, y, t: y.mean() * 0 + x.mean()
+    stats = engine.train_one_epoch(lin, crit, data, Opt(), Sched(), torch.device('cpu'), 0, args=types.SimpleNamespace(accum_iter=1), reducer=red)
+    assert len(steps) == 3, (rank, len(steps))
+    exp = sum(r + 1 + i for r in range(world) for i in range(3)) / (3 * world)
+    assert abs(stats['loss'] - exp) < 1e-6, (rank, stats, exp)
+    # the search engine takes the same decision (its loop is driven without a model here: the agreed length is what matters)
+    assert engine._agreed_length(data, torch.device('cpu'), red) == 3
+    out[rank] = 1
+    dist.destroy_process_group()
+
+
+def test_uneven_loaders_do_not_hang_world2():
+    mp.set_start_method('spawn', force=True)
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        ctx = mp.spawn(_worker_uneven_loaders, args=(2, _free_port(), out), nprocs=2, join=False)
+        import time
+        t0 = time.time()
+        while not ctx.join(timeout=5):
+            assert time.time() - t0 < 120, 'a rank is waiting in a collective'
+        assert dict(out) == {0: 1, 1: 1}
+
+
 @pytest.mark.parametrize('n', [4, 8])
 def test_bench_self_launch_four_and_eight_ranks(n):
     """the self-launch path with FOUR and with EIGHT ranks (gloo rehearsal of the driver's N = 4 / 8 launches): rendezvous, broadcast,
