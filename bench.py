@@ -249,7 +249,8 @@ def report_exchange(reducer, rank, world, dev, seconds, steps):
     rows = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(rows, mine)
     if rank == 0:
-        print(f'[exchange] buckets in launch order (MB): {reducer.bucket_sizes_mb()}', file=sys.stderr, flush=True)
+        print(f'[exchange] buckets in launch order (MB): {reducer.bucket_sizes_mb()}; CUs the GEMM plans leave to the exchange kernels: '
+              f'{getattr(reducer, "_reserved", 0)} (OFB_DP_RESERVE_CUS)', file=sys.stderr, flush=True)
         for r in rows:
             r = r.tolist()
             hid = f', {100.0 * (1.0 - r[3] / r[5]):.0f} % of it hidden under backward' if r[5] > 0 else ''

@@ -15,6 +15,8 @@ backward.  Replaces DistributedDataParallel(find_unused_parameters=True) of refe
   travels as zeros and is not installed.
 """
 import contextlib
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -87,9 +89,10 @@ def broadcast_tensors(tensors, src=0, process_group=None):
 
 class GradAllReducer:
     def __init__(self, params, bucket_bytes=25 * 1024 * 1024, process_group=None, force_collective=False, broadcast=True,
-                 extra_tensors=(), first_bucket_bytes=4 * 1024 * 1024):
+                 extra_tensors=(), first_bucket_bytes=4 * 1024 * 1024, reserve_cus=None):
         global _active
         self.group = process_group
+        self.reserve_cus = reserve_cus
         # force_collective: issue the all-reduce even in a one-rank group (rehearses the RCCL path on a single GPU)
         self.force_collective = bool(force_collective) and dist.is_initialized()
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
@@ -140,12 +143,36 @@ class GradAllReducer:
         # at the reduced bucket and autograd keeps accumulating into it.
         self.sync = True
         _active = self
+        self._reserve()
+
+    def _reserve(self, on=True):
+        """With more than one rank the exchange's kernels sit on some CUs for the length of backward.  The GEMM's persistent grids count on
+        two workgroup slots per CU and use all of a CU's LDS: one resident foreign workgroup that holds ANY LDS keeps a GEMM workgroup
+        off its CU, and a single-round launch then ends a whole tile late - measured +5 % per step for 16, 32 or 64 such workgroups
+        alike, and back to +0.5...1 % when the GEMM plans for that many CUs fewer (profiles/r06_cu_thief_step_vs_resident_workgroups.txt;
+        planning for 64 fewer against 64 residents: +11 %, the cure worse than the disease).  Default: 32 CUs left to the exchange when
+        world > 1 (`reserve_cus=` / OFB_DP_RESERVE_CUS: another count, 0 = none); nothing is reserved in a one-rank group."""
+        if not torch.cuda.is_available():
+            return
+        n = self.reserve_cus
+        if n is None:
+            n = int(os.environ.get('OFB_DP_RESERVE_CUS', '32')) if self.world > 1 else 0
+        from . import hip
+        if not on or n <= 0:
+            if getattr(self, '_reserved', 0):
+                hip.tune(hip.TUNE_GEMM_CUS, 0)
+            self._reserved = 0
+            return
+        cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+        hip.tune(hip.TUNE_GEMM_CUS, max(cus - n, cus // 2))
+        self._reserved = n
 
     def close(self):
         global _active
         for h in self._handles:
             h.remove()
         self._handles = []
+        self._reserve(False)
         if _active is self:
             _active = None
 
@@ -155,7 +182,7 @@ class GradAllReducer:
         sync, prescaled = self.sync, self.prescaled
         self.close()
         self.__init__(params, bucket_bytes=self.bucket_bytes, process_group=self.group, force_collective=self.force_collective,
-                      extra_tensors=extra_tensors, first_bucket_bytes=self.first_bucket_bytes)
+                      extra_tensors=extra_tensors, first_bucket_bytes=self.first_bucket_bytes, reserve_cus=self.reserve_cus)
         self.sync, self.prescaled = sync, prescaled
 
     def bucket_sizes_mb(self):
