@@ -485,7 +485,10 @@ class MlpBranch(torch.autograd.Function):
         x2d = x.view(M, D)
         gv = None if g is None else _c(g.reshape(-1))
         hid = w1.shape[0]
-        hpre = hip.aux_t(M, hid, x.device) if _AUX_T else _new(x, M, hid)      # T-layout (the GEMM's own): see below
+        # T-layout (the GEMM's own: see below) where every column tile of the hidden width is whole (hid % 192 == 0: all MLP options of
+        # DeiT-S / DeiT-B); a ragged last column tile would take the parked epilogue through the layout's index map, slower than row-major
+        aux_t = _AUX_T and hid % 192 == 0
+        hpre = hip.aux_t(M, hid, x.device) if aux_t else _new(x, M, hid)
         r2d = x2d if resid is None else _c(resid).view(M, D)
         xP, w1P, w2P = _P(x, M, D), hip.weight_h(w1), hip.weight_h(w2)
         ctx.wp = (w1P, w2P)
@@ -494,19 +497,19 @@ class MlpBranch(torch.autograd.Function):
         # GELU'(pre-activation) is kept in f32 (`hpre` holds the derivative here): the epilogue has Phi and phi in hand, and the
         # backward epilogue becomes a single multiply.  It is stored the way the GEMM's waves hold their accumulators (T-layout): both
         # epilogues then run straight from the accumulator registers (gemm_h.hip: the direct epilogue)
-        _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU_GRAD_T if _AUX_T else hip.ACT_GELU_GRAD, aux=hpre, want_f32=False,
+        _, hP = p_linear_fwd(xP, M, D, w1P, b1, colscale=gv, act=hip.ACT_GELU_GRAD_T if aux_t else hip.ACT_GELU_GRAD, aux=hpre, want_f32=False,
                              want_p=True)
         if gv is not None:
             hip.gated_register(w1, gv, hid, D)
         out, _ = p_linear_fwd(hP, M, hid, w2P, b2, rowscale=rowscale, rs_div=_rs_div(rowscale, M), resid=r2d)
         ctx.save_for_backward(xP.buf, hpre, hP.buf, w1, b1, w2, gv, rowscale)
-        ctx.meta = (B, N, D, resid is None, b2 is not None)
+        ctx.meta = (B, N, D, resid is None, b2 is not None, aux_t)
         return out.view(B, N, D)
 
     @staticmethod
     def backward(ctx, dout):
         xbuf, hpre, hbuf, w1, b1, w2, gv, rowscale = ctx.saved_tensors
-        B, N, D, self_resid, has_b2 = ctx.meta
+        B, N, D, self_resid, has_b2, aux_t = ctx.meta
         M, hid = B * N, w1.shape[0]
         xP, hP = _pm(xbuf, M, D), _pm(hbuf, M, hid)
         d2 = _c(dout).view(M, D)
@@ -520,12 +523,12 @@ class MlpBranch(torch.autograd.Function):
         w1P, w2P = ctx.wp
         # the fc1 bias gradient (column sums of this H-format-only result) rides on the epilogue
         if b1 is not None:
-            _, dhP, part = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX_T if _AUX_T else hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True,
+            _, dhP, part = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX_T if aux_t else hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True,
                                               want_colpart=True)
             db1_raw = (part, part.shape[0])                  # per-tile partial sums: added up by their consumer
         else:
             db1_raw = None
-            _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX_T if _AUX_T else hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True)
+            _, dhP = p_linear_bwd_input(d2sP, M, D, w2P, hid, act=hip.ACT_MULAUX_T if aux_t else hip.ACT_MULAUX, aux=hpre, want_f32=False, want_p=True)
         dw2 = grad_slot(w2)
         dw2 = dw2 if dw2 is not None else _new(d2, D, hid)
         with (hip.side_work(d2.device, keep=[d2sP.buf, hP.buf]) if _side_ok(w2, tokens=M) else _nullctx()):
