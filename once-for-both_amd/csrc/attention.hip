@@ -342,6 +342,9 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
 // 64-byte dS rows swap their two 32-byte halves with bit 2 of the key.
 // Output: f32 dq | dk | dv in the qkv packing; dqkv_amax (optional) receives max |output| by atomic max (the exponent of the H-format
 // copy ofb_to_hformat_colsum makes of it).
+#ifndef OFB_ATT_KB_HOLD
+#define OFB_ATT_KB_HOLD 0             /* 1: K fragments held across the two query tiles - built, bit-identical, NEUTRAL (round 6: profiles/r06_attention_kb_hold_neutral.txt) */
+#endif
 #define AB_NW 8                       /* waves: 0..6 own 32 key positions each, wave 7 only stages and takes a dQ tile */
 #define AB_NKW 7
 #define AB_THREADS (64 * AB_NW)
@@ -599,6 +602,17 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
       for (int ks = 0; ks < 2; ++ks) {
         if (ks < nks) {
           const int off = a_row + ((((4 * ks + gl)) ^ a_sw) << 4);
+#if OFB_ATT_KB_HOLD
+          // lab form: the K fragments of this wave's two key tiles are read ONCE per k-step and held across both query
+          // tiles - half the K-fragment LDS reads of this phase, +10 registers (231), same MFMAs in the same order (bit-identical);
+          // measured 130.2 / 129.8 / 131.7 us against 130.7 / 130.4 / 130.7: the phase is not bound by those reads
+          __builtin_amdgcn_sched_barrier(0);
+          att_hx8 kbh[2][2];
+#pragma unroll
+          for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) kbh[kt][pl] = *reinterpret_cast<const att_hx8*>(Kpl + pl * AB_KPL + (32 * w + 16 * kt) * 128 + off);
+#endif
 #pragma unroll
           for (int qt = 0; qt < 2; ++qt) {
             // (the fences keep hipcc from hoisting every group's fragment reads to the top of the block)
@@ -611,10 +625,14 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
             }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
+#if OFB_ATT_KB_HOLD
+              S[qt][kt] = att_mfma3_swapped(qa, kbh[kt], S[qt][kt]);         // bit-identical to the forward's S (times 2^(2 he))
+#else
               att_hx8 kb[2];
 #pragma unroll
               for (int pl = 0; pl < 2; ++pl) kb[pl] = *reinterpret_cast<const att_hx8*>(Kpl + pl * AB_KPL + (32 * w + 16 * kt) * 128 + off);
               S[qt][kt] = att_mfma3_swapped(qa, kb, S[qt][kt]);              // bit-identical to the forward's S (times 2^(2 he))
+#endif
               dPa[qt][kt] = att_mfma3(oa, Vb[kt][ks], dPa[qt][kt]);
             }
           }
