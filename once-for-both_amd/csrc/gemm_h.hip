@@ -886,7 +886,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
     // runs: the NEXT unit's first stages are requested before the accumulators are touched (their DMA round trip hides under the
     // epilogue's arithmetic and stores).  Row- and column-interior tiles only (whole tile inside the matrix); the others park.
     constexpr bool DIRECT_CT = MF == 16 && !TAIL && CF::WM == 2 && WN == 2 && MB == 4 && NB == 6 && BMT == 128 && BN == 192 && NST == 2 &&
-                               (EPI == (E_P | E_GELUG | E_AUXT) || EPI == (E_P | E_MULAUX | E_AUXT));
+                               (EPI == (E_P | E_GELUG | E_AUXT) || EPI == (E_P | E_MULAUX | E_AUXT)) && OFB_LAB_ABLATE != 9;
     bool direct_done = false;
     if constexpr (DIRECT_CT) {
       if ((p.stagger & 256) != 0 && cur.m0 + BMT <= g.M && cur.n0 + BN <= g.N) {
