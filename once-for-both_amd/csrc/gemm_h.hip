@@ -34,6 +34,9 @@ typedef short hs16x8 __attribute__((ext_vector_type(8)));
 #ifndef OFB_LAB_ABLATE
 #define OFB_LAB_ABLATE 0
 #endif
+#ifndef OFB_EPI_PRIO
+#define OFB_EPI_PRIO 1              /* wave priority during the direct epilogue (lab: 0 / 3) */
+#endif
 #ifndef OFB_H_NTERM
 #define OFB_H_NTERM 3               /* 4: also h2 h2 (lab: accuracy comparison) */
 #endif
@@ -892,6 +895,10 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
       if ((p.stagger & 256) != 0 && cur.m0 + BMT <= g.M && cur.n0 + BN <= g.N) {
         direct_done = true;
         constexpr bool GELUG = (EPI & E_GELUG) != 0;
+        // the epilogue's arithmetic and store issue go AHEAD of the co-resident workgroup's K loop (s_setprio 1 here, 0 again at the
+        // end): fc1 126.5 / 130.1 -> 118.6 / 118.4 us, dH 117.6 -> 115.4, the twelve products 10.77 -> 10.58 ms; priority 3 gains less
+        // (profiles/r06_gemm_epilogue_priority.txt).  The sooner a workgroup's stores are issued, the sooner its next K loop starts.
+        __builtin_amdgcn_s_setprio(OFB_EPI_PRIO);
         if (nxt.ok) {
           const int n_nk16 = nxt.it1 - nxt.it0, n_nst = (n_nk16 + KH - 1) / KH;
           const char* na = Apl + (A_KC ? (size_t)(nxt.m0 / 4) * a_ncb * GRAN : (size_t)(nxt.m0 / 16) * GRAN) + nxt.it0 * a_k16;
@@ -962,6 +969,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
             if (lane < 16) g.colpart[(size_t)(2 * (cur.m0 / BMT) + (w / WN)) * g.N + col] = csum;
           }
         }
+        __builtin_amdgcn_s_setprio(0);
       }
     }
     if (!direct_done)
@@ -1016,6 +1024,9 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
       // tiles of the pruned / finetune shapes): N is a multiple of 4 there, so a column quad lies wholly inside or wholly outside
       const bool wide = TAIL || (cur.m0 + BMT <= g.M && (p.stagger & 1) != 0);   // p.stagger bit 0: "wide epilogue allowed" (alignment checked on the host)
       constexpr int NQ = BN / 4, NIT = ((HR / 4) * NQ + CF::NT - 1) / CF::NT;         // column quads per row; items per full pass and thread
+#ifdef OFB_LAB_EPI_PRIO_ALL
+      __builtin_amdgcn_s_setprio(OFB_LAB_EPI_PRIO_ALL);             // lab: the parked epilogue ahead of the co-resident K loop as well
+#endif
       __builtin_amdgcn_s_barrier();                                 // every wave has finished its fragment reads / its LDS-DMA
 #pragma unroll
       for (int half = 0; half < NPASS; ++half) {
@@ -1286,6 +1297,9 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
         __syncthreads();
         if (t == 0) g.rn_out[(cur.m0 / BMT) * p.nt + cur.n0 / BN] = Rmx[0];
       }
+#ifdef OFB_LAB_EPI_PRIO_ALL
+      __builtin_amdgcn_s_setprio(0);
+#endif
     }
     OFB_HSTAMP(3);
     ++sidx;
