@@ -61,6 +61,12 @@ def deit_base_patch16_224_mim(pretrained=False, mae=True, pretrained_strict=Fals
 
 
 @register_model
+def deit_tiny_patch16_224_finetune(pretrained=False, **kwargs):
+    """not registered by the reference; the plain counterpart of deit_tiny_patch16_224_mim (BASELINE config 1 plumbing)."""
+    return _finetune('tiny', pretrained, kwargs)
+
+
+@register_model
 def deit_small_patch16_224_finetune(pretrained=False, **kwargs):
     return _finetune('small', pretrained, kwargs)
 
