@@ -166,11 +166,6 @@ def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None, fold=
     if defer:
         hip.gate_fold_bwd_deferred(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K, dbraw_rows=rows, fold=fold)
         _end_of_backward_callback()                       # (joins the side stream, then flushes)
-        # The queue holds dW / db / dg until the flush.  What autograd receives are ALIASES of them: AccumulateGrad adopts an incoming
-        # gradient only if nobody else references that tensor object and CLONES it otherwise - a clone taken now would copy memory
-        # the fold has not written yet (the deferred LayerNorm sums hand out views of their buffer for the same reason)
-        dW, dg = dW.view(N, K), dg.view(-1)
-        db = None if db is None else db.view(-1)
     return dx, dW, db, dg
 
 
