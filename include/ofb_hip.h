@@ -216,14 +216,7 @@ int ofb_colsum_multi(const ofb_colsum_job* jobs_dev, int32_t n_jobs, int32_t max
 int ofb_scale_rows(const float* W, const float* g, float* out, int32_t N, int32_t K, void* stream);
 int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float* g, const float* dbraw, int32_t dbraw_rows, const float* b,
                       float* dW, float* db, float* dg, int32_t N, int32_t K, int32_t fold, void* stream);
-/* the same for many layers in ONE launch (all gated layers of a backward pass): jobs_dev = n_jobs descriptors in device memory,
- * max_rows = the largest N / fold among them.  Every pointer / count as in ofb_gate_fold_bwd (dbraw, b, db may be NULL). */
-typedef struct ofb_gate_fold_job {
-  const float* dWraw; const float* W; const float* g; const float* dbraw; const float* b;
-  float* dW; float* db; float* dg;
-  int32_t N, K, dbraw_rows, fold;
-} ofb_gate_fold_job;
-int ofb_gate_fold_bwd_multi(const ofb_gate_fold_job* jobs_dev, int32_t n_jobs, int32_t max_rows, void* stream);
+
 
 /* ---------------------------------------------------------------------------------------------
  * Attention core softmax(q k^T * scale) v with probabilities kept on chip

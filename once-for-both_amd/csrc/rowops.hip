@@ -640,14 +640,6 @@ __global__ __launch_bounds__(256) void gate_fold_bwd_kernel(const float* __restr
                                                             int dbraw_rows, int fold) {
   gate_fold_bwd_body(dWraw, W, g, dbraw, b, dW, db, dg, N, K, dbraw_rows, fold);
 }
-// every gated layer of a backward pass in ONE launch (24 per DeiT search step: the kernel is latency bound, ~10 us each on its own):
-// blockIdx.y = job
-__global__ __launch_bounds__(256) void gate_fold_bwd_multi_kernel(const ofb_gate_fold_job* __restrict__ jobs) {
-  const ofb_gate_fold_job j = jobs[blockIdx.y];
-  if ((int)blockIdx.x * 4 >= j.N / j.fold) return;
-  gate_fold_bwd_body(j.dWraw, j.W, j.g, j.dbraw, j.b, j.dW, j.db, j.dg, j.N, j.K, j.dbraw_rows, j.fold);
-}
-
 }  // namespace
 
 namespace {
@@ -811,13 +803,6 @@ extern "C" int ofb_gate_fold_bwd(const float* dWraw, const float* W, const float
   return ofb_launch_status();
 }
 
-
-// max_rows = the largest N / fold among the jobs (grid extent)
-extern "C" int ofb_gate_fold_bwd_multi(const ofb_gate_fold_job* jobs_dev, int32_t n_jobs, int32_t max_rows, void* stream) {
-  if (!jobs_dev || n_jobs <= 0 || n_jobs > 65535 || max_rows <= 0) return OFB_EINVAL;
-  hipLaunchKernelGGL(gate_fold_bwd_multi_kernel, dim3(ofb_cdiv(max_rows, 4), n_jobs), dim3(256), 0, (hipStream_t)stream, jobs_dev);
-  return ofb_launch_status();
-}
 
 // out[N] = column sums of x[M][ld] for every job, one launch; max_N = the widest job
 extern "C" int ofb_colsum_multi(const ofb_colsum_job* jobs_dev, int32_t n_jobs, int32_t max_N, void* stream) {

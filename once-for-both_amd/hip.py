@@ -23,7 +23,7 @@ ACT_NONE, ACT_GELU, ACT_DGELU, ACT_GELU_GRAD, ACT_MULAUX, ACT_GELU_GRAD_T, ACT_M
 SYMBOLS = [
     'ofb_gemm_h', 'ofb_gemm_h_workspace_bytes', 'ofb_gemm_h_colpart_rows', 'ofb_gemm_h_aux_t_floats', 'ofb_hformat_bytes', 'ofb_to_hformat', 'ofb_patchify_hformat', 'ofb_to_hformat_colsum', 'ofb_to_hformat_colsum_nb', 'ofb_to_hformat_multi', 'ofb_from_hformat', 'ofb_colsum_h', 'ofb_colsum_h_slabs', 'ofb_tune', 'ofb_gemm_h_rn_tiles',
     'ofb_splitk_reduce', 'ofb_prof_enable', 'ofb_prof_collect',
-    'ofb_layernorm_fwd', 'ofb_layernorm_fwd_h', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_h', 'ofb_layernorm_bwd_h_rn', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi', 'ofb_gate_fold_bwd_multi',
+    'ofb_layernorm_fwd', 'ofb_layernorm_fwd_h', 'ofb_layernorm_bwd_blocks', 'ofb_layernorm_bwd', 'ofb_layernorm_bwd_h', 'ofb_layernorm_bwd_h_rn', 'ofb_colsum_slabs', 'ofb_colsum', 'ofb_colsum_multi',
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_amax', 'ofb_attention_fwd', 'ofb_attention_fwd_h', 'ofb_attention_bwd', 'ofb_attention_bwd_wgmax',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
@@ -653,50 +653,17 @@ def colsum_deferred(x, ld, M, N, out):
     _deferred.append((x, int(ld), int(M), int(N), out))
 
 
-class GateFoldJob(C.Structure):
-    _fields_ = [('dWraw', C.c_void_p), ('W', C.c_void_p), ('g', C.c_void_p), ('dbraw', C.c_void_p), ('b', C.c_void_p), ('dW', C.c_void_p),
-                ('db', C.c_void_p), ('dg', C.c_void_p), ('N', C.c_int32), ('K', C.c_int32), ('dbraw_rows', C.c_int32), ('fold', C.c_int32)]
-
-
-_deferred_folds = []         # gate folds of this backward pass (gate_fold_bwd_deferred): ONE launch at the next flush
-
-
-def gate_fold_bwd_deferred(dWraw, W, g, dbraw, b, dW, db, dg, N, K, dbraw_rows=1, fold=1):
-    """gate_fold_bwd, queued: all gated layers of a backward pass are folded by ONE launch at the next flush_deferred() (end of
-    backward, a bucket going to the exchange, the optimizer step, the gate backward) - on the stream that flush runs on, so the caller
-    must have ordered the producers of dWraw / dbraw before that point (the flush sites join the side stream first or run on it)."""
-    if dbraw is not None and dbraw.numel() < dbraw_rows * N:
-        raise OfbError('gate_fold_bwd: dbraw must hold dbraw_rows * N floats')
-    if N % fold or dg.numel() < N // fold:
-        raise OfbError('gate_fold_bwd: dg must hold N / fold floats')
-    _deferred_folds.append((dWraw, W, g, dbraw, b, dW, db, dg, int(N), int(K), int(dbraw_rows), int(fold)))
-
-
 def flush_deferred():
-    if not _deferred and not _deferred_folds:
+    if not _deferred:
         return
-    keep = []
-    if _deferred:
-        tab = (ColsumJob * len(_deferred))()
-        for t, (x, ld, M, N, out) in zip(tab, _deferred):
-            t.x, t.out, t.ld, t.M, t.N = x.data_ptr(), out.data_ptr(), ld, M, N
-        dev = _deferred[0][0].device
-        dev_tab, host = upload_structs(tab, dev)
-        check(lib().ofb_colsum_multi(ptr(dev_tab), _i(len(_deferred)), _i(max(j[3] for j in _deferred)), stream()), 'ofb_colsum_multi')
-        keep.append((dev_tab, host, list(_deferred)))          # inputs stay referenced until the next flush (stream order frees them)
-        _deferred.clear()
-    if _deferred_folds:
-        tab = (GateFoldJob * len(_deferred_folds))()
-        for t, j in zip(tab, _deferred_folds):
-            (t.dWraw, t.W, t.g, t.dbraw, t.b, t.dW, t.db, t.dg) = (None if x is None else x.data_ptr() for x in j[:8])
-            t.N, t.K, t.dbraw_rows, t.fold = j[8:]
-        dev = _deferred_folds[0][0].device
-        dev_tab, host = upload_structs(tab, dev)
-        check(lib().ofb_gate_fold_bwd_multi(ptr(dev_tab), _i(len(_deferred_folds)), _i(max(j[8] // j[11] for j in _deferred_folds)), stream()),
-              'ofb_gate_fold_bwd_multi')
-        keep.append((dev_tab, host, list(_deferred_folds)))
-        _deferred_folds.clear()
-    _deferred_keep[0] = keep
+    tab = (ColsumJob * len(_deferred))()
+    for t, (x, ld, M, N, out) in zip(tab, _deferred):
+        t.x, t.out, t.ld, t.M, t.N = x.data_ptr(), out.data_ptr(), ld, M, N
+    dev = _deferred[0][0].device
+    dev_tab, host = upload_structs(tab, dev)
+    check(lib().ofb_colsum_multi(ptr(dev_tab), _i(len(_deferred)), _i(max(j[3] for j in _deferred)), stream()), 'ofb_colsum_multi')
+    _deferred_keep[0] = (dev_tab, host, list(_deferred))       # inputs stay referenced until the next flush (stream order frees them)
+    _deferred.clear()
 
 
 def scale_rows(W, g, out, N, K):

@@ -74,7 +74,6 @@ def p_linear_bwd_weight(dyP, xP, M, N, K, out=None):
 
 
 _cb_queued = [False]
-_FOLD_DEFER = os.environ.get('OFB_FOLD_DEFER', '1') != '0'      # 0: one gate-fold launch per gated layer, where it is produced (round 5)
 
 
 _SIDE_MIN_TOKENS = int(os.environ.get('OFB_SIDE_MIN_TOKENS', '12000'))
@@ -118,11 +117,10 @@ def _end_of_backward_callback():
 def begin_step():
     """called at the start of every model forward: a backward pass that raised leaves its end-of-pass callback unqueued-but-flagged
     and its deferred jobs behind; start clean"""
-    if _cb_queued[0] or _deferred_params or hip._deferred or hip._deferred_folds:
+    if _cb_queued[0] or _deferred_params or hip._deferred:
         _cb_queued[0] = False
         _deferred_params.clear()
         hip._deferred.clear()
-        hip._deferred_folds.clear()
 
 
 hip._forward_hooks.append(begin_step)
@@ -139,9 +137,6 @@ def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None, fold=
     (partials [rows][N], rows) straight from the producing kernel - the gate-fold kernel adds partial rows up itself."""
     N, K = WP.R, WP.C
     side = _side_ok(W, b, tokens=M)                      # asked of the Parameter itself: a view's .grad is always None
-    # the gate fold of every gated layer of this pass in ONE launch at the next flush (hip.gate_fold_bwd_deferred) - unless a gradient
-    # is being accumulated into (AccumulateGrad would read dW / db on the spot)
-    defer = _FOLD_DEFER and gvec is not None and _grad_of(W) is None and (b is None or _grad_of(b) is None)
     W = W.view(N, K)
     slot = grad_slot(W)
     if gvec is None:
@@ -161,11 +156,9 @@ def _p_gated_linear_bwd(dyP, dy_colsum, xP, M, W, WP, b, gvec, resid=None, fold=
     db, dg, dWraw = (_new(W, N) if b is not None else None), _new(W, N // fold), _new(W, N, K)   # fold: see hip.gate_fold_bwd
     with (hip.side_work(W.device, keep=[dyP.buf, xP.buf, dWraw, dbraw, gvec]) if side else _nullctx()):
         p_linear_bwd_weight(dyP, xP, M, N, K, out=dWraw)
-        if not defer:
-            hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K, dbraw_rows=rows, fold=fold)
-    if defer:
-        hip.gate_fold_bwd_deferred(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K, dbraw_rows=rows, fold=fold)
-        _end_of_backward_callback()                       # (joins the side stream, then flushes)
+        # (round 6: queueing the 24 folds of a pass for ONE multi-job launch at the end of backward was built and measured - 16.57 /
+        #  16.60 / 16.61 against 16.55 / 16.57 / 16.58 ms per step: they already hide on the side stream - and removed again)
+        hip.gate_fold_bwd(dWraw, W, gvec, dbraw, b, dW, db, dg, N, K, dbraw_rows=rows, fold=fold)
     return dx, dW, db, dg
 
 
@@ -789,7 +782,6 @@ class BiMaskGates(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         hip.join_side()                                   # gate gradients of the gated Linear layers come off the side stream
-        hip.flush_deferred()                              # ... or out of the deferred fold of all of them (hip.gate_fold_bwd_deferred)
         descs_dev, _, buf, rank, plan = ctx.keep
         n = len(plan)
         dgs, dwrs, dwms = grads[:n], grads[n:2 * n], grads[2 * n:3 * n]
