@@ -34,6 +34,9 @@ typedef short hs16x8 __attribute__((ext_vector_type(8)));
 #ifndef OFB_LAB_ABLATE
 #define OFB_LAB_ABLATE 0
 #endif
+#ifndef OFB_DIRECT_PAIR
+#define OFB_DIRECT_PAIR 1           /* direct epilogue: neighbouring lanes pair their plane slots into 16-byte stores (0: two 8-byte stores per lane) */
+#endif
 #ifndef OFB_EPI_PRIO
 #define OFB_EPI_PRIO 1              /* wave priority during the direct epilogue (lab: 0 / 3) */
 #endif
@@ -956,9 +959,22 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
             ofb_hsplit_pair(o[0] * so, o[1] * so, h1a, h2a);
             ofb_hsplit_pair(o[2] * so, o[3] * so, h1b, h2b);
             char* slot = Cpl + ((size_t)(((cur.m0 + wm0 + 16 * mi) >> 2) + g4) * g.c_ncb + (col >> 4)) * GRAN + (col & 15) * 8;
+#if OFB_DIRECT_PAIR
+            // two neighbouring lanes hold the 8-byte slots of two neighbouring columns: they swap one slot (DPP quad_perm 1,0,3,2), the
+            // even lane then stores BOTH h1 slots (16 contiguous bytes), the odd lane both h2 slots - one dwordx4 store per lane and
+            // block instead of two dwordx2
+            const bool even = (lane & 1) == 0;
+            const unsigned sa_ = even ? h2a : h1a, sb_ = even ? h2b : h1b;          // what the neighbour stores for me
+            const unsigned ra = (unsigned)__builtin_amdgcn_mov_dpp((int)sa_, 0xB1, 0xF, 0xF, true);
+            const unsigned rb = (unsigned)__builtin_amdgcn_mov_dpp((int)sb_, 0xB1, 0xF, 0xF, true);
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 v4 = even ? (u32x4){h1a, h1b, ra, rb} : (u32x4){ra, rb, h2a, h2b};
+            OFB_NT_STORE(v4, reinterpret_cast<u32x4*>(even ? slot : slot + 120));    // odd: plane 2 of the pair = slot - 8 + 128
+#else
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
             OFB_NT_STORE(((u32x2){h1a, h1b}), reinterpret_cast<u32x2*>(slot));
             OFB_NT_STORE(((u32x2){h2a, h2b}), reinterpret_cast<u32x2*>(slot + 128));
+#endif
             csum += (o[0] + o[1]) + (o[2] + o[3]);
           }
           if (g.colpart) {
