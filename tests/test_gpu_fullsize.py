@@ -218,6 +218,40 @@ def test_full_size_step_is_bit_reproducible():
     assert all(bool(torch.isfinite(g).all()) for g in grads[0].values())
 
 
+def test_full_size_step_on_the_cus_a_data_parallel_exchange_leaves():
+    """configs[2] on one GPU: with more than one rank `dp.GradAllReducer` plans every GEMM for 256 - 32 = 224 CUs (OFB_TUNE_GEMM_CUS; RCCL's
+    kernels hold the rest during backward).  Other rounds, tails and K cuts, the same arithmetic: loss and every gradient tensor of the
+    bs-128 step agree with the 256-CU run to summation-order level, and the step stays bit-reproducible on the smaller grid."""
+    from ofb_amd import hip
+    m, crit, imgs, labels = _setup()
+    m.train()
+    runs = []
+    try:
+        for cus in (0, 224, 224):
+            hip.tune(hip.TUNE_GEMM_CUS, cus)
+            for p in m.parameters():
+                p.grad = None
+            total, logits = _loss(m, crit, imgs, labels)
+            total.backward()
+            torch.cuda.synchronize()
+            runs.append((float(total.detach()), logits.detach().clone(), {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        hip.tune(hip.TUNE_GEMM_CUS, 0)
+    (l0, lg0, g0), (l1, lg1, g1), (l2, lg2, g2) = runs
+    assert abs(l0 - l1) <= 1e-6 * abs(l0), (l0, l1)
+    assert float((lg0 - lg1).norm() / lg0.norm()) < 1e-6
+    worst = (0.0, '')
+    for k in g0:
+        nrm = float(g0[k].double().norm())
+        if nrm < 1e-12:
+            continue
+        err = float((g0[k].double() - g1[k].double()).norm()) / nrm
+        worst = max(worst, (err, k))
+        assert err < 2e-5, (k, err)
+        assert torch.equal(g1[k], g2[k]), k
+    print(f'224-CU plans against 256-CU plans: worst gradient tensor {worst[0]:.2e} ({worst[1]})')
+
+
 def test_full_size_forward_is_batch_separable():
     """every sample's logits depend on that sample alone: the 128-image forward equals four 32-image forwards (different GEMM
     tilings / stream-K cuts, so equal to rounding, not bitwise)."""

@@ -409,3 +409,20 @@ def test_single_round_scheduling_switches_move_tiles_not_bits():
     for out, rn in outs[1:]:
         assert torch.equal(out, outs[0][0])
         assert (rn is None) == (outs[0][1] is None) and (rn is None or torch.equal(rn, outs[0][1]))
+
+
+@pytest.mark.parametrize('cus', [224, 200, 131])
+def test_gemm_h_full_size_products_on_fewer_cus(cus):
+    """OFB_TUNE_GEMM_CUS (what `dp.GradAllReducer` sets in a group of more than one rank: 256 - 32 = 224 CUs for the GEMM plans while
+    RCCL's kernels hold the rest; 200 and the odd 131 stand for other reservations): the persistent grid shrinks to 2 x cus workgroups,
+    every plan - rounds, streamed tails, the one-round balance, the direct epilogue's unit chain, the weight gradients' K cuts - is
+    another one.  The full-size checks of this file must hold unchanged on them."""
+    from ofb_amd import hip
+    try:
+        hip.tune(hip.TUNE_GEMM_CUS, cus)
+        test_gemm_h_direct_epilogue_full_size_fc1_and_dh()
+        test_gemm_h_deit_small_layer_shapes()
+        test_gemm_h_between_one_and_two_rounds(25216, 384, 384)
+        test_gemm_h_between_one_and_two_rounds(27800, 384, 384)
+    finally:
+        hip.tune(hip.TUNE_GEMM_CUS, 0)
