@@ -54,14 +54,42 @@ __device__ __forceinline__ float ofb_dgelu(float x) {
   return Phi + x * phi;
 }
 
+// Whole-wave reductions (every lane gets the result; call them with all 64 lanes active).  The tree is the xor butterfly 32, 16, 8, 4,
+// 2, 1 - v[i] = v[i] (+) v[i ^ o] - and the results are BIT-identical to the `__shfl_xor` form it replaces (the operation is
+// commutative, every lane combines the same two values at every level), but no step goes through the LDS crossbar (ds_bpermute_b32:
+// an address VGPR, an lgkmcnt round trip of >= 100 cycles per level, six levels in a row): xor 32 / 16 are the gfx950 half / row
+// exchanges v_permlane32_swap / v_permlane16_swap of (v, v) - afterwards the pair holds (own, partner) or (partner, own) -, xor 8 is
+// row_ror:8, xor 4 two bank-masked row shifts, xor 2 / 1 quad permutes (DPP).  Measured on the LayerNorm kernels, round 6.
+#ifdef OFB_LAB_SHFL_REDUCE
+#define OFB_WAVE_REDUCE(v, OP)                                                                                  \
+  _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) v = OP(v, __shfl_xor(v, o, 64));
+#else
+#define OFB_DPP_F(x, ctrl, bank) __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, x), __builtin_bit_cast(int, x), (ctrl), 0xF, (bank), false))
+#define OFB_WAVE_REDUCE(v, OP)                                                                                  \
+  {                                                                                                             \
+    const unsigned ub_ = __builtin_bit_cast(unsigned, v);                                                       \
+    const auto r32_ = __builtin_amdgcn_permlane32_swap(ub_, ub_, false, false);                                 \
+    v = OP(__builtin_bit_cast(float, (unsigned)r32_[0]), __builtin_bit_cast(float, (unsigned)r32_[1]));        \
+    const unsigned uc_ = __builtin_bit_cast(unsigned, v);                                                       \
+    const auto r16_ = __builtin_amdgcn_permlane16_swap(uc_, uc_, false, false);                                 \
+    v = OP(__builtin_bit_cast(float, (unsigned)r16_[0]), __builtin_bit_cast(float, (unsigned)r16_[1]));        \
+    v = OP(v, OFB_DPP_F(v, 0x128, 0xF));                       /* row_ror:8 = lane ^ 8 */                        \
+    {                                                          /* lane ^ 4: banks 0, 2 take lane + 4 (row_shl:4), banks 1, 3 lane - 4 (row_shr:4) */ \
+      int t_ = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x104, 0xF, 0x5, false);                         \
+      t_ = __builtin_amdgcn_update_dpp(t_, __builtin_bit_cast(int, v), 0x114, 0xF, 0xA, false);                 \
+      v = OP(v, __builtin_bit_cast(float, t_));                                                                 \
+    }                                                                                                           \
+    v = OP(v, OFB_DPP_F(v, 0x4E, 0xF));                        /* quad_perm [2,3,0,1] = lane ^ 2 */              \
+    v = OP(v, OFB_DPP_F(v, 0xB1, 0xF));                        /* quad_perm [1,0,3,2] = lane ^ 1 */              \
+  }
+#endif
+__device__ __forceinline__ float ofb_add_(float a, float b) { return a + b; }
 __device__ __forceinline__ float ofb_wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  OFB_WAVE_REDUCE(v, ofb_add_)
   return v;
 }
 __device__ __forceinline__ float ofb_wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  OFB_WAVE_REDUCE(v, fmaxf)
   return v;
 }
 

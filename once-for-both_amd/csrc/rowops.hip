@@ -268,25 +268,34 @@ __device__ __forceinline__ void ln_p_store(char* __restrict__ P, int ncb, int rg
     }
   }
 }
+// (every lane reads an in-bounds address - lanes past the row's end re-read its first pair and drop it -: no branch around the load.  With
+//  the loads behind `if (c < D)` hipcc put a vmcnt(0) at every join and the rows of a group arrived in four round trips instead of one)
 template <int NJ>
 __device__ __forceinline__ void ln_p_load(float (&v)[2 * NJ], const float* __restrict__ p, int D, int lane) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = (j * 64 + lane) * 2;
-    float2 t = make_float2(0.f, 0.f);
-    if (c < D) t = *reinterpret_cast<const float2*>(p + c);
-    v[2 * j] = t.x; v[2 * j + 1] = t.y;
+    const bool in = c < D;
+    const float2 t = *reinterpret_cast<const float2*>(p + (in ? c : 0));
+    v[2 * j] = in ? t.x : 0.f; v[2 * j + 1] = in ? t.y : 0.f;
   }
 }
-// the same for rows that are not read again in this pass (saved activations and incoming gradients in the backward)
+// the same for rows that are not read again in this pass (saved activations and incoming gradients in the backward); the widest rows
+// keep the branch (the redirected offsets cost the registers that decide their occupancy)
 template <int NJ>
 __device__ __forceinline__ void ln_p_load_nt(float (&v)[2 * NJ], const float* __restrict__ p, int D, int lane) {
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int c = (j * 64 + lane) * 2;
-    float2 t = make_float2(0.f, 0.f);
-    if (c < D) { const ofb_f32x2 q = OFB_NT_LOAD(reinterpret_cast<const ofb_f32x2*>(p + c)); t = make_float2(q[0], q[1]); }
-    v[2 * j] = t.x; v[2 * j + 1] = t.y;
+    const bool in = c < D;
+    if constexpr (NJ <= 3) {
+      const ofb_f32x2 q = OFB_NT_LOAD(reinterpret_cast<const ofb_f32x2*>(p + (in ? c : 0)));
+      v[2 * j] = in ? q[0] : 0.f; v[2 * j + 1] = in ? q[1] : 0.f;
+    } else {
+      ofb_f32x2 q = {0.f, 0.f};
+      if (in) q = OFB_NT_LOAD(reinterpret_cast<const ofb_f32x2*>(p + c));
+      v[2 * j] = q[0]; v[2 * j + 1] = q[1];
+    }
   }
 }
 
@@ -295,9 +304,15 @@ __global__ __launch_bounds__(256) void ln_fwd_p_kernel(const float* __restrict__
                                                        const float* __restrict__ beta, float* __restrict__ y, char* __restrict__ yP,
                                                        float* __restrict__ mean, float* __restrict__ rstd, int rows, int D, float eps) {
   constexpr int NE = 2 * NJ;
-  const int lane = threadIdx.x & 63, rg = blockIdx.x * 4 + (threadIdx.x >> 6);
+  // (the wave index as a scalar: row bases then live in SGPRs and the row loads are base + one per-lane offset + immediates)
+  const int lane = threadIdx.x & 63, rg = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (4 * rg >= rows) return;
   float g[NE], b[NE], v[4][NE];
+  // the four rows are requested FIRST, gamma / beta and the bound of the output behind them (one memory round trip for the lot: the
+  // kernel is one pass of short waves - whatever a wave waits for before its rows are under way is added to the whole launch)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) ln_p_load<NJ>(v[r], x + (size_t)min(4 * rg + r, rows - 1) * D, D, lane);
+  __builtin_amdgcn_sched_barrier(0);                       // (left alone hipcc sinks the row loads below the bound's wait for gamma / beta)
   ln_p_load<NJ>(g, gamma, D, lane);
   ln_p_load<NJ>(b, beta, D, lane);
   float binf, rn2;
@@ -306,31 +321,42 @@ __global__ __launch_bounds__(256) void ln_fwd_p_kernel(const float* __restrict__
   if (blockIdx.x == 0 && threadIdx.x == 0) { ofb_hhdr* h = reinterpret_cast<ofb_hhdr*>(yP); h->e = he; h->amax = binf; h->rn2sq = rn2; h->cn2sq = 0.f; }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = 4 * rg + r;
-    if (row < rows) ln_p_load<NJ>(v[r], x + (size_t)row * D, D, lane);
-    else {
+    if (4 * rg + r >= rows) {                              // padding rows of the last row group: zero planes
 #pragma unroll
       for (int i = 0; i < NE; ++i) v[r][i] = 0.f;
     }
   }
+  // the four rows' statistics side by side: four independent reduction chains per step instead of eight chains one after the other
+  // (per row the same operations in the same order as before)
+  float mu[4], rs[4];
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    const int row = 4 * rg + r;
-    if (row >= rows) continue;                             // padding rows of the last row group stay zero
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NE; ++i) s += v[r][i];
-    const float mu = ofb_wave_sum(s) / (float)D;
+    mu[r] = s;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) mu[r] = ofb_wave_sum(mu[r]) / (float)D;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < NE; ++i) {
       const int c = ((i >> 1) * 64 + lane) * 2 + (i & 1);
-      const float d = (c < D) ? v[r][i] - mu : 0.f;
+      const float d = (c < D) ? v[r][i] - mu[r] : 0.f;
       q += d * d;
     }
-    const float rs = 1.0f / sqrtf(ofb_wave_sum(q) / (float)D + eps);
+    rs[r] = q;
+  }
 #pragma unroll
-    for (int i = 0; i < NE; ++i) v[r][i] = (v[r][i] - mu) * rs * g[i] + b[i];     // columns >= D: g = b = 0 -> 0
+  for (int r = 0; r < 4; ++r) rs[r] = 1.0f / sqrtf(ofb_wave_sum(rs[r]) / (float)D + eps);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = 4 * rg + r;
+    if (row >= rows) continue;                             // padding rows of the last row group stay zero
+#pragma unroll
+    for (int i = 0; i < NE; ++i) v[r][i] = (v[r][i] - mu[r]) * rs[r] * g[i] + b[i];     // columns >= D: g = b = 0 -> 0
     if (y) {
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
@@ -338,7 +364,7 @@ __global__ __launch_bounds__(256) void ln_fwd_p_kernel(const float* __restrict__
         if (c < D) *reinterpret_cast<float2*>(y + (size_t)row * D + c) = make_float2(v[r][2 * j], v[r][2 * j + 1]);
       }
     }
-    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    if (lane == 0) { mean[row] = mu[r]; rstd[row] = rs[r]; }
   }
   const int Dp = (D + 15) & ~15;
   ln_p_store<NJ>(yP + OFB_HHDR, Dp >> 4, rg, lane, Dp, v, ofb_h_pow2(he));
@@ -353,27 +379,45 @@ __global__ __launch_bounds__(256) void ln_bwd_p_kernel(const float* __restrict__
                                                        const float* __restrict__ stat, int stat_nb, float rn_fac) {
   constexpr int NE = 2 * NJ;
   __shared__ float red[4 * 3 * 128 * NJ];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // (scalar: row bases in SGPRs)
   const int Dp = (D + 15) & ~15;
   float g[NE], ag[NE], ab[NE], ac[NE];
   ln_p_load<NJ>(g, gamma, D, lane);
   const float hs = ofb_h_pow2(ofb_h_exp(ln_stat_gather(stat, stat_nb, red, reinterpret_cast<ofb_hhdr*>(dxP), rowscale, (rows + rs_div - 1) / rs_div, rn_fac)));
 #pragma unroll
   for (int i = 0; i < NE; ++i) ag[i] = ab[i] = ac[i] = 0.f;
+  // A row group's x and dy rows, statistics and row factors are requested together, before anything is used (12 KB in flight per wave
+  // at D = 384; row by row it was 3 KB, with the row factor's own round trip behind every row) - round 6, scripts/lab/ln_bench.py.
+  // Wider rows keep fewer rows in flight (registers).
+  constexpr int RH = NJ <= 3 ? 4 : 1;
   for (int rg = blockIdx.x * 4 + w; 4 * rg < rows; rg += gridDim.x * 4) {
+    float xv[4][NE], dv[4][NE], mu4[4], rs4[4], sc4[4];
+    auto request = [&](int r0) {
+#pragma unroll
+      for (int q = r0; q < r0 + RH; ++q) {
+        const int row = min(4 * rg + q, rows - 1);          // (rows past the end re-read the last one; they are dropped below)
+        ln_p_load_nt<NJ>(xv[q], x + (size_t)row * D, D, lane);
+        ln_p_load_nt<NJ>(dv[q], dy + (size_t)row * D, D, lane);
+        mu4[q] = mean[row]; rs4[q] = rstd[row];
+        sc4[q] = rowscale ? rowscale[rs_div == 1 ? row : row / rs_div] : 1.f;
+      }
+    };
+    request(0);
     float o[4][NE];                                        // dx * rowscale of the group's rows
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
+      if (r > 0 && r % RH == 0) request(r);
       const int row = 4 * rg + r;
       if (row >= rows) {
 #pragma unroll
         for (int i = 0; i < NE; ++i) o[r][i] = 0.f;
         continue;
       }
-      float v[NE], d[NE];
-      ln_p_load_nt<NJ>(v, x + (size_t)row * D, D, lane);
-      ln_p_load_nt<NJ>(d, dy + (size_t)row * D, D, lane);
-      const float mu = mean[row], rs = rstd[row];
+      float (&v)[NE] = xv[r];
+      float (&d)[NE] = dv[r];
+      float rr[NE];
+      if (NJ <= 3 && dres) ln_p_load<NJ>(rr, dres + (size_t)row * D, D, lane);          // (in flight under the row's two reductions)
+      const float mu = mu4[r], rs = rs4[r];
       float s1 = 0.f, s2 = 0.f;
 #pragma unroll
       for (int i = 0; i < NE; ++i) {
@@ -391,12 +435,11 @@ __global__ __launch_bounds__(256) void ln_bwd_p_kernel(const float* __restrict__
 #pragma unroll
       for (int i = 0; i < NE; ++i) v[i] = rs * (d[i] - c1 - v[i] * c2);
       if (dres) {
-        float rr[NE];
-        ln_p_load<NJ>(rr, dres + (size_t)row * D, D, lane);
+        if (NJ > 3) ln_p_load<NJ>(rr, dres + (size_t)row * D, D, lane);     // (wide rows: registers)
 #pragma unroll
         for (int i = 0; i < NE; ++i) v[i] += rr[i];
       }
-      const float sc = rowscale ? rowscale[rs_div == 1 ? row : row / rs_div] : 1.f;
+      const float sc = sc4[r];
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
         const int c = (j * 64 + lane) * 2;
