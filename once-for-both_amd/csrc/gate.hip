@@ -29,8 +29,14 @@ __global__ __launch_bounds__(256) void gates_fwd_kernel(const ofb_gate_desc* __r
   __shared__ float hs[16];
   __shared__ int rank_h[16];
   __shared__ float red[4];
-  const ofb_gate_desc& d = descs[blockIdx.y];
+  // the module's descriptor is copied into LDS first (94 words, one coalesced read): its fields - thresholds inside the cell loops,
+  // pointers, shapes - were otherwise re-fetched from global memory wherever they are used, a chain of small dependent round trips
+  __shared__ ofb_gate_desc dsh;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  static_assert(sizeof(ofb_gate_desc) % 4 == 0 && sizeof(ofb_gate_desc) / 4 <= 256, "descriptor copy");
+  if (t < (int)(sizeof(ofb_gate_desc) / 4)) reinterpret_cast<unsigned*>(&dsh)[t] = reinterpret_cast<const unsigned*>(&descs[blockIdx.y])[t];
+  __syncthreads();
+  const ofb_gate_desc& d = dsh;
   const int HC = d.H * d.C, cells = d.A0 * d.A1;
   if ((int)blockIdx.x * 256 >= HC) return;
   cell_softmax(d, p, t);
@@ -65,7 +71,27 @@ __global__ __launch_bounds__(256) void gates_fwd_kernel(const ofb_gate_desc* __r
     const int h = e / d.C, c = e % d.C;
     const float sc = d.score[e];
     int rc = 0;
-    if (staged) {
+    if (staged && d.C % 64 == 0) {
+      // a wave's 64 elements are 64 consecutive columns cw .. cw + 63 of ONE row: left of them every lane counts o >= sc, right of
+      // them o > sc - one compare and one add per element; the tie rule with its column test (seven instructions per element, ~11 k
+      // per thread on a 1536-wide MLP row: most of this launch's 46 us) is only needed inside the wave's own 64 columns
+      const float* row = srow + (h - h0) * d.C;
+      const int cw = __builtin_amdgcn_readfirstlane(c), C = d.C;
+      int k = 0;
+      for (; k < cw; k += 4) {
+        const float o0 = row[k], o1 = row[k + 1], o2 = row[k + 2], o3 = row[k + 3];
+        rc += (o0 >= sc) + (o1 >= sc) + (o2 >= sc) + (o3 >= sc);
+      }
+      for (; k < cw + 64; k += 4) {
+        const float o0 = row[k], o1 = row[k + 1], o2 = row[k + 2], o3 = row[k + 3];
+        rc += ((o0 > sc) || (o0 == sc && k < c)) + ((o1 > sc) || (o1 == sc && k + 1 < c)) + ((o2 > sc) || (o2 == sc && k + 2 < c)) +
+              ((o3 > sc) || (o3 == sc && k + 3 < c));
+      }
+      for (; k < C; k += 4) {
+        const float o0 = row[k], o1 = row[k + 1], o2 = row[k + 2], o3 = row[k + 3];
+        rc += (o0 > sc) + (o1 > sc) + (o2 > sc) + (o3 > sc);
+      }
+    } else if (staged) {
       const float* row = srow + (h - h0) * d.C;
       int k = 0;
       for (; k + 4 <= d.C; k += 4) {
@@ -138,9 +164,15 @@ __global__ __launch_bounds__(256) void gates_bwd_kernel(const ofb_gate_desc* __r
                                                         const ofb_gate_grad* __restrict__ grads) {
   __shared__ float p[64];
   __shared__ float dp[64];
-  const ofb_gate_desc& d = descs[blockIdx.x];
-  const ofb_gate_grad& gr = grads[blockIdx.x];
+  __shared__ ofb_gate_desc dsh;                              // (descriptor and gradient table entry in LDS: see gates_fwd_kernel)
+  __shared__ ofb_gate_grad gsh;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  static_assert(sizeof(ofb_gate_grad) % 4 == 0 && sizeof(ofb_gate_grad) / 4 <= 256, "gradient entry copy");
+  if (t < (int)(sizeof(ofb_gate_desc) / 4)) reinterpret_cast<unsigned*>(&dsh)[t] = reinterpret_cast<const unsigned*>(&descs[blockIdx.x])[t];
+  if (t < (int)(sizeof(ofb_gate_grad) / 4)) reinterpret_cast<unsigned*>(&gsh)[t] = reinterpret_cast<const unsigned*>(&grads[blockIdx.x])[t];
+  __syncthreads();
+  const ofb_gate_desc& d = dsh;
+  const ofb_gate_grad& gr = gsh;
   const int HC = d.H * d.C, cells = d.A0 * d.A1;
   if (t < 64) p[t] = (t < cells) ? d.prob[t] : 0.f;
   int n_on = 0;
@@ -159,13 +191,36 @@ __global__ __launch_bounds__(256) void gates_bwd_kernel(const ofb_gate_desc* __r
     const int i = cell / d.A1, j = cell % d.A1;
     const int ht = d.head_thr[i], ct = d.chan_thr[j];
     float s = 0.f;
-    if (d.on[cell])
-      for (int e = lane; e < HC; e += 64) {
-        const int rk = d.rank[e], rh = rk >> 16, rc = rk & 0xffff;
-        float up = (gr.dg ? (1.0f - d.w_p) * gr.dg[e] : 0.f) + (gr.dwr ? gr.dwr[e] : 0.f);
-        s += (rh < ht && rc < ct) ? up : 0.f;
-        if (gr.dwm) s += ((e / d.C) < ht && (e % d.C) < ct) ? gr.dwm[e] : 0.f;
+    if (d.on[cell]) {
+      // four sweeps' loads in flight together (one sweep at a time this loop was 24 dependent round trips on a 1536-wide module);
+      // the sum keeps its order: element e, then e + 64, ...
+      const float wq = 1.0f - d.w_p;
+      const int C = d.C;
+      const float* dg = gr.dg; const float* dwr = gr.dwr; const float* dwm = gr.dwm; const int* rank = d.rank;
+      int e = lane;
+      for (; e + 192 < HC; e += 256) {
+        int rk[4]; float a[4], b[4], m[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int eu = e + 64 * u;
+          rk[u] = rank[eu];
+          a[u] = dg ? dg[eu] : 0.f; b[u] = dwr ? dwr[eu] : 0.f; m[u] = dwm ? dwm[eu] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int eu = e + 64 * u, rh = rk[u] >> 16, rc = rk[u] & 0xffff;
+          const float up = (dg ? wq * a[u] : 0.f) + b[u];
+          s += (rh < ht && rc < ct) ? up : 0.f;
+          if (dwm) s += ((eu / C) < ht && (eu % C) < ct) ? m[u] : 0.f;
+        }
       }
+      for (; e < HC; e += 64) {
+        const int rk = rank[e], rh = rk >> 16, rc = rk & 0xffff;
+        float up = (dg ? wq * dg[e] : 0.f) + (dwr ? dwr[e] : 0.f);
+        s += (rh < ht && rc < ct) ? up : 0.f;
+        if (dwm) s += ((e / C) < ht && (e % C) < ct) ? dwm[e] : 0.f;
+      }
+    }
     s = ofb_wave_sum(s);
     if (lane == 0) dp[cell] = s + dws * (float)(ht * ct);
   }

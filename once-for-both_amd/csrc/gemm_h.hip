@@ -102,22 +102,42 @@ __device__ __forceinline__ void store_h4(char* slot, float v0, float v1, float v
 // ---- statistics + conversion f32 <-> H-format ---------------------------------------------------------------------
 // value = X * rowscale[r / rs_div] (optional).  Stage 1: hdr.amax = max|value|, hdr.rn2sq = max_r sum_c value^2 by atomic max
 // (header zeroed by a memset node ahead of the launch); one wave per row, grid-stride.
+// One wave's rows r_first, r_first + r_stride, ...: FOUR rows at a time - their loads are in flight together and their row sums are
+// reduced side by side (one row at a time every row cost a memory round trip and a reduction chain of its own: the bound passes ran
+// at 9 % of the HBM rate).  Per row the same sum in the same order; rows past the end take part with factor 0.
+__device__ __forceinline__ void hstat_rows(const float* __restrict__ X, size_t ld, int R, int C, int r_first, int r_stride,
+                                           const float* __restrict__ rowscale, int rs_div, int lane, float& am, float& rn) {
+  for (int r = r_first; r < R; r += 4 * r_stride) {
+    const float* row[4];
+    float sc[4], ss[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int rk = r + k * r_stride;
+      const bool ok = rk < R;
+      const int rr = ok ? rk : r;
+      row[k] = X + (size_t)rr * ld;
+      sc[k] = !ok ? 0.f : (rowscale ? rowscale[rs_div == 1 ? rr : rr / rs_div] : 1.f);
+      ss[k] = 0.f;
+    }
+    for (int c = lane; c < C; c += 64) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float v = row[k][c] * sc[k];
+        am = fmaxf(am, fabsf(v));
+        ss[k] += v * v;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ss[k] = ofb_wave_sum(ss[k]);
+    rn = fmaxf(fmaxf(rn, fmaxf(ss[0], ss[1])), fmaxf(ss[2], ss[3]));
+  }
+}
 __global__ __launch_bounds__(256) void hstat_kernel(const float* __restrict__ X, int R, int C, int ld, ofb_hhdr* __restrict__ hdr,
                                                     const float* __restrict__ rowscale, int rs_div) {
   __shared__ float red[2][4];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float am = 0.f, rn = 0.f;
-  for (int r = blockIdx.x * 4 + w; r < R; r += gridDim.x * 4) {
-    const float sc = rowscale ? rowscale[rs_div == 1 ? r : r / rs_div] : 1.f;
-    const float* row = X + (size_t)r * ld;
-    float ss = 0.f;
-    for (int c = lane; c < C; c += 64) {
-      const float v = row[c] * sc;
-      am = fmaxf(am, fabsf(v));
-      ss += v * v;
-    }
-    rn = fmaxf(rn, ofb_wave_sum(ss));
-  }
+  hstat_rows(X, (size_t)ld, R, C, blockIdx.x * 4 + w, gridDim.x * 4, rowscale, rs_div, lane, am, rn);
   am = ofb_wave_max_pos(am);
   if (lane == 0) { red[0][w] = am; red[1][w] = rn; }
   __syncthreads();
@@ -202,19 +222,9 @@ constexpr int HM_NB = 32;
 __global__ __launch_bounds__(256) void hstat_multi_kernel(const ofb_hformat_job* __restrict__ jobs, float* __restrict__ scratch) {
   __shared__ float red[2][4];
   const ofb_hformat_job j = jobs[blockIdx.y];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float am = 0.f, rn = 0.f;
-  for (int r = blockIdx.x * 4 + w; r < j.R; r += HM_NB * 4) {
-    const float sc = j.rowscale ? j.rowscale[r] : 1.f;
-    const float* row = j.X + (size_t)r * j.ld;
-    float ss = 0.f;
-    for (int c = lane; c < j.C; c += 64) {
-      const float v = row[c] * sc;
-      am = fmaxf(am, fabsf(v));
-      ss += v * v;
-    }
-    rn = fmaxf(rn, ofb_wave_sum(ss));
-  }
+  hstat_rows(j.X, (size_t)j.ld, j.R, j.C, blockIdx.x * 4 + w, HM_NB * 4, j.rowscale, 1, lane, am, rn);
   am = ofb_wave_max_pos(am);
   if (lane == 0) { red[0][w] = am; red[1][w] = rn; }
   __syncthreads();

@@ -74,7 +74,6 @@ __device__ __forceinline__ void ofb_atomic_max_pos(float* addr, float v) {
   if (__float_as_uint(v) > __hip_atomic_load(a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(a, __float_as_uint(v));
 }
 __device__ __forceinline__ float ofb_wave_max_pos(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  OFB_WAVE_REDUCE(v, fmaxf)                                  // (ofb_common.h: the xor butterfly without the LDS crossbar)
   return v;
 }
