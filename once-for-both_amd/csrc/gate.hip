@@ -269,53 +269,85 @@ __global__ void spars_finalize_kernel(const ofb_gate_desc* __restrict__ descs, i
 
 // FLOPs (MAC) model of vision_transformer.py:759-783 with e = W(0), (sd_l, hid_l) = W(1+2l), W(2+2l), where W(s) is the
 // live staircase sum wsum[live_slot[s]] or, for a module compress() has finished, the constant wconst[s].
-__global__ void flops_loss_kernel(const float* __restrict__ wsum, ofb_flops_cfg c, float* __restrict__ out,
-                                  float* __restrict__ dwsum) {
-  if (threadIdx.x != 0) return;
-  // n: the ACTIVE patch count of the searched model (vision_transformer.py:768: weighted_mask.sum() once a patch-cell compress()
-  // has produced it - a probability-weighted count, so a float - else the full patch count)
-  const double N = c.num_patches, n = c.active_patches ? (double)c.active_patches[0] : (double)c.num_patches, D = c.embed_dim, H = c.num_heads, dh = c.head_dim, hid = c.hidden,
-               P2 = c.patch_area, ncls = c.num_classes, Dln = c.ln_dim > 0 ? c.ln_dim : c.embed_dim;
-  auto slot = [&](int s) { return c.live_slot ? c.live_slot[s] : s; };
-  auto W = [&](int s) { const int j = slot(s); return (double)(j >= 0 ? wsum[j] : c.wconst[s]); };
-  const double e = W(0);
-  double total = N * D * 3.0 * P2, searched = N * e * 3.0 * P2, de = N * 3.0 * P2, dn = 0.0;
-  for (int l = 0; l < c.depth; ++l) {
-    const double sd = W(1 + 2 * l), hh = W(2 + 2 * l);
-    const double aH = c.active_heads ? (double)c.active_heads[l] : H;
-    total += 2.0 * D * N;
-    searched += 2.0 * Dln * n;
-    dn += 2.0 * Dln;
-    total += N * (H * dh * 3.0 * H * dh) + 3.0 * N * H * dh + H * N * dh * N + H * N * N + 5.0 * H * N * N + H * N * N * dh +
-             N * (H * dh * H * dh) + N * H * dh;
-    searched += n * (e * 3.0 * sd) + 3.0 * n * sd + n * n * sd + aH * n * n + 5.0 * aH * n * n + n * n * sd + n * (sd * e) + n * e;
-    const double dsd = n * e * 3.0 + 3.0 * n + n * n + n * n + n * e;
-    dn += e * 3.0 * sd + 3.0 * sd + 2.0 * n * sd + 2.0 * aH * n + 10.0 * aH * n + 2.0 * n * sd + sd * e + e;
-    de += n * 3.0 * sd + n * sd + n;
-    total += (2.0 * D * hid + D + hid) * N;
-    searched += (e * hh + hh * e + e + hh) * n;
-    dn += e * hh + hh * e + e + hh;
-    const double dhh = (2.0 * e + 1.0) * n;
-    de += (2.0 * hh + 1.0) * n;
-    const int ja = slot(1 + 2 * l), jm = slot(2 + 2 * l);
-    if (ja >= 0) dwsum[ja] = (float)dsd;   // provisional: scaled below
-    if (jm >= 0) dwsum[jm] = (float)dhh;
+// One wave.  The 1 + 2 depth staircase sums, their slots and the head counts are fetched side by side into LDS, lane 0 evaluates the
+// model in double precision out of LDS (the same operations in the same order as when it walked global memory: 25 dependent loads
+// through the slot table, then 25 store -> load round trips to scale its own provisional gradients - 12 us), and the lanes write
+// the scaled gradients together.
+constexpr int FL_MAXS = 160;                                // slots held in LDS (depth <= 79; deeper models take the serial path)
+__global__ __launch_bounds__(64) void flops_loss_kernel(const float* __restrict__ wsum, ofb_flops_cfg c, float* __restrict__ out,
+                                                        float* __restrict__ dwsum) {
+  __shared__ double Wsh[FL_MAXS];
+  __shared__ int slot_sh[FL_MAXS];
+  __shared__ float aH_sh[FL_MAXS / 2], dprov[FL_MAXS];
+  __shared__ double kde[2];
+  const int t = threadIdx.x, ns = 1 + 2 * c.depth;
+  const bool lds = ns <= FL_MAXS;
+  if (lds) {
+    for (int s = t; s < ns; s += 64) {
+      const int j = c.live_slot ? c.live_slot[s] : s;
+      slot_sh[s] = j;
+      Wsh[s] = (double)(j >= 0 ? wsum[j] : c.wconst[s]);
+    }
+    for (int l = t; l < c.depth; l += 64) aH_sh[l] = c.active_heads ? (float)c.active_heads[l] : (float)c.num_heads;
+    for (int j = t; j < c.n_live; j += 64) dprov[j] = 0.f;
   }
-  total += D * ncls;
-  searched += e * ncls;
-  de += ncls;
-  total /= 1e9;
-  searched /= 1e9;
-  const double diff = (searched - (double)c.target) / total;
-  const double k = 2.0 * diff / total / 1e9;      // d loss / d searched_raw
-  out[0] = (float)(diff * diff);
-  out[1] = (float)total;
-  out[2] = (float)searched;
-  out[3] = (float)(k * dn);                       // d loss / d active_patches
-  const int je = slot(0);
-  for (int j = 0; j < c.n_live; ++j)
-    if (j != je) dwsum[j] = (float)(k * (double)dwsum[j]);
-  if (je >= 0) dwsum[je] = (float)(k * de);
+  __syncthreads();
+  if (t == 0) {
+    // n: the ACTIVE patch count of the searched model (vision_transformer.py:768: weighted_mask.sum() once a patch-cell compress()
+    // has produced it - a probability-weighted count, so a float - else the full patch count)
+    const double N = c.num_patches, n = c.active_patches ? (double)c.active_patches[0] : (double)c.num_patches, D = c.embed_dim, H = c.num_heads, dh = c.head_dim, hid = c.hidden,
+                 P2 = c.patch_area, ncls = c.num_classes, Dln = c.ln_dim > 0 ? c.ln_dim : c.embed_dim;
+    auto slot = [&](int s) { return lds ? slot_sh[s] : (c.live_slot ? c.live_slot[s] : s); };
+    auto W = [&](int s) { if (lds) return Wsh[s]; const int j = slot(s); return (double)(j >= 0 ? wsum[j] : c.wconst[s]); };
+    auto prov = [&](int j, float v) { if (lds) dprov[j] = v; else dwsum[j] = v; };
+    const double e = W(0);
+    double total = N * D * 3.0 * P2, searched = N * e * 3.0 * P2, de = N * 3.0 * P2, dn = 0.0;
+    for (int l = 0; l < c.depth; ++l) {
+      const double sd = W(1 + 2 * l), hh = W(2 + 2 * l);
+      const double aH = lds ? (double)aH_sh[l] : (c.active_heads ? (double)c.active_heads[l] : H);
+      total += 2.0 * D * N;
+      searched += 2.0 * Dln * n;
+      dn += 2.0 * Dln;
+      total += N * (H * dh * 3.0 * H * dh) + 3.0 * N * H * dh + H * N * dh * N + H * N * N + 5.0 * H * N * N + H * N * N * dh +
+               N * (H * dh * H * dh) + N * H * dh;
+      searched += n * (e * 3.0 * sd) + 3.0 * n * sd + n * n * sd + aH * n * n + 5.0 * aH * n * n + n * n * sd + n * (sd * e) + n * e;
+      const double dsd = n * e * 3.0 + 3.0 * n + n * n + n * n + n * e;
+      dn += e * 3.0 * sd + 3.0 * sd + 2.0 * n * sd + 2.0 * aH * n + 10.0 * aH * n + 2.0 * n * sd + sd * e + e;
+      de += n * 3.0 * sd + n * sd + n;
+      total += (2.0 * D * hid + D + hid) * N;
+      searched += (e * hh + hh * e + e + hh) * n;
+      dn += e * hh + hh * e + e + hh;
+      const double dhh = (2.0 * e + 1.0) * n;
+      de += (2.0 * hh + 1.0) * n;
+      const int ja = slot(1 + 2 * l), jm = slot(2 + 2 * l);
+      if (ja >= 0) prov(ja, (float)dsd);   // provisional: scaled below
+      if (jm >= 0) prov(jm, (float)dhh);
+    }
+    total += D * ncls;
+    searched += e * ncls;
+    de += ncls;
+    total /= 1e9;
+    searched /= 1e9;
+    const double diff = (searched - (double)c.target) / total;
+    const double k = 2.0 * diff / total / 1e9;      // d loss / d searched_raw
+    out[0] = (float)(diff * diff);
+    out[1] = (float)total;
+    out[2] = (float)searched;
+    out[3] = (float)(k * dn);                       // d loss / d active_patches
+    kde[0] = k; kde[1] = de;
+    if (!lds) {
+      const int je = slot(0);
+      for (int j = 0; j < c.n_live; ++j)
+        if (j != je) dwsum[j] = (float)(k * (double)dwsum[j]);
+      if (je >= 0) dwsum[je] = (float)(k * de);
+    }
+  }
+  __syncthreads();
+  if (lds) {
+    const double k = kde[0], de = kde[1];
+    const int je = slot_sh[0];
+    for (int j = t; j < c.n_live; j += 64) dwsum[j] = (j == je) ? (float)(k * de) : (float)(k * (double)dprov[j]);
+  }
 }
 
 }  // namespace

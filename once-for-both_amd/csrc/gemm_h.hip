@@ -202,18 +202,18 @@ __global__ void patchify_hformat_kernel(const float* __restrict__ img, int B, in
   const int gw = Ww / patch, L = (Hh / patch) * gw, R = B * L, Cc = Cin * patch * patch;
   const int c = blockIdx.x * blockDim.x + threadIdx.x, rg = blockIdx.y;
   if (c >= ncb * 16) return;
-  const int ch = c / (patch * patch), rem = c - ch * patch * patch, i = rem / patch, j = rem - i * patch;
+  // (in-bounds addresses for every lane, no branch around the four loads: they leave together)
+  const int cc = min(c, Cc - 1);
+  const int ch = cc / (patch * patch), rem = cc - ch * patch * patch, i = rem / patch, j = rem - i * patch;
   float v[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const int r = 4 * rg + t;
-    float x = 0.f;
-    if (r < R && c < Cc) {
-      const int b = r / L, l = r - b * L, py = l / gw, px = l - py * gw;
-      x = img[(((size_t)b * Cin + ch) * Hh + py * patch + i) * Ww + px * patch + j];
-    }
-    v[t] = x * s;
+    const int r = 4 * rg + t, rc = min(r, R - 1);
+    const int b = rc / L, l = rc - b * L, py = l / gw, px = l - py * gw;
+    v[t] = img[(((size_t)b * Cin + ch) * Hh + py * patch + i) * Ww + px * patch + j];
   }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) v[t] = (4 * rg + t < R && c < Cc) ? v[t] * s : 0.f;
   ofb_store_h4(P + OFB_HHDR, ncb, rg, c, v[0], v[1], v[2], v[3]);
 }
 // Many matrices in ONE launch pair (the weights of the model, once per optimizer step).  Stage 1: HM_NB blocks per job leave their

@@ -37,20 +37,35 @@ __global__ __launch_bounds__(256) void embed_assemble_bwd_kernel(const float* __
     const float gc = g ? g[c] : 1.0f, pc = pos[(size_t)t * D + c];
     const float mt = mtok ? mtok[c] : 0.f, cl = (t == 0) ? cls[c] : 0.f;
     float apos = 0.f, ag = 0.f, amt = 0.f;
-    for (int b = b0; b < b1; ++b) {
-      const float d = dtok[((size_t)b * (L + 1) + t) * D + c];
-      if (t == 0) {
-        apos += d * gc;
-        ag += d * (cl + pc);
-      } else {
-        const float m = mask ? mask[b * L + t - 1] : 0.f;
-        const size_t ci = ((size_t)b * L + t - 1) * D + c;
-        const float cv = conv[ci];
-        const float dk = d * gc * (1.0f - m);
-        dconv[ci] = dk;
-        apos += dk;
-        amt += d * gc * m;
-        ag += d * ((cv + pc) * (1.0f - m) + m * mt);
+    // four images' loads in flight together (one image at a time the sweep was a chain of dependent round trips: 45 us for 116 MB);
+    // the sums keep their order: image b, then b + 1, ...
+    for (int bb = b0; bb < b1; bb += 4) {
+      float d4[4], m4[4], cv4[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = min(bb + u, b1 - 1);                   // (past the chunk's end: re-read its last image, dropped below)
+        d4[u] = dtok[((size_t)b * (L + 1) + t) * D + c];
+        m4[u] = (t > 0 && mask) ? mask[b * L + t - 1] : 0.f;
+        cv4[u] = (t > 0) ? conv[((size_t)b * L + t - 1) * D + c] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int b = bb + u;
+        if (b >= b1) break;
+        const float d = d4[u];
+        if (t == 0) {
+          apos += d * gc;
+          ag += d * (cl + pc);
+        } else {
+          const float m = m4[u];
+          const size_t ci = ((size_t)b * L + t - 1) * D + c;
+          const float cv = cv4[u];
+          const float dk = d * gc * (1.0f - m);
+          dconv[ci] = dk;
+          apos += dk;
+          amt += d * gc * m;
+          ag += d * ((cv + pc) * (1.0f - m) + m * mt);
+        }
       }
     }
     const size_t o = ((size_t)z * (L + 1) + t) * D + c;

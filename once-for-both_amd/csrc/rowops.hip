@@ -576,6 +576,15 @@ __global__ __launch_bounds__(1024) void colsum_multi_kernel(const ofb_colsum_job
   float s0 = 0.f, s1 = 0.f;                                // two loads in flight per thread; rows w, w + 16, ... added in order
   if (col < j.N) {
     int r = w;
+    // (eight loads in flight, added in the same order as the two-at-a-time loop below would: 1024 rows of partials were 32 dependent
+    //  round trips per thread)
+    for (; r + 112 < j.M; r += 128) {
+      float a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { a[u] = j.x[(size_t)(r + 32 * u) * j.ld + col]; b[u] = j.x[(size_t)(r + 32 * u + 16) * j.ld + col]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s0 += a[u]; s1 += b[u]; }
+    }
     for (; r + 16 < j.M; r += 32) { s0 += j.x[(size_t)r * j.ld + col]; s1 += j.x[(size_t)(r + 16) * j.ld + col]; }
     if (r < j.M) s0 += j.x[(size_t)r * j.ld + col];
   }

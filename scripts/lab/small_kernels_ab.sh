@@ -12,7 +12,7 @@ import csv, glob, sys
 f = glob.glob(f'/tmp/sk_{sys.argv[1]}/**/*kernel_stats.csv', recursive=True)[0]
 for r in csv.DictReader(open(f)):
     n = r['Name']
-    if any(k in n for k in ('gates_fwd', 'gates_bwd', 'hstat', 'spars_finalize', 'flops_loss', 'to_hformat_kernel', 'to_hformat_multi', 'ln_bwd_p', 'ln_fwd_p', 'colsum_multi')):
+    if any(k in n for k in ('gates_fwd', 'gates_bwd', 'hstat', 'spars_finalize', 'flops_loss', 'to_hformat_kernel', 'to_hformat_multi', 'ln_bwd_p', 'ln_fwd_p', 'colsum_multi', 'embed_assemble', 'patchify', 'norm_targets', 'adamw', 'ln_bwd_kernel', 'ln_bwd_stat')):
         import re
         k = re.search(r'(\w+_kernel)', n)
         print(f"{(k.group(1) if k else n[:40]):34s} calls {r['Calls']:>6s} avg {float(r['AverageNs']) / 1e3:8.1f} us")
