@@ -23,6 +23,42 @@ __global__ __launch_bounds__(256) void embed_assemble_fwd_kernel(const float* __
   }
 }
 
+// the same for D % 4 == 0: a block takes FOUR token rows, a thread float4 columns, both trips' loads in flight together (one 1.5-KB
+// row per 256-thread block was 25 k tiny blocks: 27 us for 77 MB)
+__global__ __launch_bounds__(256) void embed_assemble_fwd4_kernel(const float* __restrict__ conv, const float* __restrict__ g,
+                                                                  const float* __restrict__ pos, const float* __restrict__ cls,
+                                                                  const float* __restrict__ mtok, const float* __restrict__ mask,
+                                                                  float* __restrict__ tok, int B, int L, int D) {
+  const int D4 = D >> 2, rows = B * (L + 1), items = 4 * D4;
+  f32x4 cv[2], pv[2], gv[2], mv[2];
+  float m[2];
+  int rowi[2], c4i[2], ti[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int it = threadIdx.x + 256 * u;
+    const int r = it / D4, c4 = it - r * D4, row = min(blockIdx.x * 4 + r, rows - 1);
+    const int b = row / (L + 1), t = row - b * (L + 1);
+    rowi[u] = (it < items && blockIdx.x * 4 + r < rows) ? row : -1; c4i[u] = c4; ti[u] = t;
+    m[u] = (t > 0 && mask) ? mask[b * L + t - 1] : 0.f;
+    cv[u] = (t > 0) ? reinterpret_cast<const f32x4*>(conv + ((size_t)b * L + t - 1) * D)[c4] : reinterpret_cast<const f32x4*>(cls)[c4];
+    pv[u] = reinterpret_cast<const f32x4*>(pos + (size_t)t * D)[c4];
+    gv[u] = g ? reinterpret_cast<const f32x4*>(g)[c4] : f32x4{1.f, 1.f, 1.f, 1.f};
+    mv[u] = mtok ? reinterpret_cast<const f32x4*>(mtok)[c4] : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    if (rowi[u] < 0) continue;
+    f32x4 v;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // (element for element the expressions of embed_assemble_fwd_kernel)
+      const float e = (ti[u] == 0) ? cv[u][k] + pv[u][k] : (cv[u][k] + pv[u][k]) * (1.0f - m[u]) + m[u] * mv[u][k];
+      v[k] = gv[u][k] * e;
+    }
+    reinterpret_cast<f32x4*>(tok + (size_t)rowi[u] * D)[c4i[u]] = v;
+  }
+}
+
 // grid (L+1, chunks): block (t, z) sweeps its batch chunk.  Writes dconv rows and per-(chunk) partials:
 //   ppos[z][t][c] (-> dpos, dcls), pg[z*(L+1)+t][c] (-> dg), pmt[z*(L+1)+t][c] (-> dmask_token)
 __global__ __launch_bounds__(256) void embed_assemble_bwd_kernel(const float* __restrict__ dtok, const float* __restrict__ conv,
@@ -154,9 +190,26 @@ __global__ __launch_bounds__(256) void norm_targets_masked_kernel(const float* _
   const int patch = ids[blockIdx.x], c = blockIdx.y, b = patch / L, l = patch % L, py = l / gw, px = l % gw;
   const float* plane = img + ((size_t)b * C + c) * Hh * Ww;
   const int y0 = py * P - R, x0 = px * P - R, wn = P + K - 1;
-  for (int i = threadIdx.x; i < wn * wn; i += 256) {
-    const int yy = i / wn, xx = i % wn, y = y0 + yy, x = x0 + xx;
-    win[yy * PITCH + xx] = (y >= 0 && y < Hh && x >= 0 && x < Ww) ? plane[(size_t)y * Ww + x] : 0.f;
+  // the window's pixels: every thread's (up to 16) loads leave together, branch-free, and reach LDS afterwards (one element at a time
+  // - load, wait, store - the window cost sixteen dependent round trips per block: most of this launch's 60 us).  Row / column of
+  // element i by a float reciprocal: exact for i < 4096, wn <= 62 (the quotient is never within 0.008 of an integer).
+  {
+    constexpr int NLD = (WIN * WIN + 255) / 256;
+    const float rwn = 1.0f / (float)wn;
+    float tmp[NLD];
+    int at[NLD];
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) {
+      const int i = threadIdx.x + 256 * u;
+      const int yy = (int)(((float)i + 0.5f) * rwn), xx = i - yy * wn, y = y0 + yy, x = x0 + xx;
+      const bool ok = i < wn * wn && y >= 0 && y < Hh && x >= 0 && x < Ww;
+      const float v = plane[ok ? (size_t)y * Ww + x : (size_t)0];
+      tmp[u] = ok ? v : 0.f;
+      at[u] = i < wn * wn ? yy * PITCH + xx : -1;
+    }
+#pragma unroll
+    for (int u = 0; u < NLD; ++u)
+      if (at[u] >= 0) win[at[u]] = tmp[u];
   }
   __syncthreads();
   // horizontal zero-padded window sums of v and v^2 for the P columns of the patch, every row of the window: a thread keeps K + 3
@@ -374,8 +427,14 @@ __global__ __launch_bounds__(256) void adamw_kernel(const ofb_adamw_tensor* __re
 extern "C" int ofb_embed_assemble_fwd(const float* conv, const float* g, const float* pos, const float* cls, const float* mask_token,
                                       const float* mask, float* tokens, int32_t B, int32_t L, int32_t D, void* stream) {
   if (!conv || !pos || !cls || !tokens || B <= 0 || L <= 0 || D <= 0) return OFB_EINVAL;
-  hipLaunchKernelGGL(embed_assemble_fwd_kernel, dim3(B * (L + 1)), dim3(256), 0, (hipStream_t)stream, conv, g, pos, cls,
-                     mask_token, mask, tokens, B, L, D);
+  const bool al16 = ofb_aligned16(conv) && ofb_aligned16(pos) && ofb_aligned16(cls) && ofb_aligned16(tokens) && (!g || ofb_aligned16(g)) &&
+                    (!mask_token || ofb_aligned16(mask_token));
+  if (D % 4 == 0 && D <= 512 && al16)                       // (4 rows x D / 4 float4 items <= 2 x 256 threads)
+    hipLaunchKernelGGL(embed_assemble_fwd4_kernel, dim3(ofb_cdiv(B * (L + 1), 4)), dim3(256), 0, (hipStream_t)stream, conv, g, pos, cls,
+                       mask_token, mask, tokens, B, L, D);
+  else
+    hipLaunchKernelGGL(embed_assemble_fwd_kernel, dim3(B * (L + 1)), dim3(256), 0, (hipStream_t)stream, conv, g, pos, cls,
+                       mask_token, mask, tokens, B, L, D);
   return ofb_launch_status();
 }
 
