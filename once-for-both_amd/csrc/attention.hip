@@ -436,11 +436,18 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
       const float* base = i == 0 ? qbase : (i == 1 ? dobase : obase);
       const int ld = i == 0 ? ldq : ldo;
       const int pos = qb * AB_QB + (t >> 4), d4 = (t & 15) << 2;
-      sreg[i] = zero4();
-      if (valid(pos) && d4 < dh) sreg[i] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(base + (unsigned)(pos * ld + d4)));   // every row is read once
+      // every row is read once.  An in-bounds address for every lane and no branch around the load (positions / channels past the end
+      // re-read the head's first row; stage_store drops them): behind `if (valid) load` hipcc waited for the first block's request
+      // right where it was issued - a memory round trip per problem that the dQ phase was meant to hide (round 6)
+      const bool in = valid(pos) && d4 < dh;
+      sreg[i] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(base + (in ? (unsigned)(pos * ld + d4) : 0u)));
     }
   };
   auto stage_store = [&](int qb) {
+    if (!(valid(qb * AB_QB + (t >> 4)) && ((t & 15) << 2) < dh)) {
+#pragma unroll
+      for (int i = 0; i < 3; ++i) sreg[i] = zero4();
+    }
     {                                                       // -delta of the row and |dO_row|_2: 16 lanes hold its 64 channels
       float d = sreg[1][0] * sreg[2][0] + sreg[1][1] * sreg[2][1] + sreg[1][2] * sreg[2][2] + sreg[1][3] * sreg[2][3];
       float n2 = sreg[1][0] * sreg[1][0] + sreg[1][1] * sreg[1][1] + sreg[1][2] * sreg[1][2] + sreg[1][3] * sreg[1][3];
