@@ -359,6 +359,16 @@ int ofb_ls_cross_entropy(const float* logits, const int64_t* labels, float* row_
  * [B][L-len_keep]): global ids b*L + l of the removed patches, so the decoder can run on those rows only. */
 int ofb_patch_mask(const float* noise, float* mask, int32_t* masked_ids, int32_t B, int32_t L, int32_t len_keep, void* stream);
 
+/* Scalar mixing of one search micro-step's losses (reference losses.py:97-104 `w1*attn + w2*mlp + w4*embed + w5*flops`, engine.py:134-144
+ * `base + arch + stopgrad(base / decoder_loss) * decoder_loss`) in one launch; every input is a device scalar (spars3: three), any may be null:
+ *   out3[0] = arch  = (w0 spars3[0] + w1 spars3[1]) + w2 spars3[2] + w3 flops[0]      (null terms: 0)
+ *   out3[1] = coef  = base / dec                                                       (base or dec null: 0)
+ *   out3[2] = total = (base + arch) + coef * dec
+ * The criterion calls it with (spars3, flops) for `arch`, the engine with (base, flops = arch, w3 = 1, dec) for `total`; the gradients are
+ * the constants w0..w3, 1 and coef (ofb_scale_by_scalar chains them). */
+int ofb_loss_mix(const float* base, const float* spars3, const float* flops, const float* dec, float w0, float w1, float w2, float w3,
+                 float* out3, void* stream);
+
 /* out = x * scalar_dev[0] (chains a device-resident upstream gradient without a host sync) */
 int ofb_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream);
 

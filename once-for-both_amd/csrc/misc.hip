@@ -527,6 +527,27 @@ extern "C" int ofb_patch_mask(const float* noise, float* mask, int32_t* masked_i
   return ofb_launch_status();
 }
 
+// the scalar mixing of a search micro-step's losses in one launch (it was ~14 one-element ATen launches between forward and backward)
+__global__ void loss_mix_kernel(const float* __restrict__ base, const float* __restrict__ spars3, const float* __restrict__ flops,
+                                const float* __restrict__ dec, float w0, float w1, float w2, float w3, float* __restrict__ out3) {
+  if (threadIdx.x != 0) return;
+  float arch = 0.f;
+  if (spars3) arch = (spars3[0] * w0 + spars3[1] * w1) + spars3[2] * w2;
+  if (flops) arch += w3 * flops[0];
+  const float b = base ? base[0] : 0.f;
+  const float coef = (base && dec) ? b / dec[0] : 0.f;
+  out3[0] = arch;
+  out3[1] = coef;
+  out3[2] = dec ? (b + arch) + coef * dec[0] : b + arch;
+}
+
+extern "C" int ofb_loss_mix(const float* base, const float* spars3, const float* flops, const float* dec, float w0, float w1, float w2,
+                            float w3, float* out3, void* stream) {
+  if (!out3) return OFB_EINVAL;
+  hipLaunchKernelGGL(loss_mix_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, base, spars3, flops, dec, w0, w1, w2, w3, out3);
+  return ofb_launch_status();
+}
+
 extern "C" int ofb_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream) {
   if (!x || !scalar_dev || !out || n <= 0) return OFB_EINVAL;
   const int blocks = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);

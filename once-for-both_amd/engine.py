@@ -14,11 +14,16 @@ def mix_losses(loss, decoder_loss):
     """engine.py:134-144: base + arch + stopgrad(base / decoder_loss) * decoder_loss."""
     if isinstance(loss, tuple):
         base, arch = loss
-        total = base + arch
     else:
-        base, arch, total = loss, None, loss
-    if not isinstance(decoder_loss, float):
-        total = total + (base / decoder_loss).detach() * decoder_loss
+        base, arch = loss, None
+    dec = None if isinstance(decoder_loss, float) else decoder_loss
+    if (arch is not None or dec is not None) and isinstance(base, torch.Tensor) and base.is_cuda:
+        from . import ops
+        if ops._scalar_ok(base, arch, dec):
+            return base, arch, ops.TotalLoss.apply(base, arch, dec)       # one launch instead of four one-element ATen kernels
+    total = base if arch is None else base + arch
+    if dec is not None:
+        total = total + (base / dec).detach() * dec
     return base, arch, total
 
 

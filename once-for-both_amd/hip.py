@@ -27,7 +27,7 @@ SYMBOLS = [
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_amax', 'ofb_attention_fwd', 'ofb_attention_fwd_h', 'ofb_attention_bwd', 'ofb_attention_bwd_wgmax',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
-    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak', 'ofb_diag_cu_thief',
+    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_loss_mix', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak', 'ofb_diag_cu_thief',
     'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm', 'ofb_random_erase',
     'ofb_randaug_layer', 'ofb_normalize_u8', 'ofb_jpeg_parse', 'ofb_jpeg_decode_coefficients', 'ofb_jpeg_plan_batch', 'ofb_jpeg_decode_batch', 'ofb_jpeg_decode_pixels',
 ]
@@ -848,6 +848,12 @@ def pmim_loss_bwd(rec, targets, mask, ids, n_rows, out2, upstream, drec, B, L, P
 def ls_cross_entropy(logits, labels, row_loss, loss, grad, B, Cn, smoothing):
     check(lib().ofb_ls_cross_entropy(ptr(logits), ptr(labels), ptr(row_loss), ptr(loss), ptr(grad), _i(B), _i(Cn),
                                      _f(smoothing), stream()), 'ofb_ls_cross_entropy')
+
+
+def loss_mix(base, spars3, flops, dec, w, out3):
+    """out3 = (arch, base / dec, base + arch + (base / dec) * dec) from device scalars (any of the inputs None): include/ofb_hip.h."""
+    check(lib().ofb_loss_mix(ptr(base), ptr(spars3), ptr(flops), ptr(dec), _f(w[0]), _f(w[1]), _f(w[2]), _f(w[3]), ptr(out3), stream()),
+          'ofb_loss_mix')
 
 
 def scale_by_scalar(x, scalar_dev, out, n):

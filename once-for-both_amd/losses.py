@@ -79,10 +79,14 @@ class OFBSearchLOSS(nn.Module):
                 and loss_mlp.data_ptr() == sp.data_ptr() + 4 and loss_embedding.data_ptr() == sp.data_ptr() + 8):
             # the three module terms are the slots of ONE device vector (the gate kernel's output): w1 a + w2 m + w4 e as one weighted
             # sum - 4 launches forward and 2 backward instead of 7 and ~12 (three select-backward fills and their accumulation)
-            key = (float(self.w1), float(self.w2), float(self.w4), sp.device, sp.dtype)
-            if self._w_vec is None or self._w_vec[0] != key:      # the weights are plain attributes: follow later edits
-                self._w_vec = (key, torch.tensor(key[:3], device=sp.device, dtype=sp.dtype))
-            arch = (sp * self._w_vec[1]).sum() + self.w5 * loss_flops
+            if ops._scalar_ok(loss_flops) and sp.is_cuda and sp.dtype == torch.float32 and sp.is_contiguous():
+                # one launch forward, one backward (round 6; the weights are plain attributes: read at every call)
+                arch = ops.ArchLoss.apply(sp, loss_flops, float(self.w1), float(self.w2), float(self.w4), float(self.w5))
+            else:
+                key = (float(self.w1), float(self.w2), float(self.w4), sp.device, sp.dtype)
+                if self._w_vec is None or self._w_vec[0] != key:      # the weights are plain attributes: follow later edits
+                    self._w_vec = (key, torch.tensor(key[:3], device=sp.device, dtype=sp.dtype))
+                arch = (sp * self._w_vec[1]).sum() + self.w5 * loss_flops
         else:
             arch = self.w1 * loss_attn + self.w2 * loss_mlp + self.w4 * loss_embedding + self.w5 * loss_flops
         if self.w3 != 0:

@@ -695,6 +695,59 @@ class LabelSmoothingCE(torch.autograd.Function):
         return out, None, None
 
 
+def _scalar_ok(*ts):
+    return all(t is None or (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == torch.float32 and t.numel() == 1) for t in ts)
+
+
+_w4_cache = {}
+
+
+class ArchLoss(torch.autograd.Function):
+    """w1 * attn + w2 * mlp + w4 * embed + w5 * flops (reference losses.py:97-104) from the gate kernel's 3-slot sparsity vector and the
+    FLOPs loss, one launch forward (ofb_loss_mix) and one backward (the weights times the upstream scalar)."""
+
+    @staticmethod
+    def forward(ctx, spars3, flops, w1, w2, w4, w5):
+        out3 = _new(spars3, 3)
+        hip.loss_mix(None, spars3, flops, None, (w1, w2, w4, w5), out3)
+        key = (float(w1), float(w2), float(w4), float(w5), spars3.device)
+        wv = _w4_cache.get(key)
+        if wv is None:
+            if len(_w4_cache) > 64:
+                _w4_cache.clear()
+            wv = _w4_cache[key] = torch.tensor(key[:4], device=spars3.device, dtype=torch.float32)
+        ctx.wv = wv
+        return out3[0]
+
+    @staticmethod
+    def backward(ctx, up):
+        out = torch.empty_like(ctx.wv)
+        hip.scale_by_scalar(ctx.wv, _c(up).reshape(1), out, 4)
+        return out[:3], out[3], None, None, None, None
+
+
+class TotalLoss(torch.autograd.Function):
+    """base + arch + stopgrad(base / decoder_loss) * decoder_loss (reference engine.py:134-144), one launch forward; backward: the
+    upstream scalar for base and arch, upstream * (base / decoder_loss) for the decoder loss."""
+
+    @staticmethod
+    def forward(ctx, base, arch, dec):
+        out3 = _new(base, 3)
+        hip.loss_mix(base, None, arch, dec, (0.0, 0.0, 0.0, 1.0), out3)
+        ctx.coef = out3[1:2]
+        ctx.has = (arch is not None, dec is not None)
+        return out3[2]
+
+    @staticmethod
+    def backward(ctx, up):
+        ddec = None
+        if ctx.has[1]:
+            ddec = torch.empty_like(ctx.coef)
+            hip.scale_by_scalar(ctx.coef, _c(up).reshape(1), ddec, 1)
+            ddec = ddec[0]
+        return up, (up if ctx.has[0] else None), ddec
+
+
 class FlopsLoss(torch.autograd.Function):
     """((searched - target) / total)^2 over the MAC model of vision_transformer.py:759-783 (base_model.py:31-35).
     n_active: None, or the 0-dim device tensor of the searched model's patch count (vision_transformer.py:768; differentiable

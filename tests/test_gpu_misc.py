@@ -69,3 +69,36 @@ def test_patch_mask_and_ce():
     (loss * 1.7).backward()
     assert abs(float(loss) - float(ref)) < 1e-5
     assert float((ld.grad.cpu() / 1.7 - logits.grad).abs().max()) < 1e-7
+
+
+def test_loss_mixing_is_the_reference_expression():
+    """ops.ArchLoss / ops.TotalLoss (ofb_loss_mix: one launch each) against the expressions of reference losses.py:97-104 and
+    engine.py:134-144 written out in torch: values and every gradient, with and without the arch term / the decoder loss."""
+    import ofb_amd
+    from ofb_amd import ops, engine
+    dev = torch.device('cuda')
+    torch.manual_seed(5)
+    w = (0.5, 0.25, 0.125, 5.0)
+    for with_arch, with_dec in ((True, True), (True, False), (False, True)):
+        leaves = [torch.rand(3, device=dev, requires_grad=True), torch.rand((), device=dev, requires_grad=True),
+                  (torch.rand((), device=dev) + 3).requires_grad_(True), (torch.rand((), device=dev) + 0.5).requires_grad_(True)]
+        res = []
+        for fused in (True, False):
+            sp, fl, base, dec = [x.detach().clone().requires_grad_(True) for x in leaves]
+            if with_arch:
+                arch = ops.ArchLoss.apply(sp, fl, *w) if fused else (sp * torch.tensor(w[:3], device=dev)).sum() + w[3] * fl
+            else:
+                arch = None
+            d = dec if with_dec else 0.
+            if fused:
+                b2, a2, total = engine.mix_losses((base, arch) if with_arch else base, d)
+            else:
+                total = base if arch is None else base + arch
+                if with_dec:
+                    total = total + (base / dec).detach() * dec
+            (total * 1.7).backward()
+            res.append([total.detach()] + [None if x.grad is None else x.grad.clone() for x in (sp, fl, base, dec)])
+        for a, b in zip(*res):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (with_arch, with_dec, a, b)
