@@ -369,6 +369,19 @@ int ofb_patch_mask(const float* noise, float* mask, int32_t* masked_ids, int32_t
 int ofb_loss_mix(const float* base, const float* spars3, const float* flops, const float* dec, float w0, float w1, float w2, float w3,
                  float* out3, void* stream);
 
+/* The two readers of the final token stream stream_rows [B][T][D], T = L + 1 (reference vision_transformer.py:735-744: `x[:, 0]` for the head,
+ * the masked patch tokens for the decoder): cls_out [B][D] = row b T; z_out [n_ids][D] = token row of global patch id p = b L + l, i.e.
+ * stream row p + p / L + 1.  bwd: dstream [B][T][D] = 0 everywhere except those rows (dcls / dz may be null); the rows are disjoint and
+ * unique. */
+int ofb_token_taps_fwd(const float* stream_rows, const int32_t* patch_ids, int32_t n_ids, int32_t B, int32_t T, int32_t D, float* cls_out,
+                       float* z_out, void* stream);
+int ofb_token_taps_bwd(const float* dcls, const float* dz, const int32_t* patch_ids, int32_t n_ids, int32_t B, int32_t T, int32_t D,
+                       float* dstream, void* stream);
+
+/* timm DropPath factors (reference vision_transformer.py:152 `DropPath`): out[r][b] = floor(keep[r] + u[r][b]) / keep[r] for R residual
+ * branches x B samples, u uniform in [0, 1). */
+int ofb_droppath_scales(const float* u, const float* keep, float* out, int32_t R, int32_t B, void* stream);
+
 /* out = x * scalar_dev[0] (chains a device-resident upstream gradient without a host sync) */
 int ofb_scale_by_scalar(const float* x, const float* scalar_dev, float* out, int64_t n, void* stream);
 

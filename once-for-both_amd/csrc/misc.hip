@@ -518,6 +518,63 @@ extern "C" int ofb_ls_cross_entropy(const float* logits, const int64_t* labels, 
   return ofb_launch_status();
 }
 
+// The two readers of the final token stream [B][T = L + 1][D] (vision_transformer.py:735-744): block r < B copies image r's cls row,
+// block B + i the token row of masked patch ids[i] (global patch id p = b L + l -> token row p + p / L + 1).  One launch for what was
+// three index launches, a strided copy and a gather; the backward zero-fills the stream gradient (a memset node) and scatters both
+// kinds of rows (disjoint, unique: plain stores) in one launch.
+__global__ __launch_bounds__(128) void token_taps_kernel(const float* __restrict__ src_stream, const float* __restrict__ rows_cls,
+                                                         const float* __restrict__ rows_z, const int32_t* __restrict__ ids, int B, int T,
+                                                         int D, float* __restrict__ dst_cls, float* __restrict__ dst_z,
+                                                         float* __restrict__ dst_stream) {
+  const int r = blockIdx.x, L = T - 1;
+  size_t srow;                                               // the block's row of the stream
+  if (r < B) srow = (size_t)r * T;
+  else { const int p = ids[r - B]; srow = (size_t)p + p / L + 1; }
+  // gather (dst_stream null): stream row -> compact row; scatter: compact row -> stream row
+  const float* s = dst_stream ? (r < B ? rows_cls + (size_t)r * D : rows_z + (size_t)(r - B) * D) : src_stream + srow * D;
+  float* d = dst_stream ? dst_stream + srow * D : (r < B ? dst_cls + (size_t)r * D : dst_z + (size_t)(r - B) * D);
+  if (s == nullptr) return;                                  // (scatter without that kind of row)
+  if ((D & 3) == 0 && ofb_aligned16_dev(s) && ofb_aligned16_dev(d)) {
+    for (int c = threadIdx.x; c < (D >> 2); c += 128) reinterpret_cast<f32x4*>(d)[c] = reinterpret_cast<const f32x4*>(s)[c];
+  } else {
+    for (int c = threadIdx.x; c < D; c += 128) d[c] = s[c];
+  }
+}
+
+extern "C" int ofb_token_taps_fwd(const float* stream_rows, const int32_t* patch_ids, int32_t n_ids, int32_t B, int32_t T, int32_t D,
+                                  float* cls_out, float* z_out, void* stream) {
+  if (!stream_rows || !cls_out || B <= 0 || T < 2 || D <= 0 || n_ids < 0 || (n_ids > 0 && (!patch_ids || !z_out))) return OFB_EINVAL;
+  hipLaunchKernelGGL(token_taps_kernel, dim3(B + n_ids), dim3(128), 0, (hipStream_t)stream, stream_rows, (const float*)nullptr,
+                     (const float*)nullptr, patch_ids, B, T, D, cls_out, z_out, (float*)nullptr);
+  return ofb_launch_status();
+}
+
+extern "C" int ofb_token_taps_bwd(const float* dcls, const float* dz, const int32_t* patch_ids, int32_t n_ids, int32_t B, int32_t T,
+                                  int32_t D, float* dstream, void* stream) {
+  if (!dstream || B <= 0 || T < 2 || D <= 0 || n_ids < 0 || (dz && n_ids > 0 && !patch_ids)) return OFB_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(dstream, 0, (size_t)B * T * D * sizeof(float), s) != hipSuccess) return OFB_EINVAL;
+  const int n = dz ? n_ids : 0;
+  if (!dcls && n == 0) return ofb_launch_status();
+  hipLaunchKernelGGL(token_taps_kernel, dim3(B + n), dim3(128), 0, s, (const float*)nullptr, dcls, dz, patch_ids, B, T, D, (float*)nullptr,
+                     (float*)nullptr, dstream);
+  return ofb_launch_status();
+}
+
+// timm DropPath factors of all residual branches in one launch: out[r][b] = floor(keep[r] + u[r][b]) / keep[r]
+__global__ void droppath_scales_kernel(const float* __restrict__ u, const float* __restrict__ keep, float* __restrict__ out, int R, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * B) return;
+  const float k = keep[i / B];
+  out[i] = floorf(k + u[i]) / k;
+}
+
+extern "C" int ofb_droppath_scales(const float* u, const float* keep, float* out, int32_t R, int32_t B, void* stream) {
+  if (!u || !keep || !out || R <= 0 || B <= 0) return OFB_EINVAL;
+  hipLaunchKernelGGL(droppath_scales_kernel, dim3(ofb_cdiv(R * B, 256)), dim3(256), 0, (hipStream_t)stream, u, keep, out, R, B);
+  return ofb_launch_status();
+}
+
 extern "C" int ofb_patch_mask(const float* noise, float* mask, int32_t* masked_ids, int32_t B, int32_t L, int32_t len_keep,
                               void* stream) {
   if (!noise || !mask || B <= 0 || L <= 0 || len_keep < 0 || len_keep > L) return OFB_EINVAL;

@@ -12,6 +12,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 static inline int ofb_launch_status() { return (int)hipGetLastError(); }
 static inline bool ofb_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 static inline int ofb_cdiv(int a, int b) { return (a + b - 1) / b; }
+__device__ __forceinline__ bool ofb_aligned16_dev(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
 // profiling hook (prof.hip): brackets a launch with events when enabled
 void ofb_prof_pre(int tag, hipStream_t s, double work);

@@ -27,7 +27,7 @@ SYMBOLS = [
     'ofb_scale_rows', 'ofb_gate_fold_bwd', 'ofb_amax', 'ofb_attention_fwd', 'ofb_attention_fwd_h', 'ofb_attention_bwd', 'ofb_attention_bwd_wgmax',
     'ofb_gates_fwd', 'ofb_gates_bwd', 'ofb_flops_loss',
     'ofb_embed_assemble_fwd', 'ofb_embed_assemble_chunks', 'ofb_embed_assemble_bwd', 'ofb_norm_targets', 'ofb_norm_targets_masked',
-    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_loss_mix', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak', 'ofb_diag_cu_thief',
+    'ofb_pmim_loss_fwd', 'ofb_pmim_loss_bwd', 'ofb_ls_cross_entropy', 'ofb_loss_mix', 'ofb_token_taps_fwd', 'ofb_token_taps_bwd', 'ofb_droppath_scales', 'ofb_scale_by_scalar', 'ofb_index_select', 'ofb_ema_update', 'ofb_adamw_step', 'ofb_adamw_step_dev', 'ofb_nonfinite_watch', 'ofb_multi_copy', 'ofb_upload', 'ofb_patch_mask', 'ofb_diag_mfma_peak', 'ofb_diag_cu_thief',
     'ofb_mixup_batch', 'ofb_mixup_targets', 'ofb_soft_cross_entropy', 'ofb_crop_resize_scratch_bytes', 'ofb_crop_resize_norm', 'ofb_random_erase',
     'ofb_randaug_layer', 'ofb_normalize_u8', 'ofb_jpeg_parse', 'ofb_jpeg_decode_coefficients', 'ofb_jpeg_plan_batch', 'ofb_jpeg_decode_batch', 'ofb_jpeg_decode_pixels',
 ]
@@ -848,6 +848,20 @@ def pmim_loss_bwd(rec, targets, mask, ids, n_rows, out2, upstream, drec, B, L, P
 def ls_cross_entropy(logits, labels, row_loss, loss, grad, B, Cn, smoothing):
     check(lib().ofb_ls_cross_entropy(ptr(logits), ptr(labels), ptr(row_loss), ptr(loss), ptr(grad), _i(B), _i(Cn),
                                      _f(smoothing), stream()), 'ofb_ls_cross_entropy')
+
+
+def token_taps_fwd(stream_rows, patch_ids, n_ids, B, T, D, cls_out, z_out):
+    check(lib().ofb_token_taps_fwd(ptr(stream_rows), ptr(patch_ids), _i(n_ids), _i(B), _i(T), _i(D), ptr(cls_out), ptr(z_out), stream()),
+          'ofb_token_taps_fwd')
+
+
+def token_taps_bwd(dcls, dz, patch_ids, n_ids, B, T, D, dstream):
+    check(lib().ofb_token_taps_bwd(ptr(dcls), ptr(dz), ptr(patch_ids), _i(n_ids), _i(B), _i(T), _i(D), ptr(dstream), stream()),
+          'ofb_token_taps_bwd')
+
+
+def droppath_scales(u, keep, out, R, B):
+    check(lib().ofb_droppath_scales(ptr(u), ptr(keep), ptr(out), _i(R), _i(B), stream()), 'ofb_droppath_scales')
 
 
 def loss_mix(base, spars3, flops, dec, w, out3):

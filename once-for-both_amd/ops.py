@@ -614,23 +614,27 @@ class TokenTaps(torch.autograd.Function):
     rows); here ONE zero tensor receives both (cls rows and masked rows are disjoint and unique: plain copies, no accumulation)."""
 
     @staticmethod
-    def forward(ctx, latent, tok_rows):
+    def forward(ctx, latent, patch_ids):
+        """patch_ids: int32 global patch ids b * L + l of the masked patches (ofb_patch_mask's list); their token rows are computed in
+        the kernel.  One launch forward (ofb_token_taps_fwd), a memset node + one launch backward (round 6: they were five and three)."""
         B, T, D = latent.shape
-        ctx.save_for_backward(tok_rows)
+        latent = _c(latent)
+        n = int(patch_ids.numel())
+        cls, z = _new(latent, B, D), _new(latent, n, D)
+        hip.token_taps_fwd(latent, patch_ids if n else None, n, B, T, D, cls, z if n else None)
+        ctx.save_for_backward(patch_ids)
         ctx.shape = (B, T, D)
-        return latent[:, 0].contiguous(), latent.reshape(B * T, D).index_select(0, tok_rows)
+        return cls, z
 
     @staticmethod
     def backward(ctx, dcls, dz):
-        (tok_rows,) = ctx.saved_tensors
+        (patch_ids,) = ctx.saved_tensors
         B, T, D = ctx.shape
         like = dcls if dcls is not None else dz
-        g = torch.zeros(B * T, D, device=like.device, dtype=like.dtype)
-        if dcls is not None:
-            g.view(B, T, D)[:, 0].copy_(dcls)
-        if dz is not None:
-            g.index_add_(0, tok_rows, dz)                     # (int32 indices are fine here; unique rows: 0 + x)
-        return g.view(B, T, D), None
+        g = torch.empty(B, T, D, device=like.device, dtype=torch.float32)
+        n = int(patch_ids.numel())
+        hip.token_taps_bwd(None if dcls is None else _c(dcls), None if (dz is None or n == 0) else _c(dz), patch_ids if n else None, n, B, T, D, g)
+        return g, None
 
 
 def norm_targets(imgs, ksize=47):

@@ -478,7 +478,12 @@ class MIMVisionTransformer(MAEBaseModel):
             if getattr(self, '_dp_keep', None) is None or self._dp_keep[0] != key:
                 self._dp_keep = (key, torch.tensor([1.0 - rates[i] for i in live for _ in range(2)], device=dev).unsqueeze(1))
             keep = self._dp_keep[1]
-            scales = torch.floor(keep + u[:2 * len(live)]) / keep
+            un = u[:2 * len(live)]
+            if un.is_cuda and un.dtype == torch.float32 and un.is_contiguous():
+                scales = torch.empty_like(un)
+                hip.droppath_scales(un, keep, scales, un.shape[0], un.shape[1])        # floor(keep + u) / keep in one launch
+            else:
+                scales = torch.floor(keep + un) / keep
         for i, blk in enumerate(self.blocks):
             rs = [None, None]
             if scales is not None and rates[i] > 0:
@@ -497,8 +502,7 @@ class MIMVisionTransformer(MAEBaseModel):
             # only masked patches reach the loss (M = 0 elsewhere, vision_transformer.py:724-729): decode just those rows.
             # token row of global patch id p = b*L + l is  b*(L+1) + 1 + l = p + p // L + 1
             ids = self._masked_ids
-            tok_rows = ids + torch.div(ids, L, rounding_mode='floor') + 1
-            cls_rows, z = ops.TokenTaps.apply(latent, tok_rows)
+            cls_rows, z = ops.TokenTaps.apply(latent, ids)
             dec = self.decoder[0]
             rec = ops.Linear.apply(z, dec.weight.view(dec.weight.shape[0], -1), dec.bias)      # 1x1 conv, patch layout
             # norm_targets(imgs, 47) for the masked patches' pixels only: one fused kernel over their 62 x 62 windows

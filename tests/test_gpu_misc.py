@@ -102,3 +102,37 @@ def test_loss_mixing_is_the_reference_expression():
             assert (a is None) == (b is None)
             if a is not None:
                 assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), (with_arch, with_dec, a, b)
+
+
+@pytest.mark.parametrize('B,L,D,n_per', [(5, 196, 384, 10), (3, 9, 66, 4), (2, 16, 40, 0)])
+def test_token_taps_gather_and_scatter(B, L, D, n_per):
+    """ops.TokenTaps (ofb_token_taps_fwd / _bwd): the cls rows and the masked patches' token rows of the final stream, and the stream
+    gradient with exactly those rows set - against index arithmetic written out in torch (reference vision_transformer.py:735-744)."""
+    from ofb_amd import ops
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(B * 1000 + L)
+    T = L + 1
+    latent = torch.randn(B, T, D, device=dev, generator=g, requires_grad=True)
+    ids = torch.cat([b * L + torch.randperm(L, device=dev, generator=g)[:n_per] for b in range(B)]).to(torch.int32) if n_per else \
+        torch.empty(0, device=dev, dtype=torch.int32)
+    cls, z = ops.TokenTaps.apply(latent, ids)
+    rows = (ids + torch.div(ids, L, rounding_mode='floor') + 1).long()
+    assert torch.equal(cls, latent.detach()[:, 0])
+    assert torch.equal(z, latent.detach().reshape(B * T, D)[rows])
+    dcls, dz = torch.randn_like(cls), torch.randn_like(z)
+    (cls * dcls).sum().add((z * dz).sum()).backward()
+    ref = torch.zeros(B * T, D, device=dev)
+    ref.view(B, T, D)[:, 0] = dcls
+    ref[rows] = dz
+    assert torch.equal(latent.grad.reshape(B * T, D), ref)
+
+
+def test_droppath_scales_match_the_timm_expression():
+    from ofb_amd import hip
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(11)
+    u = torch.rand(22, 128, device=dev, generator=g)
+    keep = (1.0 - torch.linspace(0.0, 0.1, 12, device=dev)[1:].repeat_interleave(2)).unsqueeze(1).contiguous()
+    out = torch.empty_like(u)
+    hip.droppath_scales(u, keep, out, 22, 128)
+    assert torch.equal(out, torch.floor(keep + u) / keep)
