@@ -531,9 +531,9 @@ __global__ __launch_bounds__(128) void token_taps_kernel(const float* __restrict
   if (r < B) srow = (size_t)r * T;
   else { const int p = ids[r - B]; srow = (size_t)p + p / L + 1; }
   // gather (dst_stream null): stream row -> compact row; scatter: compact row -> stream row
+  if (dst_stream && (r < B ? rows_cls : rows_z) == nullptr) return;      // (scatter without that kind of row: it stays zero)
   const float* s = dst_stream ? (r < B ? rows_cls + (size_t)r * D : rows_z + (size_t)(r - B) * D) : src_stream + srow * D;
   float* d = dst_stream ? dst_stream + srow * D : (r < B ? dst_cls + (size_t)r * D : dst_z + (size_t)(r - B) * D);
-  if (s == nullptr) return;                                  // (scatter without that kind of row)
   if ((D & 3) == 0 && ofb_aligned16_dev(s) && ofb_aligned16_dev(d)) {
     for (int c = threadIdx.x; c < (D >> 2); c += 128) reinterpret_cast<f32x4*>(d)[c] = reinterpret_cast<const f32x4*>(s)[c];
   } else {

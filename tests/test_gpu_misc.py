@@ -125,6 +125,18 @@ def test_token_taps_gather_and_scatter(B, L, D, n_per):
     ref.view(B, T, D)[:, 0] = dcls
     ref[rows] = dz
     assert torch.equal(latent.grad.reshape(B * T, D), ref)
+    # only one of the two readers has a gradient
+    from ofb_amd import hip
+    for dc, dzz in ((dcls, None), (None, dz)):
+        if dzz is None or ids.numel():
+            g2 = torch.full((B, T, D), float('nan'), device=dev)
+            hip.token_taps_bwd(dc, dzz, ids if ids.numel() else None, int(ids.numel()), B, T, D, g2)
+            ref2 = torch.zeros(B * T, D, device=dev)
+            if dc is not None:
+                ref2.view(B, T, D)[:, 0] = dc
+            if dzz is not None:
+                ref2[rows] = dzz
+            assert torch.equal(g2.reshape(B * T, D), ref2)
 
 
 def test_droppath_scales_match_the_timm_expression():
