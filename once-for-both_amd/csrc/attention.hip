@@ -48,6 +48,9 @@ typedef short att_s16x4 __attribute__((ext_vector_type(4)));
 typedef short att_s16x8 __attribute__((ext_vector_type(8)));
 typedef ofb_f16x8 att_hx8;
 
+#ifndef OFB_ATT_STAGE_OFF_SIMD0
+#define OFB_ATT_STAGE_OFF_SIMD0 1     /* forward: staging by the nine waves that do not sit on SIMD 0 (0: lab, all thirteen stage) */
+#endif
 #define AF_KB 32                       // keys per block
 #define AF_NB ((ATT_NMAX + AF_KB - 1) / AF_KB)      // 7 blocks cover 224 >= 208 keys
 #define AF_PITCH 128                   // bytes per key row of one plane: 64 f16
@@ -134,11 +137,22 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   if (PF && blockIdx.x == 0 && blockIdx.y == 0 && t == 0) { ofb_hhdr* h = reinterpret_cast<ofb_hhdr*>(oP); h->e = he; h->amax = qb; h->rn2sq = 0.f; h->cn2sq = 0.f; }
 
   // staging items: idx < 512 -> K float4 (key = idx/16, d = 4*(idx%16)); 512 <= idx < 1024 -> V float4, same coordinates
+  // Who stages: the thirteen waves sit round-robin on the four SIMDs, so SIMD 0 hosts FOUR of them (0, 4, 8, 12) and paces every key block
+  // (profiles/r06_attention_forward_stamps.txt: everybody waits at the block barrier for wave 12).  The staging - global loads, f16
+  // split, LDS stores - is therefore done by the NINE waves of the other SIMDs, two items each; SIMD 0's waves only multiply.
+#if OFB_ATT_STAGE_OFF_SIMD0
+  const bool stager = (w & 3) != 0;
+  const int sid = stager ? ((w >> 2) * 3 + (w & 3) - 1) * 64 + lane : 1 << 20;      // 0 .. 575 (else: no items)
+  constexpr int SSTRIDE = 576;
+#else
+  const int sid = t;
+  constexpr int SSTRIDE = ATT_THREADS;
+#endif
   f32x4 sreg[3];
   auto stage_load = [&](int kb) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int idx = t + ATT_THREADS * i;
+      const int idx = sid + SSTRIDE * i;
       sreg[i] = zero4();
       if (idx < 1024) {
         const int key = kb * AF_KB + ((idx & 511) >> 4), d4 = (idx & 15) << 2;
@@ -150,7 +164,7 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
     char* st = smem + buf * AF_STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      const int idx = t + ATT_THREADS * i;
+      const int idx = sid + SSTRIDE * i;
       if (idx >= 1024) continue;
       const int kk = (idx & 511) >> 4, d16 = idx & 15, chunk = d16 >> 1;
       unsigned h0, l0, h1, l1;
