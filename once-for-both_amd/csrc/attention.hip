@@ -244,8 +244,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
           S[tk][r] = sv;
           mb = fmaxf(mb, sv);
         }
-      mb = fmaxf(mb, __shfl_xor(mb, 16, 64));
-      mb = fmaxf(mb, __shfl_xor(mb, 32, 64));
+      OFB_XOR_STEP(mb, fmaxf, 16)                         // (register-only exchanges: ofb_common.h)
+      OFB_XOR_STEP(mb, fmaxf, 32)
       const float m_new = fmaxf(m_run, mb);                 // finite from block 0 on (key 0 is always valid)
       const float alpha = __expf(m_run - m_new);
       m_run = m_new;
@@ -283,8 +283,8 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
   }
   if (!active) return;
   float l = l_run;
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
+  OFB_XOR_STEP(l, ofb_add_, 16)
+  OFB_XOR_STEP(l, ofb_add_, 32)
   const float linv = (1.0f / l) * ofb_h_pow2(-(he + ATT_PE));
 #pragma unroll
   for (int dt = 0; dt < 4; ++dt) O[dt] *= linv;
@@ -465,8 +465,8 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
     {                                                       // -delta of the row and |dO_row|_2: 16 lanes hold its 64 channels
       float d = sreg[1][0] * sreg[2][0] + sreg[1][1] * sreg[2][1] + sreg[1][2] * sreg[2][2] + sreg[1][3] * sreg[2][3];
       float n2 = sreg[1][0] * sreg[1][0] + sreg[1][1] * sreg[1][1] + sreg[1][2] * sreg[1][2] + sreg[1][3] * sreg[1][3];
-      d += __shfl_xor(d, 8, 64); d += __shfl_xor(d, 4, 64); d += __shfl_xor(d, 2, 64); d += __shfl_xor(d, 1, 64);
-      n2 += __shfl_xor(n2, 8, 64); n2 += __shfl_xor(n2, 4, 64); n2 += __shfl_xor(n2, 2, 64); n2 += __shfl_xor(n2, 1, 64);
+      OFB_XOR_STEP(d, ofb_add_, 8) OFB_XOR_STEP(d, ofb_add_, 4) OFB_XOR_STEP(d, ofb_add_, 2) OFB_XOR_STEP(d, ofb_add_, 1)
+      OFB_XOR_STEP(n2, ofb_add_, 8) OFB_XOR_STEP(n2, ofb_add_, 4) OFB_XOR_STEP(n2, ofb_add_, 2) OFB_XOR_STEP(n2, ofb_add_, 1)
       if ((t & 15) == 0) {
         const int ri = ring(qb) + (t >> 4);
         ndel[ri] = -d; ndo[ri] = sqrtf(n2);
@@ -557,11 +557,11 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
           for (int j = 0; j < 4; ++j) { const float x = vraw[kt][ks][u][j]; n2 += x * x; xv[4 * u + j] = x * hs; }
         att_split8(xv, Vb[kt][ks]);
       }
-      n2 += __shfl_xor(n2, 16, 64); n2 += __shfl_xor(n2, 32, 64);     // the key's 64 channels sit in the four lane groups
+      OFB_XOR_STEP(n2, ofb_add_, 16) OFB_XOR_STEP(n2, ofb_add_, 32)     // the key's 64 channels sit in the four lane groups
       vn = fmaxf(vn, n2);
     }
-    vn = fmaxf(vn, __shfl_xor(vn, 1, 64)); vn = fmaxf(vn, __shfl_xor(vn, 2, 64));
-    vn = fmaxf(vn, __shfl_xor(vn, 4, 64)); vn = fmaxf(vn, __shfl_xor(vn, 8, 64));
+    OFB_XOR_STEP(vn, fmaxf, 1) OFB_XOR_STEP(vn, fmaxf, 2)
+    OFB_XOR_STEP(vn, fmaxf, 4) OFB_XOR_STEP(vn, fmaxf, 8)
     if (lane == 0) vmax[w] = vn;
   }
   AB_STAMP(62);
@@ -606,8 +606,8 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
     int eds;
     {
       float dm = ndo[ring(qb) + (lane & 31)];
-      dm = fmaxf(dm, __shfl_xor(dm, 1, 64)); dm = fmaxf(dm, __shfl_xor(dm, 2, 64)); dm = fmaxf(dm, __shfl_xor(dm, 4, 64));
-      dm = fmaxf(dm, __shfl_xor(dm, 8, 64)); dm = fmaxf(dm, __shfl_xor(dm, 16, 64));
+      OFB_XOR_STEP(dm, fmaxf, 1) OFB_XOR_STEP(dm, fmaxf, 2) OFB_XOR_STEP(dm, fmaxf, 4)
+      OFB_XOR_STEP(dm, fmaxf, 8) OFB_XOR_STEP(dm, fmaxf, 16)
       eds = __builtin_amdgcn_readfirstlane(ofb_h_exp(2.002f * dm * vnorm));
     }
     if (has_keys) {

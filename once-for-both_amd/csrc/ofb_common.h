@@ -84,6 +84,30 @@ __device__ __forceinline__ float ofb_dgelu(float x) {
     v = OP(v, OFB_DPP_F(v, 0xB1, 0xF));                        /* quad_perm [1,0,3,2] = lane ^ 1 */              \
   }
 #endif
+// single butterfly levels v = OP(v, v[lane ^ o]) without the LDS crossbar (OP commutative; all 64 lanes active): the pieces of OFB_WAVE_REDUCE
+#ifdef OFB_LAB_SHFL_REDUCE
+#define OFB_XOR_STEP(v, OP, o) v = OP(v, __shfl_xor(v, o, 64))
+#else
+#define OFB_XOR_STEP(v, OP, o)                                                                                  \
+  {                                                                                                             \
+    if constexpr ((o) == 1) v = OP(v, OFB_DPP_F(v, 0xB1, 0xF));                                                 \
+    else if constexpr ((o) == 2) v = OP(v, OFB_DPP_F(v, 0x4E, 0xF));                                            \
+    else if constexpr ((o) == 4) {                                                                              \
+      int t_ = __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), 0x104, 0xF, 0x5, false);                         \
+      t_ = __builtin_amdgcn_update_dpp(t_, __builtin_bit_cast(int, v), 0x114, 0xF, 0xA, false);                 \
+      v = OP(v, __builtin_bit_cast(float, t_));                                                                 \
+    } else if constexpr ((o) == 8) v = OP(v, OFB_DPP_F(v, 0x128, 0xF));                                         \
+    else if constexpr ((o) == 16) {                                                                             \
+      const unsigned u_ = __builtin_bit_cast(unsigned, v);                                                      \
+      const auto r_ = __builtin_amdgcn_permlane16_swap(u_, u_, false, false);                                   \
+      v = OP(__builtin_bit_cast(float, (unsigned)r_[0]), __builtin_bit_cast(float, (unsigned)r_[1]));           \
+    } else {                                                                                                    \
+      const unsigned u_ = __builtin_bit_cast(unsigned, v);                                                      \
+      const auto r_ = __builtin_amdgcn_permlane32_swap(u_, u_, false, false);                                   \
+      v = OP(__builtin_bit_cast(float, (unsigned)r_[0]), __builtin_bit_cast(float, (unsigned)r_[1]));           \
+    }                                                                                                           \
+  }
+#endif
 __device__ __forceinline__ float ofb_add_(float a, float b) { return a + b; }
 __device__ __forceinline__ float ofb_wave_sum(float v) {
   OFB_WAVE_REDUCE(v, ofb_add_)
