@@ -990,8 +990,8 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
           if (g.colpart) {
             // column sums of the wave's 64 rows: the four lane groups hold four row quads of the column; the tile's two wave rows
             // leave one partial row each (rows 2 tile, 2 tile + 1: ofb_gemm_h_colpart_rows counts them)
-            csum += __shfl_xor(csum, 16, 64);
-            csum += __shfl_xor(csum, 32, 64);
+            OFB_XOR_STEP(csum, ofb_add_, 16)                  // (register-only exchanges: ofb_common.h)
+            OFB_XOR_STEP(csum, ofb_add_, 32)
             if (lane < 16) g.colpart[(size_t)(2 * (cur.m0 / BMT) + (w / WN)) * g.N + col] = csum;
           }
         }
@@ -1216,7 +1216,7 @@ __global__ __launch_bounds__(CF::NT, CF::WGS) void gemm_h_kernel(const ofb_gemm_
                 const f32x4 v = *reinterpret_cast<const f32x4*>(Rp + rr * NQ + (NQ / 4) * part + 4 * q4);
                 ss += (v[0] + v[1]) + (v[2] + v[3]);
               }
-              ss += __shfl_xor(ss, 1, 64); ss += __shfl_xor(ss, 2, 64);
+              OFB_XOR_STEP(ss, ofb_add_, 1) OFB_XOR_STEP(ss, ofb_add_, 2)
               const float v = row < g.M ? g.rn_rowfac[row] * sqrtf(ss) : 0.f;
               const float m = ofb_wave_max_pos(v);
               if (lane == 0) atomicMax(reinterpret_cast<unsigned*>(Rmx), __float_as_uint(m));
