@@ -236,14 +236,21 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
       }
       // online softmax: this lane holds keys kb*32 + 16 tk + 4g + r of query c
       float mb = -INFINITY;
+      if ((kb + 1) * AF_KB <= N) {                            // (only the last key block has positions past the end: no masks elsewhere)
 #pragma unroll
-      for (int tk = 0; tk < 2; ++tk)
+        for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float sv = (kb * AF_KB + 16 * tk + 4 * g + r < N) ? S[tk][r] : -INFINITY;
-          S[tk][r] = sv;
-          mb = fmaxf(mb, sv);
-        }
+          for (int r = 0; r < 4; ++r) mb = fmaxf(mb, S[tk][r]);
+      } else {
+#pragma unroll
+        for (int tk = 0; tk < 2; ++tk)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float sv = (kb * AF_KB + 16 * tk + 4 * g + r < N) ? S[tk][r] : -INFINITY;
+            S[tk][r] = sv;
+            mb = fmaxf(mb, sv);
+          }
+      }
       OFB_XOR_STEP(mb, fmaxf, 16)                         // (register-only exchanges: ofb_common.h)
       OFB_XOR_STEP(mb, fmaxf, 32)
       const float m_new = fmaxf(m_run, mb);                 // finite from block 0 on (key 0 is always valid)
