@@ -508,8 +508,9 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
 #pragma unroll
   for (int i = 0; i < NIT; ++i) {
     const int idx = t + AB_THREADS * i, pos = idx >> 4, c4 = idx & 15;
-    kv[i] = zero4();
-    if (valid(key0 + pos) && 4 * c4 < dh) kv[i] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(kbase + (unsigned)((key0 + pos) * ldq + 4 * c4)));
+    // (in-bounds addresses and no branches around the prologue's loads either; what lies past the end is dropped where it is used)
+    const bool in = valid(key0 + pos) && 4 * c4 < dh;
+    kv[i] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(kbase + (in ? (unsigned)((key0 + pos) * ldq + 4 * c4) : 0u)));
   }
   if (!LONG && t < AB_NPOS && valid(t)) {
     const size_t li = ((size_t)b * H + head) * N + t;
@@ -526,8 +527,8 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int d0 = 32 * ks + 8 * g + 4 * u;
-        vraw[kt][ks][u] = zero4();
-        if (kv_ok && d0 < dh) vraw[kt][ks][u] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(vbase + (unsigned)(pos * ldq + d0)));
+        const bool in = kv_ok && d0 < dh;
+        vraw[kt][ks][u] = OFB_NT_LOAD(reinterpret_cast<const f32x4*>(vbase + (in ? (unsigned)(pos * ldq + d0) : 0u)));
       }
   }
   AB_STAMP(58);
@@ -536,8 +537,9 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
   for (int i = 0; i < NIT; ++i) {
     const int idx = t + AB_THREADS * i, pos = idx >> 4, c4 = idx & 15;
     unsigned h0, l0, h1, l1;
-    ofb_hsplit_pair(kv[i][0] * hs, kv[i][1] * hs, h0, l0);
-    ofb_hsplit_pair(kv[i][2] * hs, kv[i][3] * hs, h1, l1);
+    const f32x4 kk = (valid(key0 + pos) && 4 * c4 < dh) ? kv[i] : zero4();
+    ofb_hsplit_pair(kk[0] * hs, kk[1] * hs, h0, l0);
+    ofb_hsplit_pair(kk[2] * hs, kk[3] * hs, h1, l1);
     char* p = Kpl + pos * 128 + ((((c4 >> 1) ^ ab_swz(pos))) << 4) + ((c4 & 1) << 3);
     *reinterpret_cast<uint2*>(p) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(p + AB_KPL) = make_uint2(l0, l1);
@@ -561,7 +563,10 @@ __global__ __launch_bounds__(AB_THREADS, 2) void attn_bwd_kernel(const float* __
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-          for (int j = 0; j < 4; ++j) { const float x = vraw[kt][ks][u][j]; n2 += x * x; xv[4 * u + j] = x * hs; }
+          for (int j = 0; j < 4; ++j) {
+            const float x = (valid(key0 + 32 * w + 16 * kt + c) && 32 * ks + 8 * g + 4 * u < dh) ? vraw[kt][ks][u][j] : 0.f;
+            n2 += x * x; xv[4 * u + j] = x * hs;
+          }
         att_split8(xv, Vb[kt][ks]);
       }
       OFB_XOR_STEP(n2, ofb_add_, 16) OFB_XOR_STEP(n2, ofb_add_, 32)     // the key's 64 channels sit in the four lane groups
