@@ -1,4 +1,4 @@
-"""In-kernel s_memtime stamps of the attention forward (lab copy scripts/lab/attention_fwd_stamps.hip built into scripts/lab/bin/libofb_attfstamps.so):
+"""In-kernel s_memtime stamps of the attention forward (python scripts/lab/make_attention_fwd_stamps.py writes the stamped copy of the product kernel and builds scripts/lab/bin/libofb_attfstamps.so):
     OFB_LIB_PATH=scripts/lab/bin/libofb_attfstamps.so python scripts/lab/stamp_att_fwd.py
 Per wave of one mid-grid workgroup: cycles per phase, summed over the seven key blocks."""
 import ctypes as C, os, sys
