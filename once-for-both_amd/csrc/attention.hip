@@ -57,6 +57,7 @@ typedef ofb_f16x8 att_hx8;
 #define AF_PLANE (AF_KB * AF_PITCH)
 #define AF_STAGE (4 * AF_PLANE)        // K planes then V planes
 #define ATT_PE 14                      // probabilities are split as p 2^14
+#define AF_OPATCH (16 * 68 * 4)         // a wave's output patch in LDS: [16 queries][64 channels + 4] f32 (the plane patch [32 ch][20] fits inside)
 
 // 8 ALREADY SCALED floats -> two 8 x f16 fragments
 __device__ __forceinline__ void att_split8(const float (&x)[8], att_hx8 (&out)[2]) {
@@ -121,7 +122,7 @@ template <bool PF>
 __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __restrict__ qkv, float* __restrict__ out,
                                                                float* __restrict__ lse, char* __restrict__ oP, int p_ncb, int B, int N,
                                                                int H, int dh, float scale, const float* __restrict__ qkv_bound) {
-  __shared__ __attribute__((aligned(16))) char smem[(2 * AF_STAGE > ATT_NT * 2560) ? 2 * AF_STAGE : ATT_NT * 2560];   // stages; later the PF patches
+  __shared__ __attribute__((aligned(16))) char smem[(2 * AF_STAGE > ATT_NT * AF_OPATCH) ? 2 * AF_STAGE : ATT_NT * AF_OPATCH];   // stages; later the waves' output patches
   const int t = threadIdx.x, lane = t & 63, w = t >> 6, c = lane & 15, g = lane >> 4;
   const int b = blockIdx.x / H, head = blockIdx.x % H;
   const int wq = blockIdx.y * ATT_NT + w;                    // this wave's query tile (blockIdx.y > 0 only when N > 208)
@@ -304,17 +305,29 @@ __global__ __launch_bounds__(ATT_THREADS) void attn_fwd_kernel(const float* __re
       OFB_NT_STORE(ls, lse + li);                                                  // (lse and the f32 rows are read by the backward only)
       OFB_NT_STORE((m_run - ls) + ll, lse + (size_t)B * H * N + li);
     }
-    // O[dt][r] = O^T[channel 16 dt + 4g + r][query c]: four consecutive channels of this lane's query
-    float* op = out + ((size_t)b * N + q) * ldo + head * dh;
+  }
+  {
+    // The f32 rows.  O[dt][r] = O^T[channel 16 dt + 4g + r][query c]: stored from these registers one instruction writes 16 B for each of
+    // the four lanes that share a query - sixteen 64-byte segments in sixteen rows, and the stamps showed the waves' store issue taking up to
+    // 8 k cycles (13 waves x 64 segments on one CU).  Through a wave-private LDS patch [16 q][64 ch + 4] (the stage buffers are free) sixteen
+    // consecutive lanes hold one query's 256 contiguous bytes: four rows of 256 B per instruction.
+    float* Tq = reinterpret_cast<float*>(smem + w * AF_OPATCH);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-      const int ch = 16 * dt + 4 * g;
-      if (ch < dh) OFB_NT_STORE(O[dt], reinterpret_cast<f32x4*>(op + ch));
+    for (int dt = 0; dt < 4; ++dt) *reinterpret_cast<f32x4*>(&Tq[c * 68 + 16 * dt + 4 * g]) = O[dt];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int ql = 4 * pass + (lane >> 4), ck = lane & 15, qq = wq * ATT_T + ql - sft;
+      const f32x4 v = *reinterpret_cast<const f32x4*>(&Tq[ql * 68 + 4 * ck]);
+      if (qq >= 0 && qq < N && 4 * ck < dh) OFB_NT_STORE(v, reinterpret_cast<f32x4*>(out + ((size_t)b * N + qq) * ldo + head * dh + 4 * ck));
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
   }
   if (PF) {
-    // wave-private patch [32 ch][16 q + 4] f32 in the (now free) stage buffers: 2.5 KB per wave
-    float* T = reinterpret_cast<float*>(smem) + w * (32 * 20);
+    // wave-private patch [32 ch][16 q + 4] f32 (the same LDS as the row patch above): 2.5 KB per wave
+    float* T = reinterpret_cast<float*>(smem + w * AF_OPATCH);
     const int row0 = (int)((size_t)b * N) - sft + wq * ATT_T;                            // global row of tile position 0: row0 % 4 == 0
     char* oPl = oP + OFB_HHDR;
 #pragma unroll
