@@ -219,6 +219,7 @@ class Linear(torch.autograd.Function):
 #    leaves per-tile row-norm maxima (hip.gemm_h(rn=...)), parked in _rn under the gradient's identity: LN's backward kernel takes
 #    its output exponent from them instead of running a bound pass over dy (0.34 ms per DeiT-S step).  OFB_RN_HANDOVER=0: off.
 _ln_pending = [None]
+_LN_F32 = os.environ.get('OFB_LN_F32', '0') == '1'
 _grad_p = {}
 _rn = {}
 _RN_HANDOVER = os.environ.get('OFB_RN_HANDOVER', '1') != '0'
@@ -280,7 +281,10 @@ class LayerNorm(torch.autograd.Function):
         rows = x.numel() // D
         y, mean, rstd = torch.empty_like(x), _new(x, rows), _new(x, rows)
         yP = hip.HMat.for_rows_written_by_kernel(rows, D, x.device)
-        hip.layernorm_fwd_h(x, gamma, beta, y, yP, mean, rstd, rows, D, eps)
+        # fork (the block LayerNorms: the branch that follows takes the PLANES as its GEMM operand and the LayerNorm's input as its
+        # residual, AttnBranch / MlpBranch with `resid` given): nobody reads the f32 rows - they are not written (38.7 MB per call at
+        # DeiT-S bs 128, 0.93 GB per step; `y` stays an uninitialised carrier of the planes).  OFB_LN_F32=1 writes them anyway.
+        hip.layernorm_fwd_h(x, gamma, beta, y if (not fork or _LN_F32) else None, yP, mean, rstd, rows, D, eps)
         _ln_pending[0] = (yP, (gamma, rstd) if up is not None else None)
         ctx.save_for_backward(x, gamma, mean, rstd)
         ctx.fork = fork
