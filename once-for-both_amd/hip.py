@@ -132,6 +132,9 @@ class GemmHArgs(C.Structure):
     ]
 
 
+_LN_ZERO_FILL = os.environ.get('OFB_LN_ZERO_FILL', '0') == '1'
+
+
 class HMat:
     """A matrix X[R][C] in H-format (csrc/hformat.h: a 256-byte device-side header {e, amax, row / column norm bounds}, then two
     f16 planes of X * 2^e in 4 x 16 granules).  `buf` is a uint8 device tensor of ofb_hformat_bytes(R, C) bytes."""
@@ -149,6 +152,17 @@ class HMat:
         reduction along the rows / columns would read, are zeroed here"""
         pm = HMat(R, C_, device)
         if R % 16 or C_ % 16:
+            pm.buf.zero_()
+        return pm
+
+    @staticmethod
+    def for_rows_written_by_layernorm(R, C_, device):
+        """planes the LayerNorm plane kernels fill: for an even width they write every column of the last 16-column granule themselves
+        (zeros past the width: rowops.hip ln_p_store) and every 4-row group, so only the rows between R and the next multiple of 16 -
+        which a reduction along the rows would read - need zeroing.  (The blanket zero fill of for_rows_written_by_kernel was 48 fills
+        of 55 MB per finetune step at width 264: 0.47 ms.)"""
+        pm = HMat(R, C_, device)
+        if R % 16 or C_ % 2 or (_LN_ZERO_FILL and C_ % 16):            # (OFB_LN_ZERO_FILL=1: the blanket fill, for an A/B)
             pm.buf.zero_()
         return pm
 

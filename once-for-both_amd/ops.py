@@ -280,7 +280,7 @@ class LayerNorm(torch.autograd.Function):
         D = x.shape[-1]
         rows = x.numel() // D
         y, mean, rstd = torch.empty_like(x), _new(x, rows), _new(x, rows)
-        yP = hip.HMat.for_rows_written_by_kernel(rows, D, x.device)
+        yP = hip.HMat.for_rows_written_by_layernorm(rows, D, x.device)
         # fork (the block LayerNorms: the branch that follows takes the PLANES as its GEMM operand and the LayerNorm's input as its
         # residual, AttnBranch / MlpBranch with `resid` given): nobody reads the f32 rows - they are not written (38.7 MB per call at
         # DeiT-S bs 128, 0.93 GB per step; `y` stays an uninitialised carrier of the planes).  OFB_LN_F32=1 writes them anyway.
@@ -308,7 +308,7 @@ class LayerNorm(torch.autograd.Function):
         if ctx.up is not None:
             rowscale = ctx.up[0]
             part = _new(x, nb, 3 * D)
-            dxP = hip.HMat.for_rows_written_by_kernel(rows, D, x.device)
+            dxP = hip.HMat.for_rows_written_by_layernorm(rows, D, x.device)
             rn = _take_rn(dy, rows, D)                     # (always taken out of the table: see _put_rn)
             if dres is not None:
                 rn = None
