@@ -416,7 +416,7 @@ def main():
             if reducer is not None:
                 reducer.prescaled = True
                 loss = loss * reducer.grad_scale
-            loss.backward()
+            engine.run_backward(loss)
             if reducer is not None:
                 reducer.finalize()
             opt_ft.step()

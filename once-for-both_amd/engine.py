@@ -4,10 +4,26 @@
 reference's per-iteration schedule (progressive masking ratio, w_p warm-up, 3 optimizers, periodic compress).
 """
 import math
+import os
 import sys
 import time
 
 import torch
+
+# backward() on the CALLING thread: the autograd engine otherwise hands the graph to its per-device worker thread, and every one of the
+# ~100 Python backward functions of a step then takes the GIL from a thread without a lasting interpreter state - measured 9.5 vs
+# 7.9 ms of host time per search step (scripts/lab/host_profile.py), which is what decides the step time of the post-compress shapes
+# and of small batches.  OFB_BACKWARD_THREAD=engine restores torch's default.
+_BACKWARD_ON_CALLER = os.environ.get('OFB_BACKWARD_THREAD', 'caller') != 'engine'
+
+
+def run_backward(loss):
+    """loss.backward() of the epoch engines (and of bench.py's restatement of them)"""
+    if _BACKWARD_ON_CALLER:
+        with torch.autograd.set_multithreading_enabled(False):
+            loss.backward()
+    else:
+        loss.backward()
 
 
 def mix_losses(loss, decoder_loss):
@@ -43,7 +59,7 @@ def search_step(model, criterion, samples, targets, target_flops, optimizers, fi
         reducer.prescaled = True
         reducer.sync = do_step                           # exchange once per accumulation window, on its closing micro-step
         scale *= reducer.grad_scale                      # SUM all-reduce of (loss / world) gradients == average
-    (total * scale if scale != 1.0 else total).backward()
+    run_backward(total * scale if scale != 1.0 else total)
     if reducer is not None:
         reducer.finalize()
     if do_step:
@@ -272,7 +288,7 @@ def train_one_epoch(model, criterion, data_loader, optimizer, lr_schedule, devic
         if reducer is not None:
             reducer.sync = (it + 1) % accum_iter == 0    # one exchange per accumulation window
             reducer.prescaled = False                    # plain SUM, divided by the world size in finalize()
-        (loss / accum_iter if accum_iter != 1 else loss).backward()
+        run_backward(loss / accum_iter if accum_iter != 1 else loss)
         if reducer is not None:
             reducer.finalize()
         if (it + 1) % accum_iter == 0:

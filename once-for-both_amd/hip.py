@@ -5,6 +5,7 @@ and the caching allocator.  All arithmetic happens inside the library's kernels.
 """
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -66,6 +67,13 @@ def ptr(t):
     return _void_p(t.data_ptr())
 
 
+def _dp(t):
+    """ptr() for the per-call pointer writes of cached argument structs: the address as a plain int (ctypes converts it)"""
+    if not t.is_cuda or t.dtype not in _OK_DTYPES:
+        ptr(t)                                           # raises with the reason
+    return t.data_ptr()
+
+
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 _get_device = getattr(torch._C, '_cuda_getDevice', None)
 
@@ -85,6 +93,8 @@ def _f32c(t, name):
 
 
 _gemm_ws = {}
+_gemm_tl = threading.local()             # per thread: {call configuration: (argument struct, byref, partial rows, row-norm tiles, epoch, workspace bytes)}
+_gemm_cfg_epoch = [0]                    # bumped by tune(): plans (workspace, partial counts) depend on the switches
 
 
 def _workspace(device, nbytes):
@@ -133,6 +143,7 @@ class GemmHArgs(C.Structure):
 
 
 _LN_ZERO_FILL = os.environ.get('OFB_LN_ZERO_FILL', '0') == '1'
+_hbytes = {}                             # (R, C) -> ofb_hformat_bytes(R, C)
 
 
 class HMat:
@@ -141,10 +152,17 @@ class HMat:
     __slots__ = ('buf', 'R', 'C', 'ncb')
 
     def __init__(self, R, C_, device, buf=None):
-        f = lib().ofb_hformat_bytes
-        f.restype = C.c_int64
         self.R, self.C, self.ncb = int(R), int(C_), (int(C_) + 15) // 16
-        self.buf = buf if buf is not None else torch.empty(int(f(_i(R), _i(C_))), device=device, dtype=torch.uint8)
+        if buf is None:
+            n = _hbytes.get((R, C_))
+            if n is None:                                    # (~150 buffers per step, a handful of shapes: the library is asked once per shape)
+                f = lib().ofb_hformat_bytes
+                f.restype = C.c_int64
+                if len(_hbytes) > 4096:
+                    _hbytes.clear()
+                n = _hbytes[(R, C_)] = int(f(_i(R), _i(C_)))
+            buf = torch.empty(n, device=device, dtype=torch.uint8)
+        self.buf = buf
 
     @staticmethod
     def for_rows_written_by_kernel(R, C_, device):
@@ -184,6 +202,7 @@ TUNE_GEMM_MFMA, TUNE_GEMM_SCHED, TUNE_GEMM_TILE, TUNE_GEMM_T112, TUNE_GEMM_YIELD
 def tune(key, value):
     """run-time switch of a kernel variant (include/ofb_hip.h: OFB_TUNE_*): same results to rounding, for same-process A/B timing"""
     check(lib().ofb_tune(int(key), int(value)), 'ofb_tune')
+    _gemm_cfg_epoch[0] += 1
 
 
 def amax(x, out=None):
@@ -531,35 +550,78 @@ def gemm_h(A, B, a_kc, b_kc, M, N, K, C_out=None, ldc=0, Cp=None, alpha=1.0, bia
     aux_bound: bound of |aux| for the multiplying activations (default 1.13 = max gelu'); out_bound: device scalar that IS the
     bound of |output| for an H-format output (required with resid); cbound_out: device scalar that receives the bound of the
     f32 output (the exponent the attention kernels split it with)."""
-    g = GemmHArgs()
-    g.A, g.B, g.a_kc, g.b_kc, g.a_ncb, g.b_ncb = ptr(A.buf), ptr(B.buf), int(a_kc), int(b_kc), A.ncb, B.ncb
-    g.M, g.N, g.K = M, N, K
-    g.C, g.ldc = ptr(C_out), ldc
+    # ~150 calls per search step: everything that does not change from step to step - the argument struct with its scalars and
+    # null pointers, the stream-K workspace size, the number of column-sum / row-norm partials - is kept per call configuration
+    # (thread-local: the autograd engine runs backward on a thread of its own); a call then only writes the live pointers
+    if Cp is not None and (Cp.R != M or Cp.C != N):
+        raise OfbError('H-format output must be [M][N]')
+    has_part = colsum_out is not None or want_colpart
+    key = (a_kc, b_kc, M, N, K, A.ncb, B.ncb, ldc, -1 if Cp is None else Cp.ncb, alpha, rs_div, ldr, ldaux, act, aux_bound,
+           C_out is None, bias is None, colscale is None, rowscale is None, resid is None, aux is None, out_bound is None,
+           cbound_out is None, rn is None, has_part)
+    cache = _gemm_tl.__dict__.get('c')
+    if cache is None:
+        cache = _gemm_tl.c = {}
+    ent = cache.get(key)
+    if ent is None or ent[4] != _gemm_cfg_epoch[0]:
+        g = GemmHArgs()
+        g.a_kc, g.b_kc, g.a_ncb, g.b_ncb = int(a_kc), int(b_kc), A.ncb, B.ncb
+        g.M, g.N, g.K, g.ldc = M, N, K, ldc
+        g.A, g.B, g.C = ptr(A.buf), ptr(B.buf), ptr(C_out)
+        if Cp is not None:
+            g.Cp, g.c_ncb = ptr(Cp.buf), Cp.ncb
+        g.alpha, g.bias, g.colscale, g.rowscale, g.rs_div = alpha, ptr(bias), ptr(colscale), ptr(rowscale), rs_div
+        g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
+        g.aux_bound, g.out_bound, g.cbound_out = aux_bound, ptr(out_bound), ptr(cbound_out)
+        rows = int(lib().ofb_gemm_h_colpart_rows(C.byref(g))) if has_part else 0
+        n_rn, nt = 0, C.c_int32(0)
+        if rn is not None:
+            g.rn_gamma, g.rn_rowfac = ptr(rn[0]), ptr(rn[1])
+            n_rn = int(lib().ofb_gemm_h_rn_tiles(C.byref(g), C.byref(nt)))   # (0: a shape for the 96-column tile, which has no row-norm form)
+            if n_rn <= 0:
+                g.rn_gamma = g.rn_rowfac = None
+        if has_part:
+            g.colpart = 16                                   # (the plan looks at which outputs are asked for, not where they live)
+        if n_rn > 0:
+            g.rn_out = 16
+        lib().ofb_gemm_h_workspace_bytes.restype = C.c_int64
+        need = int(lib().ofb_gemm_h_workspace_bytes(C.byref(g)))
+        if len(cache) > 4096:                                # (a long search re-shapes its products at every compress())
+            cache.clear()
+        ent = cache[key] = (g, C.byref(g), rows, (n_rn, float(nt.value) ** 0.5), _gemm_cfg_epoch[0], need)
+    g, g_ref, rows, (n_rn, rn_fac), _, need = ent
+    dev = A.buf.device
+    g.A, g.B = _dp(A.buf), _dp(B.buf)
+    if C_out is not None:
+        g.C = _dp(C_out)
     if Cp is not None:
-        if Cp.R != M or Cp.C != N:
-            raise OfbError('H-format output must be [M][N]')
-        g.Cp, g.c_ncb = ptr(Cp.buf), Cp.ncb
-    g.alpha, g.bias, g.colscale, g.rowscale, g.rs_div = alpha, ptr(bias), ptr(colscale), ptr(rowscale), rs_div
-    g.resid, g.ldr, g.aux, g.ldaux, g.act = ptr(resid), ldr, ptr(aux), ldaux, act
-    g.aux_bound, g.out_bound, g.cbound_out = aux_bound, ptr(out_bound), ptr(cbound_out)
+        g.Cp = _dp(Cp.buf)
+    if bias is not None:
+        g.bias = _dp(bias)
+    if colscale is not None:
+        g.colscale = _dp(colscale)
+    if rowscale is not None:
+        g.rowscale = _dp(rowscale)
+    if resid is not None:
+        g.resid = _dp(resid)
+    if aux is not None:
+        g.aux = _dp(aux)
+    if out_bound is not None:
+        g.out_bound = _dp(out_bound)
+    if cbound_out is not None:
+        g.cbound_out = _dp(cbound_out)
     part = None
-    if colsum_out is not None or want_colpart:
-        rows = int(lib().ofb_gemm_h_colpart_rows(C.byref(g)))
-        part = torch.empty(rows, N, device=A.buf.device, dtype=torch.float32)
-        g.colpart = ptr(part)
+    if has_part:
+        part = torch.empty(rows, N, device=dev, dtype=torch.float32)
+        g.colpart = part.data_ptr()
     rn_out = None
-    if rn is not None:
-        nt = C.c_int32(0)
-        n_rn = int(lib().ofb_gemm_h_rn_tiles(C.byref(g), C.byref(nt)))
-        if n_rn > 0:                                         # (0: a shape for the 96-column tile, which has no row-norm form)
-            rn_out = (torch.empty(n_rn, device=A.buf.device, dtype=torch.float32), float(nt.value) ** 0.5)
-            g.rn_gamma, g.rn_rowfac, g.rn_out = ptr(rn[0]), ptr(rn[1]), ptr(rn_out[0])
-    lib().ofb_gemm_h_workspace_bytes.restype = C.c_int64
-    need = lib().ofb_gemm_h_workspace_bytes(C.byref(g))
+    if n_rn > 0:
+        rn_out = (torch.empty(n_rn, device=dev, dtype=torch.float32), rn_fac)
+        g.rn_gamma, g.rn_rowfac, g.rn_out = _dp(rn[0]), _dp(rn[1]), rn_out[0].data_ptr()
     if need > 0:
-        ws = _workspace(A.buf.device, need)
-        g.workspace, g.workspace_bytes = ptr(ws), ws.numel() * 4
-    check(lib().ofb_gemm_h(C.byref(g), stream()), 'ofb_gemm_h')
+        ws = _workspace(dev, need)
+        g.workspace, g.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    check(lib().ofb_gemm_h(g_ref, stream()), 'ofb_gemm_h')
     if want_colpart:
         return part
     if part is not None:

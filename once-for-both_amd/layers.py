@@ -184,8 +184,10 @@ class _Searchable:
         return outs[0]
 
     def _set_gate_outputs(self, g, wr, wm):
-        self._g, self._wr = g, wr
-        self.weighted_mask = self._shape_wm(wm)
+        # plain (unregistered) attributes, written ~75 times per step: straight into __dict__, which is where nn.Module.__setattr__
+        # puts them after its Parameter / buffer / sub-module checks
+        d = self.__dict__
+        d['_g'], d['_wr'], d['weighted_mask'] = g, wr, self._shape_wm(wm)
 
     def get_weight(self):
         """(weight_restore, prob_score) of the CURRENT forward (reference get_weight re-derives the same values)."""

@@ -16,6 +16,8 @@ class AdamW(Optimizer):
             raise ValueError('invalid AdamW hyper-parameter')
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad))
         self.param_names = param_names
+        self._tables = {}         # (group, tensors) -> (addresses, device table, pinned copy, largest tensor): step()
+        self.table_hits = 0       # launches that reused their table (tests / diagnostics)
         self._cap = None          # while / after a hipGraph capture of step(): device-resident {lr, bc1, 1/sqrt(bc2)} per launch
 
     # ---- hipGraph support (engine.GraphedStep) ---------------------------------------------------------------------------------
@@ -66,18 +68,34 @@ class AdamW(Optimizer):
                 by_step.setdefault(st['step'], []).append(p)
             b1, b2 = group['betas']
             for step, plist in by_step.items():
-                tab = (hip.AdamwTensor * len(plist))()
-                keep, maxn = [], 0
-                for i, p in enumerate(plist):
+                # the device-side tensor table of a launch is kept while every address in it stays what it was (parameters and moments
+                # live on; the caching allocator hands the gradients of a steady-state step the blocks of the step before): no
+                # table build, no upload.  While a capture is being recorded every launch gets a table of its own.
+                keep, maxn, addr = [], 0, []
+                state = self.state
+                for p in plist:
                     g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
                     if not p.is_contiguous():
                         raise hip.OfbError('AdamW needs contiguous parameters')
-                    st = self.state[p]
-                    tab[i].p, tab[i].g = p.data_ptr(), g.data_ptr()
-                    tab[i].m, tab[i].v, tab[i].n = st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel()
-                    maxn = max(maxn, p.numel())
+                    st = state[p]
+                    addr += (p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel())
                     keep.append(g)
-                dev_tab, host = hip.upload_structs(tab, plist[0].device)
+                addr = tuple(addr)
+                slot = (id(group), len(plist))
+                capturing = self._cap is not None and self._cap['active']
+                cached = None if capturing else self._tables.get(slot)
+                if cached is not None and cached[0] == addr:
+                    dev_tab, host, maxn = cached[1], cached[2], cached[3]
+                    self.table_hits += 1
+                else:
+                    tab = (hip.AdamwTensor * len(plist))()
+                    for i, p in enumerate(plist):
+                        t = tab[i]
+                        t.p, t.g, t.m, t.v, t.n = addr[5 * i:5 * i + 5]
+                        maxn = max(maxn, addr[5 * i + 4])
+                    dev_tab, host = hip.upload_structs(tab, plist[0].device)
+                    if not capturing:
+                        self._tables[slot] = (addr, dev_tab, host, maxn)
                 if self._cap is not None and self._cap['active']:
                     cap = self._cap
                     i = len(cap['slots'])

@@ -461,7 +461,7 @@ class MIMVisionTransformer(MAEBaseModel):
         if hasattr(pe, 'switch_cell'):
             wme = pe._wr_view() if not pe.finish_search else getattr(pe, 'weighted_mask', None)
             for blk in self.blocks:
-                blk.weighted_mask_embed = blk.attn.weighted_mask_embed = blk.mlp.weighted_mask_embed = wme
+                blk.__dict__['weighted_mask_embed'] = blk.attn.__dict__['weighted_mask_embed'] = blk.mlp.__dict__['weighted_mask_embed'] = wme
         depth = len(self.blocks)
         rates = [float(getattr(b.drop_path, 'drop_prob', 0.0)) for b in self.blocks]
         u = None

@@ -26,3 +26,4 @@ pr = cProfile.Profile(); pr.enable()
 for _ in range(3): engine.search_step(m, crit, imgs, labels, 1.0, opts)
 pr.disable(); torch.cuda.synchronize()
 pstats.Stats(pr).sort_stats('cumulative').print_stats(18)
+pstats.Stats(pr).sort_stats('tottime').print_stats(45)

@@ -426,3 +426,29 @@ def test_gemm_h_full_size_products_on_fewer_cus(cus):
         test_gemm_h_between_one_and_two_rounds(27800, 384, 384)
     finally:
         hip.tune(hip.TUNE_GEMM_CUS, 0)
+
+
+def test_gemm_h_cached_argument_struct_takes_every_call_s_own_pointers():
+    """hip.gemm_h keeps one argument struct per call configuration: calls that differ only in their tensors must each see their own
+    operands, side vectors and outputs; a switch change (hip.tune) drops the cached plans"""
+    from ofb_amd import hip
+    M, N, K = 300, 200, 96
+    outs = []
+    for rep in range(3):
+        a, w = _mk((M, K), 10 + rep).cuda(), _mk((N, K), 20 + rep).cuda()
+        bias, cs, res = _mk((N,), 30 + rep).cuda(), _mk((N,), 40 + rep).cuda(), _mk((M, N), 50 + rep).cuda()
+        aP, wP = hip.to_hformat(a), hip.to_hformat(w)
+        y, colsum = torch.empty(M, N, device='cuda'), torch.empty(N, device='cuda')
+        hip.gemm_h(aP, wP, 1, 1, M, N, K, C_out=y, ldc=N, bias=bias, colscale=cs, resid=res, ldr=N, colsum_out=colsum)
+        exp = ((a.double() @ w.double().t() + bias.double()) * cs.double() + res.double()).cpu()
+        _close(y, exp, f'call {rep}: product + bias, column scale, residual')
+        _close(colsum, exp.sum(0), f'call {rep}: column sums', tol=2e-5)
+        outs.append(y)
+        if rep == 1:
+            hip.tune(hip.TUNE_GEMM_YIELD, 4)                  # (its default value: only the cache epoch moves)
+    assert outs[0].data_ptr() != outs[1].data_ptr() and not torch.equal(outs[0], outs[1])
+    # same shapes, fewer side inputs: a different configuration, not the struct of the calls above with stale pointers
+    a, w = _mk((M, K), 60).cuda(), _mk((N, K), 61).cuda()
+    y = torch.empty(M, N, device='cuda')
+    hip.gemm_h(hip.to_hformat(a), hip.to_hformat(w), 1, 1, M, N, K, C_out=y, ldc=N)
+    _close(y, (a.double() @ w.double().t()).cpu(), 'plain product after the decorated ones')

@@ -148,3 +148,31 @@ def test_droppath_scales_match_the_timm_expression():
     out = torch.empty_like(u)
     hip.droppath_scales(u, keep, out, 22, 128)
     assert torch.equal(out, torch.floor(keep + u) / keep)
+
+
+def test_adamw_reuses_its_device_table_only_while_every_address_stays():
+    """optim.AdamW keeps the device-side tensor table of a launch while the parameter, gradient and moment addresses are what they
+    were: steps with in-place gradients reuse it, a new gradient tensor or replaced moments rebuild it; the walk equals
+    torch.optim.AdamW's either way"""
+    from ofb_amd.optim import AdamW
+    torch.manual_seed(3)
+    shapes = [(37, 5), (64,), (3, 7, 2)]
+    ps = [torch.nn.Parameter(torch.randn(s, device='cuda')) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = AdamW(ps, None, lr=1e-2, weight_decay=0.05)
+    ropt = torch.optim.AdamW(ref, lr=1e-2, weight_decay=0.05)
+    grads = [torch.empty_like(p) for p in ps]
+    for step in range(6):
+        if step == 3:
+            grads = [torch.empty_like(p) for p in ps]         # gradients at new addresses (the old ones are still alive)
+        for p, r, g in zip(ps, ref, grads):
+            g.copy_(torch.randn_like(p))
+            p.grad, r.grad = g, g.clone()
+        if step == 5:                                         # moments replaced (what compress() does through AdamW.update)
+            for p in ps:
+                opt.state[p]['exp_avg'] = opt.state[p]['exp_avg'].clone()
+        hits = opt.table_hits
+        opt.step(); ropt.step()
+        assert (opt.table_hits > hits) == (step in (1, 2, 4)), f'step {step}: table reuse'
+        for p, r in zip(ps, ref):
+            assert (p - r).abs().max().item() <= 2e-6 * r.abs().max().item(), f'step {step}'
