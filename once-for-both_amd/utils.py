@@ -30,6 +30,7 @@ class ModelEma:
         for p in self.ema.parameters():
             p.requires_grad_(False)
         self._table = None                       # (device table, keep-alive, n, max_numel, signature)
+        self._fast, self._fast_model, self._has_other = None, None, False     # update(): pairs of the last full walk
 
     def _load_checkpoint(self, checkpoint_path):
         ckpt = torch.load(checkpoint_path, map_location='cpu', weights_only=False)
@@ -49,24 +50,57 @@ class ModelEma:
         dev_tab, host = hip.upload_structs(tab, pairs[0][0].device)
         return dev_tab, host, len(pairs), maxn
 
-    @torch.no_grad()
-    def update(self, model):
+    _REWALK = 64                                 # fast updates between two full walks of the state dicts
+
+    def _walk(self, model):
+        """the full walk (reference utils.py ModelEma.update: both state dicts, key by key): returns the float32 pairs, copies the
+        other dtypes, adopts re-shaped tensors; remembers WHERE every pair lives (owning dict + name on both sides) for _fast_pairs"""
         needs_module = hasattr(model, 'module') and not self.ema_has_module
-        msd = model.state_dict()
-        pairs, changed = [], {}
-        for k, ema_v in self.ema.state_dict().items():
+        msd = model.state_dict(keep_vars=True)
+        pairs, changed, homes = [], {}, []
+        where_m, where_e = _tensor_homes(model), _tensor_homes(self.ema)
+        for k, ema_v in self.ema.state_dict(keep_vars=True).items():
             mk = 'module.' + k if needs_module else k
-            model_v = msd[mk].detach()
+            model_v = msd[mk]
             if model_v.shape != ema_v.shape:
-                changed[k] = model_v
+                changed[k] = model_v.detach()
             elif ema_v.dtype == torch.float32:
                 if not (ema_v.is_contiguous() and model_v.is_contiguous() and model_v.device == ema_v.device):
                     raise hip.OfbError(f'ModelEma.update: {k} must be contiguous and on the EMA device')
                 pairs.append((ema_v, model_v))
+                homes.append((where_e.get(id(ema_v)), where_m.get(id(model_v))))
             else:
-                ema_v.copy_(model_v)
+                ema_v.detach().copy_(model_v.detach())
+                self._has_other = True                           # (copied by the full walk only: such a model never takes the fast path)
+        return pairs, changed, homes
+
+    def _fast_pairs(self):
+        """the pairs of the last full walk if every one of them still sits where it sat (same tensor objects under the same names in
+        the same modules' _parameters / _buffers: compress() and adopt_state() REPLACE parameters, which this sees), else None"""
+        f = self._fast
+        if f is None or f[2] <= 0:
+            return None
+        pairs, homes, _ = f
+        for (e, m), (he, hm) in zip(pairs, homes):
+            if he is None or hm is None or he[0].get(he[1]) is not e or hm[0].get(hm[1]) is not m:
+                return None
+        f[2] -= 1
+        return pairs
+
+    @torch.no_grad()
+    def update(self, model):
+        # Two state_dict() walks per update cost the host ~1 ms per finetune micro-step: between two full walks (every _REWALK updates,
+        # and whenever a pair moved) the pairs of the last walk are re-validated in place instead.  Models with non-float32 state
+        # (integer buffers, copied rather than averaged) always take the full walk.
+        pairs = self._fast_pairs() if self._fast is not None and self._fast_model is model else None
+        changed = {}
+        if pairs is None:
+            self._has_other = False
+            pairs, changed, homes = self._walk(model)
+            ok = not changed and not self._has_other and all(he is not None and hm is not None for he, hm in homes)
+            self._fast, self._fast_model = ([pairs, homes, self._REWALK] if ok else None), model
         if pairs:
-            sig = tuple((e.data_ptr(), m.data_ptr()) for e, m in pairs)
+            sig = tuple([e.data_ptr() for e, _ in pairs] + [m.data_ptr() for _, m in pairs])
             if self._table is None or self._table[-1] != sig:          # pointers are stable between compress() calls
                 self._table = (*self._build_table(pairs), sig)
             dev_tab, _, n, maxn, _ = self._table
@@ -81,6 +115,20 @@ class ModelEma:
         for p in self.ema.parameters():
             p.requires_grad_(False)
         self._table = None
+        self._fast = None
+
+
+def _tensor_homes(root):
+    """id(tensor) -> (the _parameters / _buffers dict that holds it, its name there) for every parameter and buffer under root"""
+    homes = {}
+    for mod in root.modules():
+        for name, t in mod._parameters.items():
+            if t is not None:
+                homes[id(t)] = (mod._parameters, name)
+        for name, t in mod._buffers.items():
+            if t is not None:
+                homes[id(t)] = (mod._buffers, name)
+    return homes
 
 
 def _owner(root, dotted):

@@ -9,17 +9,38 @@ dev = torch.device('cuda')
 torch.manual_seed(0)
 args = [a for a in sys.argv[1:] if not a.startswith('--')]
 B = int(args[0]) if args else 8
-if '--pruned' in sys.argv:
-    m, _ = bench.build_pruned_search(ofb_amd, dev, 1000)
+finetune = '--finetune' in sys.argv
+if finetune:
+    import numpy as np
+    from ofb_amd.optim import AdamW
+    from ofb_amd.utils import ModelEma
+    m, _, _ = bench.build_finetune_subnet(ofb_amd, dev, 1000)
+    m.train(False)
+    opt = AdamW(m.parameters(), None, lr=1e-4, weight_decay=0.05)
+    crit = DistillationLoss(ofb_amd.SoftTargetCrossEntropy(), None, 'none', 0.5, 1.0)
+    mix = ofb_amd.Mixup(mixup_alpha=0.8, cutmix_alpha=1.0, label_smoothing=0.1, num_classes=1000)
+    np.random.seed(1)
+    ema = ModelEma(m, decay=0.99996)
 else:
-    m = ofb_amd.create_model('deit_small_patch16_224_mim', method='search', num_classes=1000, drop_path_rate=0.1, patch_search=False, mask_ratio=1.0)
-    m.correct_require_grad(0.5, 0.5, 0, 0.5)
-m.adjust_masking_ratio(0.0, 20, 100); m.to(dev).train()
-opts = engine.build_optimizers(m, 1e-4)
-crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, 0.5, 0.5, 0.0, 0.5, 5.0)
+    if '--pruned' in sys.argv:
+        m, _ = bench.build_pruned_search(ofb_amd, dev, 1000)
+    else:
+        m = ofb_amd.create_model('deit_small_patch16_224_mim', method='search', num_classes=1000, drop_path_rate=0.1, patch_search=False, mask_ratio=1.0)
+        m.correct_require_grad(0.5, 0.5, 0, 0.5)
+    m.adjust_masking_ratio(0.0, 20, 100); m.to(dev).train()
+    opts = engine.build_optimizers(m, 1e-4)
+    crit = OFBSearchLOSS(DistillationLoss(LabelSmoothingCrossEntropy(0.1), None, 'none', 0.5, 1.0), dev, 0.5, 0.5, 0.0, 0.5, 5.0)
 imgs = torch.randn(B, 3, 224, 224, device=dev); labels = torch.randint(0, 1000, (B,), device=dev)
+def ft_step():
+    x, soft = mix(imgs, labels)
+    loss = crit(x, m(x), soft)
+    engine.run_backward(loss)
+    opt.step(); opt.zero_grad(set_to_none=True)
+    ema.update(m)
 def run(n):
-    for _ in range(n): engine.search_step(m, crit, imgs, labels, 1.0, opts)
+    for _ in range(n):
+        if finetune: ft_step()
+        else: engine.search_step(m, crit, imgs, labels, 1.0, opts)
 run(12); torch.cuda.synchronize()
 for rep in range(3):
     for on_caller in (False, True):

@@ -176,3 +176,33 @@ def test_adamw_reuses_its_device_table_only_while_every_address_stays():
         assert (opt.table_hits > hits) == (step in (1, 2, 4)), f'step {step}: table reuse'
         for p, r in zip(ps, ref):
             assert (p - r).abs().max().item() <= 2e-6 * r.abs().max().item(), f'step {step}'
+
+
+def test_model_ema_fast_path_sees_replaced_and_re_pointed_parameters():
+    """ModelEma.update re-validates the pairs of its last full walk instead of walking both state dicts: a parameter that was replaced
+    (compress / adopt_state) or re-pointed (p.data = ...) must still be averaged from where it lives NOW"""
+    import ofb_amd
+    from ofb_amd.utils import ModelEma
+    torch.manual_seed(0)
+    m = ofb_amd.VisionTransformer(embed_dim=64, depth=2, num_heads=2, num_classes=5).cuda()
+    ema = ModelEma(m, decay=0.5)
+    want = {k: v.clone() for k, v in ema.ema.state_dict().items()}
+
+    def step_and_check(tag):
+        ema.update(m)
+        for k, v in m.state_dict().items():
+            want[k] = want[k] * 0.5 + (1. - 0.5) * v
+        for k, v in ema.ema.state_dict().items():
+            assert torch.equal(v, want[k]), (tag, k)
+
+    step_and_check('full walk')
+    assert ema._fast is not None and ema._fast[2] == ModelEma._REWALK
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(0.25)
+    step_and_check('fast')
+    assert ema._fast[2] == ModelEma._REWALK - 1               # the fast path ran
+    m.head.weight = torch.nn.Parameter(m.head.weight.detach() * 2.0)          # replaced object
+    step_and_check('replaced parameter')
+    m.head.bias.data = m.head.bias.data + 1.0                                   # same object, new storage
+    step_and_check('re-pointed parameter')
