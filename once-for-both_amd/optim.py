@@ -56,30 +56,35 @@ class AdamW(Optimizer):
         hip.flush_deferred()                     # queued LayerNorm / bias gradient reductions (normally done at the end of backward)
         for group in self.param_groups:
             by_step = {}
+            state = self.state
             for p in group['params']:
-                if p.grad is None:
+                g = p.grad
+                if g is None:
                     continue
-                st = self.state[p]
+                st = state[p]
                 if len(st) == 0:
                     st['step'] = 0
                     st['exp_avg'] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st['exp_avg_sq'] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st['step'] += 1
-                by_step.setdefault(st['step'], []).append(p)
+                t = st['step'] = st['step'] + 1
+                lst = by_step.get(t)
+                if lst is None:
+                    lst = by_step[t] = []
+                lst.append((p, g, st))
             b1, b2 = group['betas']
-            for step, plist in by_step.items():
+            for step, triples in by_step.items():
                 # the device-side tensor table of a launch is kept while every address in it stays what it was (parameters and moments
                 # live on; the caching allocator hands the gradients of a steady-state step the blocks of the step before): no
                 # table build, no upload.  While a capture is being recorded every launch gets a table of its own.
-                keep, maxn, addr = [], 0, []
-                state = self.state
-                for p in plist:
-                    g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                keep, maxn, addr, plist = [], 0, [], []
+                for p, g, st in triples:
+                    if not g.is_contiguous():
+                        g = g.contiguous()
                     if not p.is_contiguous():
                         raise hip.OfbError('AdamW needs contiguous parameters')
-                    st = state[p]
                     addr += (p.data_ptr(), g.data_ptr(), st['exp_avg'].data_ptr(), st['exp_avg_sq'].data_ptr(), p.numel())
                     keep.append(g)
+                    plist.append(p)
                 addr = tuple(addr)
                 slot = (id(group), len(plist))
                 capturing = self._cap is not None and self._cap['active']
