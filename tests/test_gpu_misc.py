@@ -206,3 +206,29 @@ def test_model_ema_fast_path_sees_replaced_and_re_pointed_parameters():
     step_and_check('replaced parameter')
     m.head.bias.data = m.head.bias.data + 1.0                                   # same object, new storage
     step_and_check('re-pointed parameter')
+
+
+def test_run_backward_keeps_the_pass_on_the_calling_thread():
+    """engine.run_backward: the Python backward functions of a step run on the thread that asked for the pass (torch's default hands a
+    CUDA graph to a per-device worker thread); gradients are the same either way"""
+    import threading
+    from ofb_amd import engine
+    seen = []
+
+    class Probe(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 2.0
+
+        @staticmethod
+        def backward(ctx, g):
+            seen.append(threading.get_ident())
+            return g * 2.0
+
+    x = torch.randn(8, device='cuda', requires_grad=True)
+    engine.run_backward(Probe.apply(x).sum())
+    g1 = x.grad.clone()
+    x.grad = None
+    Probe.apply(x).sum().backward()
+    assert seen[0] == threading.get_ident() and (engine._BACKWARD_ON_CALLER is False or seen[1] != seen[0])
+    assert torch.equal(g1, x.grad) and torch.equal(g1, torch.full_like(g1, 2.0))
