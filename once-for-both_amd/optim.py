@@ -73,9 +73,10 @@ class AdamW(Optimizer):
                 lst.append((p, g, st))
             b1, b2 = group['betas']
             for step, triples in by_step.items():
-                # the device-side tensor table of a launch is kept while every address in it stays what it was (parameters and moments
-                # live on; the caching allocator hands the gradients of a steady-state step the blocks of the step before): no
-                # table build, no upload.  While a capture is being recorded every launch gets a table of its own.
+                # the device-side tensor table of a launch is kept while every address in it stays what it was: no table build, no upload.
+                # That needs gradients at FIXED addresses (the data-parallel buckets' slots, gradients written in place) - plain
+                # autograd gradients get a different permutation of the caching allocator's blocks every step and rebuild the table
+                # (scripts/lab/table_reuse_count.py: 0 reuses in 20 steps).  While a capture is recorded every launch gets its own.
                 keep, maxn, addr, plist = [], 0, [], []
                 for p, g, st in triples:
                     if not g.is_contiguous():
